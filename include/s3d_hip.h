@@ -1,0 +1,202 @@
+/* s3d_hip.h -- C ABI of libs3d_hip.so: the MI355X (gfx950) kernels of the Simple3D-Former training hot path.
+ *
+ * The reference (VITA-Group/Simple3D-Former) is pure Python on PyTorch + timm and has no FFI of its own; each entry
+ * point below names the reference operator it replaces (paths relative to the reference repository root) and is what
+ * a ctypes / cffi binding on the reference side would bind (INTEGRATION.md shows that stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator in the
+ *     shipped host code).  The library never allocates or frees device memory and keeps no global state besides a
+ *     per-process error string.
+ *   - every call only ENQUEUES work on `stream` (no synchronisation, graph-capture safe).
+ *   - return value 0 = success; non-zero = failure, text via s3d_last_error_string().  Never aborts.
+ *   - bf16 tensors are passed as uint16_t*.  "hi/lo" pairs are split-bf16 planes: x ~= hi + lo;
+ *     lo may be NULL wherever documented (plain-bf16 mode).
+ *   - matrices are row-major; ld* are row pitches in ELEMENTS.
+ */
+#ifndef S3D_HIP_H
+#define S3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* s3d_stream_t; /* hipStream_t */
+
+/* ------------------------------------------------------------------------------------------------ library */
+int s3d_version(void);                       /* 10000*major + 100*minor + patch */
+const char* s3d_last_error_string(void);
+size_t s3d_sizeof(const char* struct_name);  /* ABI self-check for foreign-language mirrors; 0 if unknown */
+
+/* ------------------------------------------------------------------------------------------------ GEMM
+ * Replaces every nn.Linear / Conv-as-GEMM contraction of the path: timm Attention.qkv / .proj and Mlp.fc1 / .fc2
+ * (timm==0.3.2, called from models/vit_3d_2d_pretrain.py:466-468), Conv3d patchify of
+ * models/embed_layer_3d_modality.py:160-161,175 and their autograd backward (train_cls_voxel.py:287). */
+enum S3dGemmEpi {
+    S3D_EPI_BF16_BIAS = 0, S3D_EPI_GELU = 1, S3D_EPI_RESID = 2, S3D_EPI_TOKEN = 3, S3D_EPI_F32 = 4,
+    S3D_EPI_DGELU = 5, S3D_EPI_ATOMIC = 6, S3D_EPI_RELU = 7, S3D_EPI_DRELU = 8
+};
+typedef struct S3dGemmArgs {
+    const uint16_t* A_hi; const uint16_t* A_lo; long lda;
+    const uint16_t* B_hi; const uint16_t* B_lo; long ldb;
+    int M, N, K;
+    int kchunk;                       /* filled by the library */
+    const float* bias;
+    const float* R; long ldr;
+    float* C; long ldc;
+    uint16_t* O_hi; uint16_t* O_lo; long ldo;
+    uint16_t* aux; long ldaux;
+    float alpha;
+    const float* cls; const float* pos; int ntok;
+    float* bias_grad;
+} S3dGemmArgs;
+/* ta / tb: operand stored k-major.  (0,0) forward "x @ W^T"; (0,1) dgrad "dy @ W"; (1,1) wgrad "dy^T @ x" (split-K,
+ * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
+int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ LayerNorm
+ * nn.LayerNorm(eps=1e-6) of timm Block.norm1/.norm2 and VisionTransformer.norm (vit_3d_2d_pretrain.py:287,469). */
+typedef struct S3dLnArgs {
+    const float* x; long ldx;
+    long rows; int D; float eps;
+    const float* gamma; const float* beta;
+    uint16_t* out_hi; uint16_t* out_lo; float* out_f32; long ldo;
+    float* mean; float* rstd;
+} S3dLnArgs;
+typedef struct S3dLnBwdArgs {
+    const float* dy; long lddy;
+    const float* x; long ldx;
+    const float* mean; const float* rstd; const float* gamma;
+    const float* dres; long lddres;
+    float* dx; long lddx;
+    uint16_t* dx_bf; long lddxbf;
+    float* dgamma; float* dbeta;
+    long rows; int D;
+} S3dLnBwdArgs;
+int s3d_layernorm_fwd(const S3dLnArgs* args, s3d_stream_t stream);
+int s3d_layernorm_bwd(const S3dLnBwdArgs* args, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ attention
+ * softmax(q k^T * hd^-0.5) v of timm Attention.forward (math restated at visualize_attention_map_voxel.py:125-138)
+ * and of nn.MultiheadAttention inside group_embed (vit_3d_2d_pretrain.py:381,479; seq-first: sb=1, st=Nb). */
+typedef struct S3dAttnArgs {
+    const uint16_t* qkv_hi; const uint16_t* qkv_lo; long ld;
+    uint16_t* out_hi; uint16_t* out_lo; long ldo;
+    float* lse;
+    int Bb, H, N, D;
+    long sb, st;
+    float scale;
+    const uint16_t* dout; long lddo;
+    uint16_t* dqkv; long lddq;
+    float* delta;
+} S3dAttnArgs;
+int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
+int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ tokenizers
+ * VoxelEmbed.forward (embed_layer_3d_modality.py:170-177), VoxelNaiveProjection.forward (:202-209),
+ * VoxelEmbed_no_average.forward (:63-70): s3d_voxel_fold gathers the grid into the patch-GEMM operand
+ * (mode 0: z-folded sum, the mean is applied as alpha=1/P in the GEMM epilogue; 1: clamp(sum_z); 2: plain patches,
+ * rows b*(P^3+1)+1+idx; 3: plain patches, rows grouped '(b px py) pz' with a cls slot per group, :474-476).
+ * Token assembly (cls concat + positional add, vit_3d_2d_pretrain.py:458-466) is the S3D_EPI_TOKEN GEMM epilogue. */
+typedef struct S3dFoldArgs {
+    const float* x;
+    uint16_t* a_hi; uint16_t* a_lo; long lda;
+    int B, V, c, P, mode;
+} S3dFoldArgs;
+int s3d_voxel_fold(const S3dFoldArgs* args, s3d_stream_t stream);
+
+typedef struct S3dPosGradArgs {
+    const float* dx; long groups; int ntok, D;
+    float* dpos; float* dcls; float* dbias;
+} S3dPosGradArgs;
+int s3d_token_grads(const S3dPosGradArgs* args, s3d_stream_t stream);
+
+int s3d_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, long rows, long cols, long ld_out, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ head + loss
+ * voxel_head = nn.Linear (vit_3d_2d_pretrain.py:364) or AMSoftmaxLayer.forward (:50-56);
+ * F.cross_entropy(pred, cls_idx[, weight]) (train_cls_voxel.py:282-285). */
+typedef struct S3dHeadArgs {
+    const float* feat; int B, D, C;
+    const float* W; const float* bias;
+    float* logits;
+    int am_softmax; float am_scale;
+    const float* dlogits; float* dfeat; float* dW; float* dbias;
+    float* scratch;
+} S3dHeadArgs;
+int s3d_head_fwd(const S3dHeadArgs* args, s3d_stream_t stream);
+int s3d_head_bwd(const S3dHeadArgs* args, s3d_stream_t stream);
+
+typedef struct S3dCeArgs {
+    const float* logits; const long long* target; const float* weight;
+    long rows; int C;
+    float* loss;
+    float* dlogits;
+    float grad_scale;
+} S3dCeArgs;
+int s3d_cross_entropy(const S3dCeArgs* args, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ optimizer
+ * torch.optim.Adam(model.parameters(), lr) .step() (train_cls_voxel.py:195,288) over a flat parameter arena; also
+ * refreshes the split-bf16 weight planes and (optionally) zeroes the gradients (optimizer.zero_grad(), :277). */
+typedef struct S3dAdamState {
+    float lr, beta1, beta2, eps;
+    float grad_scale;
+    float step_size, bc2_sqrt;
+    int step;
+    int pad;
+} S3dAdamState;
+int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
+                  int zero_grad, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ timm Block
+ * One pre-norm transformer block: x += attn(norm1(x)); x += mlp(norm2(x))  (timm==0.3.2 Block.forward, invoked by
+ * `for blk in self.blocks: x = blk(x)` at vit_3d_2d_pretrain.py:467-468,481-482,493-494) and its backward. */
+typedef struct S3dBlockShape {
+    int Bb, N, D, H, hidden;      /* sequences, tokens per sequence, model dim, heads, MLP hidden */
+    float eps;
+    int split;                    /* 1: split-bf16 forward (default), 0: plain bf16 */
+} S3dBlockShape;
+typedef struct S3dBlockParams {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
+    const uint16_t *qkv_w_hi, *qkv_w_lo, *proj_w_hi, *proj_w_lo, *fc1_w_hi, *fc1_w_lo, *fc2_w_hi, *fc2_w_lo;
+} S3dBlockParams;
+typedef struct S3dBlockGrads {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
+} S3dBlockGrads;
+typedef struct S3dBlockActs {     /* written by forward, read by backward; M = Bb*N rows */
+    float *x_in, *x_mid, *x_out;                  /* fp32 residual stream [M][D] */
+    float *mean1, *rstd1, *mean2, *rstd2;         /* [M] */
+    float *lse;                                   /* [Bb*H*N] */
+    uint16_t *xn1_hi, *xn1_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *xn2_hi, *xn2_lo;
+    uint16_t *hpre, *hact_hi, *hact_lo;           /* [M][hidden] */
+} S3dBlockActs;
+typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
+    float* dxn;                                   /* [M][D] */
+    float *dx_a, *dx_b;                           /* ping-pong residual gradients [M][D] */
+    uint16_t *dx_a_bf, *dx_b_bf;                  /* bf16 copies */
+    uint16_t* dh;                                 /* [M][hidden] */
+    uint16_t* dqkv;                               /* [M][3D] */
+    uint16_t* datt;                               /* [M][D] */
+    float* delta;                                 /* [Bb*H*N] */
+} S3dBlockScratch;
+int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
+                  s3d_stream_t stream);
+/* in: d(x_out) in scratch->dx_a (+ bf16 copy dx_a_bf); out: d(x_in) in scratch->dx_a / dx_a_bf again. */
+int s3d_block_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockGrads* grads,
+                  const S3dBlockActs* acts, const S3dBlockScratch* scratch, s3d_stream_t stream);
+/* depth consecutive blocks (acts[i].x_out must alias acts[i+1].x_in); backward runs i = depth-1 .. 0. */
+int s3d_blocks_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts, int depth,
+                   s3d_stream_t stream);
+int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockGrads* grads,
+                   const S3dBlockActs* acts, const S3dBlockScratch* scratch, int first, int last,
+                   s3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S3D_HIP_H */

@@ -1,0 +1,9 @@
+// Attention launchers (see attention.hip).  Argument block = public C-ABI struct (include/s3d_hip.h):
+//   qkv [rows][ld]: q | k | v column blocks of D, head-major inside; row(b, t) = b*sb + t*st
+//   (timm: sb=N, st=1; seq-first encoder layer: sb=1, st=Nb); lse/delta [Bb*H][N].
+#pragma once
+#include "common.h"
+#include "s3d_hip.h"
+typedef S3dAttnArgs AttnArgs;
+int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s);
+int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s);

@@ -1,0 +1,453 @@
+// Multi-head attention for gfx950 (MI355X), flash-style, one wave per (batch, head, 32-row tile),
+// v_mfma_f32_32x32x16_bf16.  Works for any token count N and head dims 64 / 192 / 256:
+//   cfg-1/2  N=26  hd=64      cfg-3  N=15 / 197, hd=256 and the seq-first encoder layer (N = B*P*P, hd=192)
+//   cfg-4/5  N=257 / 513, hd=64
+//
+// Layout trick ("swapped" product): the score tile is computed transposed, S^T[key][query] = K . Q^T, so that in
+// the MFMA C/D layout (col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)) every lane owns ONE query column:
+// row max / row sum / online rescale are lane-local (16 registers + one cross-half shuffle).  The probabilities
+// are then already in B-operand layout for O^T[d][query] = V^T . P^T, whose k-slots are the 8 keys a lane holds
+// per 16-key step; the matching A operand (V^T) is gathered from an LDS-staged [32 keys][hd] tile.
+//
+// Forward runs in split-bf16 (hi + lo planes, three MFMAs per product) so logits stay within 1e-3 of the fp32
+// reference; backward runs in plain bf16 on the hi planes.
+#include "attention.h"
+
+namespace {
+
+__device__ __forceinline__ int slot_key(int s2, int h2, int j) {   // key (or query) index of k-slot (s2, lane-half, j)
+    return (j & 3) + 8 * (2 * s2 + (j >> 2)) + 4 * h2;
+}
+__device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
+
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p, bool ok) {
+    U128 u;
+    u.u = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    return u.v;
+}
+
+// cooperative (one wave) copy of a [32 rows][HD] bf16 tile into this wave's LDS region (row pitch HD*2 bytes)
+template <int HD>
+__device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld, long row0_off, long st_ld, int t0,
+                                           int N, int lane) {
+    constexpr int CPR = HD / 8;                 // 16-byte chunks per row
+#pragma unroll
+    for (int i = 0; i < (32 * CPR) / 64; ++i) {
+        const int c = lane + 64 * i;
+        const int r = c / CPR, cc = c % CPR;
+        const int t = t0 + r;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (t < N) v = *reinterpret_cast<const uint4*>(g + row0_off + (long)t * st_ld + cc * 8);
+        *reinterpret_cast<uint4*>(lds + r * HD + cc * 8) = v;
+    }
+}
+
+template <int HD>
+__device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2, int col) {
+    U128 u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u.h[j] = lds[slot_key(s2, h2, j) * HD + col];
+    return u.v;
+}
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------- forward
+template <int HD, bool SPLIT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = HD / 32, NPL = SPLIT ? 2 : 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    bf16_t* ldsV = reinterpret_cast<bf16_t*>(smem) + wave * (NPL * 32 * HD);
+
+    const int QT = (p.N + 31) / 32;
+    const long W = (long)p.Bb * p.H * QT;
+    long item = (long)blockIdx.x * 4 + wave;
+    const bool active = item < W;
+    if (!active) item = W - 1;
+    const int qt = (int)(item % QT);
+    const int bh = (int)(item / QT);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;           // + t*st_ld + which*D + d
+    const int q0 = qt * 32, qrow = q0 + l31;
+    const bool qok = qrow < p.N;
+
+    bf16x8 qh[NS], ql[SPLIT ? NS : 1];
+    {
+        const long off = base + (long)qrow * st_ld + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qh[s] = ld_frag(p.qkv_hi + off + 16 * s, qok);
+            if constexpr (SPLIT) ql[s] = ld_frag(p.qkv_lo + off + 16 * s, qok);
+        }
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    const int KT = (p.N + 31) / 32;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = kt * 32;
+        __syncthreads();                                          // previous tile's LDS reads are done
+        stage_tile<HD>(ldsV, p.qkv_hi, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
+        if constexpr (SPLIT) stage_tile<HD>(ldsV + 32 * HD, p.qkv_lo, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
+
+        const int krow = k0 + l31;
+        const bool kok = krow < p.N;
+        const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bf16x8 kh = ld_frag(p.qkv_hi + koff + 16 * s, kok);
+            if constexpr (SPLIT) {
+                const bf16x8 kl = ld_frag(p.qkv_lo + koff + 16 * s, kok);
+                sacc = MFMA32(kl, qh[s], sacc);
+                sacc = MFMA32(kh, ql[s], sacc);
+            }
+            sacc = MFMA32(kh, qh[s], sacc);
+        }
+        float sv[16], mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (k0 + acc_row(r, h2)) < p.N;
+            sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
+            mloc = fmaxf(mloc, sv[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m_i, mloc);                      // finite: every key tile holds >= 1 valid key
+        const float alpha = expf(m_i - mnew);                     // exp(-inf) = 0 on the first tile
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sv[r] = expf(sv[r] - mnew);                           // invalid keys: exp(-inf) = 0
+            lsum += sv[r];
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_i = l_i * alpha + lsum;
+        m_i = mnew;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        U128 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hi, lo;
+                split_bf16(sv[8 * s2 + j], hi, lo);
+                ph[s2].h[j] = hi;
+                pl[s2].h[j] = lo;
+            }
+        __syncthreads();                                          // V tile is staged
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 vh = gather_frag<HD>(ldsV, s2, h2, d * 32 + l31);
+                if constexpr (SPLIT) {
+                    const bf16x8 vl = gather_frag<HD>(ldsV + 32 * HD, s2, h2, d * 32 + l31);
+                    o[d] = MFMA32(vl, ph[s2].v, o[d]);
+                    o[d] = MFMA32(vh, pl[s2].v, o[d]);
+                }
+                o[d] = MFMA32(vh, ph[s2].v, o[d]);
+            }
+    }
+
+    if (active && qok) {
+        const float inv = 1.0f / l_i;
+        const long orow = ((long)b * p.sb + (long)qrow * p.st) * p.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                          // rows 8c + 4*h2 + {0..3}: 4 consecutive d
+                union { uint2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split_bf16(o[d][4 * c + i] * inv, hi.h[i], lo.h[i]);
+                const long off = orow + d * 32 + 8 * c + 4 * h2;
+                *reinterpret_cast<uint2*>(p.out_hi + off) = hi.u;
+                if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
+            }
+        if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i + logf(l_i);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dQ (+ delta)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = HD / 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    bf16_t* ldsK = reinterpret_cast<bf16_t*>(smem) + wave * (32 * HD);
+
+    const int QT = (p.N + 31) / 32;
+    const long W = (long)p.Bb * p.H * QT;
+    long item = (long)blockIdx.x * 4 + wave;
+    const bool active = item < W;
+    if (!active) item = W - 1;
+    const int qt = (int)(item % QT);
+    const int bh = (int)(item / QT);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int q0 = qt * 32, qrow = q0 + l31;
+    const bool qok = qrow < p.N;
+    const long tokrow = (long)b * p.sb + (long)qrow * p.st;
+
+    bf16x8 qf[NS], dof[NS];
+    float delta = 0.f;
+    {
+        const long off = base + (long)qrow * st_ld + h2 * 8;
+        const long doff = tokrow * p.lddo + h * HD + h2 * 8;
+        const long ooff = tokrow * p.ldo + h * HD + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qf[s] = ld_frag(p.qkv_hi + off + 16 * s, qok);
+            dof[s] = ld_frag(p.dout + doff + 16 * s, qok);
+            U128 a, ol, d;
+            a.v = ld_frag(p.out_hi + ooff + 16 * s, qok);
+            ol.v = ld_frag(p.out_lo ? p.out_lo + ooff + 16 * s : p.out_hi, qok && p.out_lo != nullptr);
+            d.v = dof[s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + bf2f(ol.h[j]));
+        }
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    const float lse_q = qok ? p.lse[(long)bh * p.N + qrow] : 0.f;
+    if (active && qok && h2 == 0) p.delta[(long)bh * p.N + qrow] = delta;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    const int KT = (p.N + 31) / 32;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = kt * 32;
+        __syncthreads();
+        stage_tile<HD>(ldsK, p.qkv_hi, p.ld, base + p.D, st_ld, k0, p.N, lane);
+        const int krow = k0 + l31;
+        const bool kok = krow < p.N;
+        const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
+        const long voff = base + 2 * p.D + (long)krow * st_ld + h2 * 8;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sacc = MFMA32(ld_frag(p.qkv_hi + koff + 16 * s, kok), qf[s], sacc);      // S^T  = K . Q^T
+            dpacc = MFMA32(ld_frag(p.qkv_hi + voff + 16 * s, kok), dof[s], dpacc);   // dP^T = V . dO^T
+        }
+        U128 dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j;
+                const bool ok = (k0 + acc_row(r, h2)) < p.N;
+                const float pr = ok ? expf(sacc[r] * p.scale - lse_q) : 0.f;
+                dsf[s2].h[j] = f2bf(pr * (dpacc[r] - delta) * p.scale);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                dq[d] = MFMA32(gather_frag<HD>(ldsK, s2, h2, d * 32 + l31), dsf[s2].v, dq[d]);   // dQ^T = K^T . dS^T
+    }
+    if (active && qok) {
+        const long orow = tokrow * p.lddq + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
+                *reinterpret_cast<uint2*>(p.dqkv + orow + d * 32 + 8 * c + 4 * h2) = v.u;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- backward: dK, dV
+// DSPLIT > 1 splits the output d-range of dK/dV over blockIdx.y (register budget at hd = 256).
+template <int HD, int DSPLIT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = HD / 32 / DSPLIT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    bf16_t* ldsQ = reinterpret_cast<bf16_t*>(smem) + wave * (2 * 32 * HD);
+    bf16_t* ldsDO = ldsQ + 32 * HD;
+    const int dblk0 = blockIdx.y * NDB;
+
+    const int KT = (p.N + 31) / 32;
+    const long W = (long)p.Bb * p.H * KT;
+    long item = (long)blockIdx.x * 4 + wave;
+    const bool active = item < W;
+    if (!active) item = W - 1;
+    const int kt = (int)(item % KT);
+    const int bh = (int)(item / KT);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int k0 = kt * 32, krow = k0 + l31;
+    const bool kok = krow < p.N;
+
+    bf16x8 kf[NS], vf[NS];
+    {
+        const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kf[s] = ld_frag(p.qkv_hi + koff + 16 * s, kok);
+            vf[s] = ld_frag(p.qkv_hi + koff + p.D + 16 * s, kok);
+        }
+    }
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+    const long dobase = (long)b * p.sb * p.lddo + h * HD;
+    const long st_lddo = p.st * p.lddo;
+    const int QT = (p.N + 31) / 32;
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q0 = qt * 32;
+        __syncthreads();
+        stage_tile<HD>(ldsQ, p.qkv_hi, p.ld, base, st_ld, q0, p.N, lane);
+        stage_tile<HD>(ldsDO, p.dout, p.lddo, dobase, st_lddo, q0, p.N, lane);
+        const int qrow = q0 + l31;
+        const bool qok = qrow < p.N;
+        const long qoff = base + (long)qrow * st_ld + h2 * 8;
+        const long dooff = dobase + (long)qrow * st_lddo + h2 * 8;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sacc = MFMA32(ld_frag(p.qkv_hi + qoff + 16 * s, qok), kf[s], sacc);     // S  = Q . K^T   (col = key)
+            dpacc = MFMA32(ld_frag(p.dout + dooff + 16 * s, qok), vf[s], dpacc);    // dP = dO . V^T
+        }
+        U128 pf[2], dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j;
+                const int q = q0 + acc_row(r, h2);
+                const bool ok = kok && (q < p.N);
+                const float lse_r = ok ? p.lse[(long)bh * p.N + q] : 0.f;
+                const float del_r = ok ? p.delta[(long)bh * p.N + q] : 0.f;
+                const float pr = ok ? expf(sacc[r] * p.scale - lse_r) : 0.f;
+                pf[s2].h[j] = f2bf(pr);
+                dsf[s2].h[j] = f2bf(pr * (dpacc[r] - del_r) * p.scale);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int col = (dblk0 + d) * 32 + l31;
+                dv[d] = MFMA32(gather_frag<HD>(ldsDO, s2, h2, col), pf[s2].v, dv[d]);    // dV^T = dO^T . P
+                dk[d] = MFMA32(gather_frag<HD>(ldsQ, s2, h2, col), dsf[s2].v, dk[d]);    // dK^T = Q^T . dS
+            }
+    }
+    if (active && kok) {
+        const long orow = ((long)b * p.sb + (long)krow * p.st) * p.lddq + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } a, v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
+                const long off = orow + (dblk0 + d) * 32 + 8 * c + 4 * h2;
+                *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
+                *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
+            }
+    }
+}
+
+template <typename K>
+void set_lds(K kern, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <int HD>
+int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
+    const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
+    dim3 grid((unsigned)((W + 3) / 4));
+    if (split) {
+        const int lds = 4 * 2 * 32 * HD * 2;
+        set_lds(attn_fwd_kernel<HD, true>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), lds, s, a);
+    } else {
+        const int lds = 4 * 32 * HD * 2;
+        set_lds(attn_fwd_kernel<HD, false>, lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), lds, s, a);
+    }
+    S3D_CHECK_LAUNCH("attention_fwd");
+    return 0;
+}
+
+template <int HD, int DSPLIT>
+int bwd_hd(const AttnArgs& a, hipStream_t s) {
+    const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
+    dim3 grid((unsigned)((W + 3) / 4));
+    {
+        const int lds = 4 * 32 * HD * 2;
+        set_lds(attn_bwd_dq_kernel<HD>, lds);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(256), lds, s, a);
+        S3D_CHECK_LAUNCH("attention_bwd_dq");
+    }
+    {
+        const int lds = 4 * 2 * 32 * HD * 2;
+        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, lds);
+        dim3 g2(grid.x, DSPLIT);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+        S3D_CHECK_LAUNCH("attention_bwd_dkv");
+    }
+    return 0;
+}
+
+int check(const AttnArgs& a) {
+    S3D_REQUIRE(a.H > 0 && a.D % a.H == 0, "attention: D=%d not divisible by H=%d", a.D, a.H);
+    const int hd = a.D / a.H;
+    S3D_REQUIRE(hd == 64 || hd == 192 || hd == 256, "attention: head dim %d not built (64/192/256)", hd);
+    S3D_REQUIRE(a.N > 0 && a.Bb > 0, "attention: empty problem");
+    S3D_REQUIRE(a.ld % 8 == 0 && a.ldo % 8 == 0, "attention: leading dims must be multiples of 8");
+    return 0;
+}
+
+}  // namespace
+
+int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s) {
+    if (int e = check(a)) return e;
+    if (split) S3D_REQUIRE(a.qkv_lo != nullptr, "attention: split mode needs the lo plane");
+    switch (a.D / a.H) {
+        case 64: return fwd_hd<64>(a, split, s);
+        case 192: return fwd_hd<192>(a, split, s);
+        default: return fwd_hd<256>(a, split, s);
+    }
+}
+
+int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
+    if (int e = check(a)) return e;
+    S3D_REQUIRE(a.lddo % 8 == 0 && a.lddq % 8 == 0, "attention: leading dims must be multiples of 8");
+    switch (a.D / a.H) {
+        case 64: return bwd_hd<64, 1>(a, s);
+        case 192: return bwd_hd<192, 2>(a, s);
+        default: return bwd_hd<256, 2>(a, s);
+    }
+}

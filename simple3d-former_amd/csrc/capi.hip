@@ -1,0 +1,220 @@
+// extern "C" surface of libs3d_hip.so (include/s3d_hip.h) + the per-block launch sequences.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "attention.h"
+#include "gemm.h"
+#include "kernels.h"
+#include "s3d_hip.h"
+
+static thread_local char g_err[512] = "";
+
+void s3d_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+#define S3D_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != 0) return rc__; \
+    } while (0)
+
+static inline hipStream_t st(s3d_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---------------------------------------------------------------------------------------------- block sequences
+namespace {
+
+GemmArgs gemm_zero() {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.alpha = 1.f;
+    return g;
+}
+
+int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockActs& a, hipStream_t s) {
+    const long M = (long)sh.Bb * sh.N;
+    const int D = sh.D, Hd = sh.hidden;
+    const bool split = sh.split != 0;
+    S3D_REQUIRE(M < (1L << 31), "block: too many rows");
+    // 1. norm1
+    LnArgs ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = a.x_in; ln.ldx = D; ln.rows = M; ln.D = D; ln.eps = sh.eps; ln.gamma = p.ln1_w; ln.beta = p.ln1_b;
+    ln.out_hi = a.xn1_hi; ln.out_lo = split ? a.xn1_lo : nullptr; ln.ldo = D; ln.mean = a.mean1; ln.rstd = a.rstd1;
+    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    // 2. qkv = xn1 @ Wqkv^T + b
+    GemmArgs g = gemm_zero();
+    g.A_hi = a.xn1_hi; g.A_lo = a.xn1_lo; g.lda = D; g.B_hi = p.qkv_w_hi; g.B_lo = p.qkv_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = 3 * D; g.K = D; g.bias = p.qkv_b; g.O_hi = a.qkv_hi; g.O_lo = split ? a.qkv_lo : nullptr; g.ldo = 3 * D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_BF16_BIAS, g, 1, s));
+    // 3. attention
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = split ? a.att_lo : nullptr;
+    at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    S3D_TRY(s3d_launch_attention_fwd(at, split, s));
+    // 4. x_mid = x_in + att @ Wproj^T + b
+    g = gemm_zero();
+    g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = D; g.K = D; g.bias = p.proj_b; g.R = a.x_in; g.ldr = D; g.C = a.x_mid; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    // 5. norm2
+    ln.x = a.x_mid; ln.gamma = p.ln2_w; ln.beta = p.ln2_b; ln.out_hi = a.xn2_hi; ln.out_lo = split ? a.xn2_lo : nullptr;
+    ln.mean = a.mean2; ln.rstd = a.rstd2;
+    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    // 6. h = gelu(xn2 @ W1^T + b1)
+    g = gemm_zero();
+    g.A_hi = a.xn2_hi; g.A_lo = a.xn2_lo; g.lda = D; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = Hd; g.O_hi = a.hact_hi;
+    g.O_lo = split ? a.hact_lo : nullptr; g.ldo = Hd;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_GELU, g, 1, s));
+    // 7. x_out = x_mid + h @ W2^T + b2
+    g = gemm_zero();
+    g.A_hi = a.hact_hi; g.A_lo = a.hact_lo; g.lda = Hd; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd;
+    g.M = (int)M; g.N = D; g.K = Hd; g.bias = p.fc2_b; g.R = a.x_mid; g.ldr = D; g.C = a.x_out; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    return 0;
+}
+
+// wgrad helper: dW[out][in] += dy^T x  (dy [M][out] bf16, x [M][in] bf16), db[out] += colsum(dy)
+int wgrad(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db, hipStream_t s) {
+    GemmArgs g = gemm_zero();
+    g.A_hi = dy; g.lda = out; g.B_hi = x; g.ldb = in; g.M = out; g.N = in; g.K = (int)M; g.C = dW; g.ldc = in;
+    g.bias_grad = db;
+    return s3d_launch_gemm(true, true, false, EPI_ATOMIC, g, 0, s);
+}
+
+int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
+              const S3dBlockScratch& w, hipStream_t s) {
+    const long M = (long)sh.Bb * sh.N;
+    const int D = sh.D, Hd = sh.hidden;
+    // ---- MLP branch: d(x_out) is in dx_a / dx_a_bf
+    S3D_TRY(wgrad(w.dx_a_bf, D, a.hact_hi, Hd, M, gr.fc2_w, gr.fc2_b, s));
+    GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)
+    g.A_hi = w.dx_a_bf; g.lda = D; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M; g.N = Hd; g.K = D;
+    g.aux = a.hpre; g.ldaux = Hd; g.O_hi = w.dh; g.ldo = Hd;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DGELU, g, 1, s));
+    S3D_TRY(wgrad(w.dh, Hd, a.xn2_hi, D, M, gr.fc1_w, gr.fc1_b, s));
+    g = gemm_zero();            // dxn2 = dh @ W1
+    g.A_hi = w.dh; g.lda = Hd; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+    LnBwdArgs lb;
+    memset(&lb, 0, sizeof(lb));
+    lb.dy = w.dxn; lb.lddy = D; lb.x = a.x_mid; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
+    lb.dres = w.dx_a; lb.lddres = D; lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D;
+    lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M; lb.D = D;
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
+    S3D_TRY(wgrad(w.dx_b_bf, D, a.att_hi, D, M, gr.proj_w, gr.proj_b, s));
+    g = gemm_zero();            // datt = dx_mid @ Wproj
+    g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_BF16_BIAS, g, 1, s));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
+    at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+    S3D_TRY(s3d_launch_attention_bwd(at, s));
+    S3D_TRY(wgrad(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b, s));
+    g = gemm_zero();            // dxn1 = dqkv @ Wqkv
+    g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+    lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = w.dx_b; lb.dx = w.dx_a;
+    lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- extern "C"
+extern "C" {
+
+int s3d_version(void) { return 100; }
+const char* s3d_last_error_string(void) { return g_err; }
+
+size_t s3d_sizeof(const char* n) {
+#define SZ(T) if (strcmp(n, #T) == 0) return sizeof(T)
+    SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
+    SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
+    SZ(S3dBlockActs); SZ(S3dBlockScratch);
+#undef SZ
+    return 0;
+}
+
+int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int splitk, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");
+    return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));
+}
+int s3d_layernorm_fwd(const S3dLnArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_layernorm_fwd: null args");
+    return s3d_launch_ln_fwd(*a, st(s));
+}
+int s3d_layernorm_bwd(const S3dLnBwdArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_layernorm_bwd: null args");
+    return s3d_launch_ln_bwd(*a, st(s));
+}
+int s3d_attention_fwd(const S3dAttnArgs* a, int split, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_attention_fwd: null args");
+    return s3d_launch_attention_fwd(*a, split != 0, st(s));
+}
+int s3d_attention_bwd(const S3dAttnArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_attention_bwd: null args");
+    return s3d_launch_attention_bwd(*a, st(s));
+}
+int s3d_voxel_fold(const S3dFoldArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_voxel_fold: null args");
+    return s3d_launch_fold(*a, st(s));
+}
+int s3d_token_grads(const S3dPosGradArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_token_grads: null args");
+    return s3d_launch_posgrad(*a, st(s));
+}
+int s3d_split_bf16(const float* src, uint16_t* hi, uint16_t* lo, long rows, long cols, long ld, s3d_stream_t s) {
+    return s3d_launch_split(src, hi, lo, rows, cols, ld, st(s));
+}
+int s3d_head_fwd(const S3dHeadArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_head_fwd: null args");
+    return s3d_launch_head_fwd(*a, st(s));
+}
+int s3d_head_bwd(const S3dHeadArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_head_bwd: null args");
+    return s3d_launch_head_bwd(*a, st(s));
+}
+int s3d_cross_entropy(const S3dCeArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_cross_entropy: null args");
+    return s3d_launch_ce(*a, st(s));
+}
+int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
+                  int zero_grad, s3d_stream_t s) {
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, st(s));
+}
+
+int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && a, "s3d_block_fwd: null args");
+    return block_fwd(*sh, *p, *a, st(s));
+}
+int s3d_block_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockGrads* g, const S3dBlockActs* a,
+                  const S3dBlockScratch* w, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && g && a && w, "s3d_block_bwd: null args");
+    return block_bwd(*sh, *p, *g, *a, *w, st(s));
+}
+int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, int depth, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && a, "s3d_blocks_fwd: null args");
+    for (int i = 0; i < depth; ++i) S3D_TRY(block_fwd(*sh, p[i], a[i], st(s)));
+    return 0;
+}
+int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockGrads* g, const S3dBlockActs* a,
+                   const S3dBlockScratch* w, int first, int last, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && g && a && w, "s3d_blocks_bwd: null args");
+    for (int i = first; i >= last; --i) S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s)));
+    return 0;
+}
+
+}  // extern "C"

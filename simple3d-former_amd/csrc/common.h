@@ -1,0 +1,72 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels of the Simple3D-Former hot path.
+// Wave = 64 lanes everywhere.  bf16 values travel as raw uint16_t in memory.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define S3D_WAVE 64
+
+// ---- bf16 <-> f32 (round-to-nearest-even; inputs are finite in this path) ----
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// split-bf16: x ~= hi + lo with hi = rne(x), lo = rne(x - hi)  (16 mantissa bits in total)
+__device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
+    hi = f2bf(x);
+    lo = f2bf(x - bf2f(hi));
+}
+
+union U128 {
+    uint4 u;
+    bf16x8 v;
+    bf16_t h[8];
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ---- host-side error plumbing (capi.hip owns the storage) ----
+void s3d_set_error(const char* fmt, ...);
+#define S3D_CHECK_LAUNCH(name)                                                         \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            s3d_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
+            return 1;                                                                  \
+        }                                                                              \
+    } while (0)
+#define S3D_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            s3d_set_error(__VA_ARGS__);   \
+            return 2;                     \
+        }                                 \
+    } while (0)

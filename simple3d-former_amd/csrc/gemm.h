@@ -1,0 +1,21 @@
+// bf16 / split-bf16 MFMA GEMM for gfx950: C[M,N] = op(A) * op(B) with fused epilogues (see gemm.hip).
+// The argument block is the public C-ABI struct (include/s3d_hip.h).
+#pragma once
+#include "common.h"
+#include "s3d_hip.h"
+
+enum {
+    EPI_BF16_BIAS = S3D_EPI_BF16_BIAS,  // O_hi/O_lo = split(acc*alpha + bias[n])                     (qkv, generic linear)
+    EPI_GELU = S3D_EPI_GELU,            // pre = acc + bias; aux = bf16(pre); O = split(gelu(pre))    (mlp.fc1)
+    EPI_RESID = S3D_EPI_RESID,          // C = acc + bias[n] + R[m][n]                                (attn.proj, mlp.fc2)
+    EPI_TOKEN = S3D_EPI_TOKEN,          // C = acc*alpha + (m%ntok==0 ? cls[n] : bias[n]) + pos[(m%ntok)*N+n]
+    EPI_F32 = S3D_EPI_F32,              // C = acc*alpha (+ bias[n])                                  (dgrad -> LayerNorm bwd)
+    EPI_DGELU = S3D_EPI_DGELU,          // O_hi = bf16(acc * gelu'(aux[m][n]))                        (mlp.fc2 dgrad)
+    EPI_ATOMIC = S3D_EPI_ATOMIC,        // atomicAdd(C[m][n], acc*alpha); optional bias_grad          (wgrad, split-K)
+    EPI_RELU = S3D_EPI_RELU,            // O = split(relu(acc + bias)), aux = bf16(pre)               (encoder linear1)
+    EPI_DRELU = S3D_EPI_DRELU,          // O_hi = bf16(aux > 0 ? acc : 0)                             (encoder linear2 dgrad)
+};
+typedef S3dGemmArgs GemmArgs;
+
+// ta/tb: operand stored k-major.  splitk <= 0: automatic (wgrad only).  Returns 0 on success.
+int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a, int splitk, hipStream_t stream);

@@ -1,0 +1,342 @@
+// Tiled MFMA GEMM for gfx950 (MI355X): 256 threads = 4 waves (2x2), v_mfma_f32_16x16x32_bf16,
+// BK = 64, double-buffered LDS, register-staged global->LDS copies.
+//
+//   * operands are bf16 planes; SPLIT adds a second ("lo") plane per operand and issues three MFMAs per
+//     product (hi*hi + hi*lo + lo*hi) -> ~16 mantissa bits at bf16 matrix-core rate (forward path),
+//   * "transposed" operands (stored k-major, as they are for dgrad's weights and wgrad's activations) are
+//     transposed in the register stage (pairs of k rows interleaved into 32-bit LDS words), so every
+//     variant reads identical k-contiguous fragments from LDS,
+//   * LDS tile = [rows][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled with (r ^ (r>>3)) & 7 so that
+//     both the direct 16-byte row stores and the transposing 4-byte stores are bank-conflict free and
+//     ds_read_b128 fragment reads are at most 2-way,
+//   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
+#include "gemm.h"
+
+namespace {
+
+template <int BR, bool T>
+struct Stager {
+    static constexpr int CH = BR / 8;                                   // 16-byte chunks along the row axis (T only)
+    static constexpr int NT = T ? (BR * 4 + 255) / 256 : BR / 32;       // tasks per thread
+    static constexpr int NV = T ? 2 * NT : NT;                          // 16-byte vectors per plane per thread
+
+    __device__ static __forceinline__ void load(uint4 (&v)[NV], const bf16_t* __restrict__ base, long ld, int r0,
+                                                int k0, int R, int kend, int tid) {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+        if constexpr (!T) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int r = (tid >> 3) + i * 32, kc = tid & 7;
+                const int gr = r0 + r, gk = k0 + kc * 8;
+                v[i] = (gr < R && gk < kend) ? *reinterpret_cast<const uint4*>(base + (long)gr * ld + gk) : zero;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int q = tid + j * 256;
+                const int rc = q % CH, kp = q / CH;
+                const int gk = k0 + 2 * kp, gr = r0 + rc * 8;
+                const bool ok = (q < CH * 32) && (gr < R);
+                v[2 * j] = (ok && gk < kend) ? *reinterpret_cast<const uint4*>(base + (long)gk * ld + gr) : zero;
+                v[2 * j + 1] =
+                    (ok && gk + 1 < kend) ? *reinterpret_cast<const uint4*>(base + (long)(gk + 1) * ld + gr) : zero;
+            }
+        }
+    }
+
+    __device__ static __forceinline__ void store(const uint4 (&v)[NV], unsigned char* lds, int tid) {
+        if constexpr (!T) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int r = (tid >> 3) + i * 32, kc = tid & 7;
+                const int sw = (r ^ (r >> 3)) & 7;
+                *reinterpret_cast<uint4*>(lds + r * 128 + ((kc ^ sw) << 4)) = v[i];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int q = tid + j * 256;
+                if (q < CH * 32) {
+                    const int rc = q % CH, kp = q / CH;
+                    U128 a, b;
+                    a.u = v[2 * j];
+                    b.u = v[2 * j + 1];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = rc * 8 + i;
+                        const int sw = (i ^ rc) & 7;                    // == (r ^ (r>>3)) & 7
+                        const int off = r * 128 + (((kp >> 2) ^ sw) << 4) + (kp & 3) * 4;
+                        *reinterpret_cast<uint32_t*>(lds + off) = (uint32_t)a.h[i] | ((uint32_t)b.h[i] << 16);
+                    }
+                }
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int r, int kc) {
+    const int sw = (r ^ (r >> 3)) & 7;
+    return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((kc ^ sw) << 4));
+}
+
+template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+    constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
+    constexpr int FM = BM / 32, FN = BN / 32;
+    using SA = Stager<BM, TA>;
+    using SB = Stager<BN, TB>;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int kend = min(p.K, kbeg + p.kchunk);
+    const int ntiles = (kend - kbeg + 63) >> 6;
+
+    uint4 va_hi[SA::NV], vb_hi[SB::NV];
+    uint4 va_lo[SPLIT ? SA::NV : 1], vb_lo[SPLIT ? SB::NV : 1];
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // bias-gradient partials (TN only): row sums of the A operand over k, taken from the staged registers
+    float bsum[TA ? SA::NT : 1][8];
+    const bool want_bsum = TA && (EPI == EPI_ATOMIC) && p.bias_grad != nullptr && blockIdx.x == 0;
+    if constexpr (TA) {
+#pragma unroll
+        for (int j = 0; j < SA::NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bsum[j][i] = 0.f;
+    }
+
+    auto gload = [&](int t) {
+        const int k0 = kbeg + t * 64;
+        SA::load(va_hi, p.A_hi, p.lda, m0, k0, p.M, kend, tid);
+        SB::load(vb_hi, p.B_hi, p.ldb, n0, k0, p.N, kend, tid);
+        if constexpr (SPLIT) {
+            SA::load(va_lo, p.A_lo, p.lda, m0, k0, p.M, kend, tid);
+            SB::load(vb_lo, p.B_lo, p.ldb, n0, k0, p.N, kend, tid);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* s = smem + buf * STAGE;
+        SA::store(va_hi, s, tid);
+        if constexpr (SPLIT) SA::store(va_lo, s + A_BYTES, tid);
+        SB::store(vb_hi, s + NPL * A_BYTES, tid);
+        if constexpr (SPLIT) SB::store(vb_lo, s + NPL * A_BYTES + B_BYTES, tid);
+        if constexpr (TA) {
+            if (want_bsum) {
+#pragma unroll
+                for (int j = 0; j < SA::NT; ++j) {
+                    U128 a, b;
+                    a.u = va_hi[2 * j];
+                    b.u = va_hi[2 * j + 1];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) bsum[j][i] += bf2f(a.h[i]) + bf2f(b.h[i]);
+                }
+            }
+        }
+    };
+
+    if (ntiles > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const bool more = (t + 1 < ntiles);
+        if (more) gload(t + 1);
+        const unsigned char* s = smem + (t & 1) * STAGE;
+        const unsigned char* sA = s;
+        const unsigned char* sB = s + NPL * A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kc = ks * 4 + (lane >> 4);
+            bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+                a_hi[i] = read_frag(sA, r, kc);
+                if constexpr (SPLIT) a_lo[i] = read_frag(sA + A_BYTES, r, kc);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + (lane & 15);
+                b_hi[j] = read_frag(sB, r, kc);
+                if constexpr (SPLIT) b_lo[j] = read_frag(sB + B_BYTES, r, kc);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) lstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // C/D layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                if (m >= p.M || n >= p.N) continue;
+                float v = acc[i][j][r];
+                if constexpr (EPI == EPI_BF16_BIAS) {
+                    v = v * p.alpha + (p.bias ? p.bias[n] : 0.f);
+                    bf16_t hi, lo;
+                    split_bf16(v, hi, lo);
+                    p.O_hi[(long)m * p.ldo + n] = hi;
+                    if (p.O_lo) p.O_lo[(long)m * p.ldo + n] = lo;
+                } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
+                    v += p.bias[n];
+                    if (p.aux) p.aux[(long)m * p.ldaux + n] = f2bf(v);
+                    const float a = (EPI == EPI_GELU) ? gelu_erf(v) : fmaxf(v, 0.f);
+                    bf16_t hi, lo;
+                    split_bf16(a, hi, lo);
+                    p.O_hi[(long)m * p.ldo + n] = hi;
+                    if (p.O_lo) p.O_lo[(long)m * p.ldo + n] = lo;
+                } else if constexpr (EPI == EPI_RESID) {
+                    p.C[(long)m * p.ldc + n] = v + p.bias[n] + p.R[(long)m * p.ldr + n];
+                } else if constexpr (EPI == EPI_TOKEN) {
+                    const int t = m % p.ntok;
+                    p.C[(long)m * p.ldc + n] = v * p.alpha + (t == 0 ? p.cls[n] : p.bias[n]) + p.pos[(long)t * p.N + n];
+                } else if constexpr (EPI == EPI_F32) {
+                    p.C[(long)m * p.ldc + n] = v * p.alpha + (p.bias ? p.bias[n] : 0.f);
+                } else if constexpr (EPI == EPI_DGELU) {
+                    p.O_hi[(long)m * p.ldo + n] = f2bf(v * gelu_erf_grad(bf2f(p.aux[(long)m * p.ldaux + n])));
+                } else if constexpr (EPI == EPI_DRELU) {
+                    p.O_hi[(long)m * p.ldo + n] = f2bf(bf2f(p.aux[(long)m * p.ldaux + n]) > 0.f ? v : 0.f);
+                } else if constexpr (EPI == EPI_ATOMIC) {
+                    atomic_add_f32(&p.C[(long)m * p.ldc + n], v * p.alpha);
+                }
+            }
+        }
+
+    if constexpr (TA && EPI == EPI_ATOMIC) {
+        if (want_bsum) {   // block-uniform
+            float* red = reinterpret_cast<float*>(smem);
+            __syncthreads();
+            for (int i = tid; i < BM; i += 256) red[i] = 0.f;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < SA::NT; ++j) {
+                const int q = tid + j * 256;
+                if (q < SA::CH * 32) {
+                    const int rc = q % SA::CH;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) atomicAdd(&red[rc * 8 + i], bsum[j][i]);
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < BM; i += 256)
+                if (m0 + i < p.M) atomic_add_f32(&p.bias_grad[m0 + i], red[i] * p.alpha);
+        }
+    }
+}
+
+template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
+int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
+    constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int LDS = 2 * NPL * (BM + BN) * 128;
+    static bool attr_set = false;
+    auto kern = gemm_kernel<BM, BN, TA, TB, SPLIT, EPI>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splitk);
+    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+    S3D_CHECK_LAUNCH("gemm");
+    return 0;
+}
+
+template <bool TA, bool TB, bool SPLIT, int EPI>
+int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
+    switch (tile) {
+        case 0: return launch_one<32, 64, TA, TB, SPLIT, EPI>(a, splitk, stream);
+        case 1: return launch_one<64, 64, TA, TB, SPLIT, EPI>(a, splitk, stream);
+        default: return launch_one<128, 128, TA, TB, SPLIT, EPI>(a, splitk, stream);
+    }
+}
+
+template <bool SPLIT>
+int launch_nt(int epi, int tile, const GemmArgs& a, hipStream_t s) {
+    switch (epi) {
+        case EPI_BF16_BIAS: return launch_tiles<false, false, SPLIT, EPI_BF16_BIAS>(tile, a, 1, s);
+        case EPI_GELU: return launch_tiles<false, false, SPLIT, EPI_GELU>(tile, a, 1, s);
+        case EPI_RELU: return launch_tiles<false, false, SPLIT, EPI_RELU>(tile, a, 1, s);
+        case EPI_RESID: return launch_tiles<false, false, SPLIT, EPI_RESID>(tile, a, 1, s);
+        case EPI_TOKEN: return launch_tiles<false, false, SPLIT, EPI_TOKEN>(tile, a, 1, s);
+        case EPI_F32: return launch_tiles<false, false, SPLIT, EPI_F32>(tile, a, 1, s);
+        default: s3d_set_error("gemm: epilogue %d not available for NT", epi); return 2;
+    }
+}
+
+}  // namespace
+
+int s3d_gemm_pick_tile(int M, int N, int splitk) {
+    auto count = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splitk; };
+    if (count(128, 128) >= 512) return 2;
+    if (count(64, 64) >= 384) return 1;
+    return 0;
+}
+
+int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in, int splitk, hipStream_t stream) {
+    GemmArgs a = a_in;
+    S3D_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
+    S3D_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 (got %ld %ld)", a.lda, a.ldb);
+    if (!ta) S3D_REQUIRE((a.K % 8) == 0, "gemm: K=%d must be a multiple of 8 for a k-contiguous A", a.K);
+    if (!tb) S3D_REQUIRE((a.K % 8) == 0, "gemm: K=%d must be a multiple of 8 for a k-contiguous B", a.K);
+    if (ta) S3D_REQUIRE((a.M % 8) == 0, "gemm: M=%d must be a multiple of 8 for a k-major A", a.M);
+    if (tb) S3D_REQUIRE((a.N % 8) == 0, "gemm: N=%d must be a multiple of 8 for a k-major B", a.N);
+    if (split) S3D_REQUIRE(a.A_lo && a.B_lo, "gemm: split mode needs lo planes");
+
+    if (ta && tb) {   // wgrad: split-K with fp32 atomics
+        S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");
+        if (splitk <= 0) {
+            const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+            splitk = (int)((512 + tiles64 - 1) / tiles64);
+            const int maxk = (a.K + 127) / 128;
+            if (splitk > maxk) splitk = maxk;
+            if (splitk < 1) splitk = 1;
+        }
+        int kchunk = ((a.K + splitk - 1) / splitk + 63) / 64 * 64;
+        splitk = (a.K + kchunk - 1) / kchunk;
+        a.kchunk = kchunk;
+        const int tile = s3d_gemm_pick_tile(a.M, a.N, splitk);
+        return launch_tiles<true, true, false, EPI_ATOMIC>(tile, a, splitk, stream);
+    }
+    a.kchunk = (a.K + 63) / 64 * 64;
+    const int tile = s3d_gemm_pick_tile(a.M, a.N, 1);
+    if (!ta && !tb) return split ? launch_nt<true>(epi, tile, a, stream) : launch_nt<false>(epi, tile, a, stream);
+    if (!ta && tb) {
+        S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
+        switch (epi) {
+            case EPI_F32: return launch_tiles<false, true, false, EPI_F32>(tile, a, 1, stream);
+            case EPI_DGELU: return launch_tiles<false, true, false, EPI_DGELU>(tile, a, 1, stream);
+            case EPI_DRELU: return launch_tiles<false, true, false, EPI_DRELU>(tile, a, 1, stream);
+            case EPI_BF16_BIAS: return launch_tiles<false, true, false, EPI_BF16_BIAS>(tile, a, 1, stream);
+            default: s3d_set_error("gemm: epilogue %d not available for NN", epi); return 2;
+        }
+    }
+    s3d_set_error("gemm: TA without TB is not supported");
+    return 2;
+}

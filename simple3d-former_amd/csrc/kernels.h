@@ -1,0 +1,35 @@
+// Argument blocks + launchers of the non-GEMM kernels (ln.hip, misc.hip).
+#pragma once
+#include "common.h"
+#include "s3d_hip.h"
+
+typedef S3dLnArgs LnArgs;
+typedef S3dLnBwdArgs LnBwdArgs;
+int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s);
+int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+
+// ---- tokenizer patch gather ("fold"): voxel grid -> GEMM A operand (split-bf16 planes) ----
+enum { FOLD_ZMEAN = 0, FOLD_NAIVE = 1, FOLD_PATCH = 2, FOLD_PATCH_GROUP = 3 };
+typedef S3dFoldArgs FoldArgs;
+int s3d_launch_fold(const FoldArgs& a, hipStream_t s);
+
+// d(pos_embed)[t][:] += sum_g dx[g*ntok+t][:], d(cls) += rows t==0, d(conv bias) += rows t>=1
+typedef S3dPosGradArgs PosGradArgs;
+int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s);
+
+// fp32 [rows][cols] -> split-bf16 planes with row pitch ld_out (pad columns untouched)
+int s3d_launch_split(const float* src, bf16_t* hi, bf16_t* lo, long rows, long cols, long ld_out, hipStream_t s);
+
+// ---- classification head (fp32 VALU; tiny) ----
+typedef S3dHeadArgs HeadArgs;
+int s3d_launch_head_fwd(const HeadArgs& a, hipStream_t s);
+int s3d_launch_head_bwd(const HeadArgs& a, hipStream_t s);
+
+// mean cross-entropy (optionally class-weighted) forward + d(logits)
+typedef S3dCeArgs CeArgs;
+int s3d_launch_ce(const CeArgs& a, hipStream_t s);
+
+// ---- fused Adam over a flat fp32 arena (+ split-bf16 shadow planes) ----
+typedef S3dAdamState AdamState;
+int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
+                    int zero_grad, hipStream_t s);

@@ -1,0 +1,143 @@
+// LayerNorm forward / backward for gfx950: one 64-lane wave per row, float4 accesses, fp32 statistics.
+// Forward emits the normalised row as split-bf16 planes (GEMM A operand) and optionally fp32; backward fuses the
+// residual-gradient add, a bf16 copy of dx (operand of the next wgrad/dgrad GEMM) and the gamma/beta gradients.
+#include "kernels.h"
+
+namespace {
+
+constexpr int MAXC = 4;   // float4 chunks per lane -> D <= 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const float* x = p.x + row * p.ldx;
+    float4 v[MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int col = c * 256 + lane * 4;
+        v[c] = (col < p.D) ? *reinterpret_cast<const float4*>(x + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += v[c].x + v[c].y + v[c].z + v[c].w;
+    }
+    const float mean = wave_sum(s) / p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < p.D) {
+            const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+            q += a * a + b * b + cc * cc + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
+    if (lane == 0) {
+        if (p.mean) p.mean[row] = mean;
+        if (p.rstd) p.rstd[row] = rstd;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < p.D) {
+            const float4 g = *reinterpret_cast<const float4*>(p.gamma + col);
+            const float4 b = *reinterpret_cast<const float4*>(p.beta + col);
+            float y[4] = {(v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y,
+                          (v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w};
+            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + row * p.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
+            if (p.out_hi) {
+                union { uint2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split_bf16(y[i], hi.h[i], lo.h[i]);
+                *reinterpret_cast<uint2*>(p.out_hi + row * p.ldo + col) = hi.u;
+                if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + row * p.ldo + col) = lo.u;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);          // [2][4 waves][D]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nw = (long)gridDim.x * 4;
+    float4 dg[MAXC], db[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += nw) {
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        float4 xh[MAXC], g[MAXC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < p.D) {
+                const float4 x = *reinterpret_cast<const float4*>(p.x + row * p.ldx + col);
+                const float4 dy = *reinterpret_cast<const float4*>(p.dy + row * p.lddy + col);
+                const float4 w = *reinterpret_cast<const float4*>(p.gamma + col);
+                xh[c] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+                g[c] = make_float4(dy.x * w.x, dy.y * w.y, dy.z * w.z, dy.w * w.w);
+                s1 += g[c].x + g[c].y + g[c].z + g[c].w;
+                s2 += g[c].x * xh[c].x + g[c].y * xh[c].y + g[c].z * xh[c].z + g[c].w * xh[c].w;
+                dg[c].x += dy.x * xh[c].x; dg[c].y += dy.y * xh[c].y; dg[c].z += dy.z * xh[c].z; dg[c].w += dy.w * xh[c].w;
+                db[c].x += dy.x; db[c].y += dy.y; db[c].z += dy.z; db[c].w += dy.w;
+            }
+        }
+        s1 = wave_sum(s1) / p.D;
+        s2 = wave_sum(s2) / p.D;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int col = c * 256 + lane * 4;
+            if (col < p.D) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.dres) r = *reinterpret_cast<const float4*>(p.dres + row * p.lddres + col);
+                float d[4] = {rstd * (g[c].x - s1 - xh[c].x * s2) + r.x, rstd * (g[c].y - s1 - xh[c].y * s2) + r.y,
+                              rstd * (g[c].z - s1 - xh[c].z * s2) + r.z, rstd * (g[c].w - s1 - xh[c].w * s2) + r.w};
+                if (p.dx) *reinterpret_cast<float4*>(p.dx + row * p.lddx + col) = make_float4(d[0], d[1], d[2], d[3]);
+                if (p.dx_bf) {
+                    union { uint2 u; bf16_t h[4]; } o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o.h[i] = f2bf(d[i]);
+                    *reinterpret_cast<uint2*>(p.dx_bf + row * p.lddxbf + col) = o.u;
+                }
+            }
+        }
+    }
+    if (p.dgamma == nullptr) return;   // uniform
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < p.D) {
+            *reinterpret_cast<float4*>(red + (0 * 4 + wave) * p.D + col) = dg[c];
+            *reinterpret_cast<float4*>(red + (1 * 4 + wave) * p.D + col) = db[c];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * p.D; i += 256) {
+        const int which = i / p.D, col = i % p.D;
+        const float s = red[(which * 4 + 0) * p.D + col] + red[(which * 4 + 1) * p.D + col] +
+                        red[(which * 4 + 2) * p.D + col] + red[(which * 4 + 3) * p.D + col];
+        atomic_add_f32((which ? p.dbeta : p.dgamma) + col, s);
+    }
+}
+
+}  // namespace
+
+int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024 && a.ldx % 4 == 0, "layernorm: D=%d must be a multiple of 4 and <= 1024", a.D);
+    if (a.rows <= 0) return 0;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("ln_fwd");
+    return 0;
+}
+
+int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
+    if (a.rows <= 0) return 0;
+    long blocks = (a.rows + 15) / 16;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 2 * 4 * a.D * sizeof(float), s, a);
+    S3D_CHECK_LAUNCH("ln_bwd");
+    return 0;
+}

@@ -1,0 +1,346 @@
+// Small HBM-bound kernels of the hot path: tokenizer patch gather, positional-embedding gradient, fp32->split-bf16,
+// classification head, cross-entropy, fused Adam.
+#include "kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------- tokenizer fold
+// One workgroup per (sample b, x-row X < P*c): the V*V-float slab x[b][X][:][:] is contiguous in HBM, is read once
+// with coalesced float4 loads into LDS, and the patch-ordered GEMM operand rows are produced from LDS.
+__global__ __launch_bounds__(256) void fold_kernel(const FoldArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sl = reinterpret_cast<float*>(smem);
+    const int V = p.V, c = p.c, P = p.P, Pc = P * c;
+    const int b = blockIdx.x / Pc, X = blockIdx.x % Pc;
+    const int px = X / c, i = X % c;
+    const float* slab = p.x + ((long)b * V + X) * V * V;
+    for (int t = threadIdx.x; t < V * V / 4; t += 256)
+        reinterpret_cast<float4*>(sl)[t] = reinterpret_cast<const float4*>(slab)[t];
+    __syncthreads();
+
+    if (p.mode == FOLD_ZMEAN) {
+        const long rowbase = (long)b * (P * P + 1) + 1 + px * P;
+        for (int t = threadIdx.x; t < Pc * c; t += 256) {
+            const int Y = t / c, k = t % c, py = Y / c, j = Y % c;
+            float s = 0.f;
+            for (int pz = 0; pz < P; ++pz) s += sl[Y * V + pz * c + k];
+            bf16_t hi, lo;
+            split_bf16(s, hi, lo);
+            const long off = (rowbase + py) * p.lda + (i * c + j) * c + k;
+            p.a_hi[off] = hi;
+            p.a_lo[off] = lo;
+        }
+    } else if (p.mode == FOLD_NAIVE) {
+        const long rowbase = (long)b * (P * P + 1) + 1 + px * P;
+        for (int Y = threadIdx.x; Y < Pc; Y += 256) {
+            float s = 0.f;
+            for (int z = 0; z < V; ++z) s += sl[Y * V + z];
+            s = fminf(fmaxf(s, 0.f), 1.f);
+            bf16_t hi, lo;
+            split_bf16(s, hi, lo);
+            const long off = (rowbase + Y / c) * p.lda + i * c + (Y % c);
+            p.a_hi[off] = hi;
+            p.a_lo[off] = lo;
+        }
+    } else {
+        for (int t = threadIdx.x; t < Pc * Pc; t += 256) {
+            const int Y = t / Pc, Z = t % Pc, py = Y / c, j = Y % c, pz = Z / c, k = Z % c;
+            long row;
+            if (p.mode == FOLD_PATCH) row = (long)b * ((long)P * P * P + 1) + 1 + ((long)px * P + py) * P + pz;
+            else row = (((long)b * P + px) * P + py) * (P + 1) + 1 + pz;
+            bf16_t hi, lo;
+            split_bf16(sl[Y * V + Z], hi, lo);
+            const long off = row * p.lda + (i * c + j) * c + k;
+            p.a_hi[off] = hi;
+            p.a_lo[off] = lo;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- pos / cls / bias grads
+__global__ void posgrad_kernel(const PosGradArgs p, long gchunk) {
+    const int t = blockIdx.x;
+    const long g0 = (long)blockIdx.y * gchunk, g1 = min(p.groups, g0 + gchunk);
+    for (int d = threadIdx.x; d < p.D; d += blockDim.x) {
+        float s = 0.f;
+        for (long g = g0; g < g1; ++g) s += p.dx[(g * p.ntok + t) * p.D + d];
+        if (p.dpos) atomic_add_f32(p.dpos + (long)t * p.D + d, s);
+        if (t == 0) { if (p.dcls) atomic_add_f32(p.dcls + d, s); }
+        else if (p.dbias) atomic_add_f32(p.dbias + d, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- fp32 -> split bf16
+__global__ void split_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long rows,
+                             long cols, long ld) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols, cidx = i % cols;
+        bf16_t h, l;
+        split_bf16(src[i], h, l);
+        hi[r * ld + cidx] = h;
+        if (lo) lo[r * ld + cidx] = l;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- head
+// one wave per (sample, class)
+__global__ __launch_bounds__(256) void head_fwd_kernel(const HeadArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (long)p.B * p.C) return;
+    const int b = (int)(item / p.C), c = (int)(item % p.C);
+    const float* x = p.feat + (long)b * p.D;
+    float dot = 0.f, xx = 0.f, ww = 0.f;
+    for (int d = lane; d < p.D; d += 64) {
+        const float xv = x[d];
+        const float wv = p.am_softmax ? p.W[(long)d * p.C + c] : p.W[(long)c * p.D + d];
+        dot += xv * wv; xx += xv * xv; ww += wv * wv;
+    }
+    dot = wave_sum(dot);
+    if (p.am_softmax) {
+        xx = wave_sum(xx); ww = wave_sum(ww);
+        dot = p.am_scale * dot / (fmaxf(sqrtf(xx), 1e-12f) * fmaxf(sqrtf(ww), 1e-12f));
+    } else {
+        dot += p.bias[c];
+    }
+    if (lane == 0) p.logits[item] = dot;
+}
+
+// linear head backward: dfeat[b][d] = sum_c dl[b][c] W[c][d];  dW[c][d] += sum_b dl[b][c] feat[b][d];  db[c] += sum_b dl[b][c]
+__global__ void head_bwd_linear_kernel(const HeadArgs p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nf = (long)p.B * p.D, nw = (long)p.C * p.D;
+    if (idx < nf) {
+        const int b = (int)(idx / p.D), d = (int)(idx % p.D);
+        float s = 0.f;
+        for (int c = 0; c < p.C; ++c) s += p.dlogits[(long)b * p.C + c] * p.W[(long)c * p.D + d];
+        p.dfeat[idx] = s;
+    } else if (idx < nf + nw) {
+        const long j = idx - nf;
+        const int c = (int)(j / p.D), d = (int)(j % p.D);
+        float s = 0.f;
+        for (int b = 0; b < p.B; ++b) s += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d];
+        atomic_add_f32(p.dW + j, s);
+    } else if (idx < nf + nw + p.C) {
+        const int c = (int)(idx - nf - nw);
+        float s = 0.f;
+        for (int b = 0; b < p.B; ++b) s += p.dlogits[(long)b * p.C + c];
+        atomic_add_f32(p.dbias + c, s);
+    }
+}
+
+// AM-softmax backward.  y[b][c] = s * xn[b].wn[c], xn = x/|x|, wn = W[:,c]/|W[:,c]| (clamp at 1e-12 ignored in bwd,
+// exactly as autograd does when the clamp is inactive).
+//   dx[b] = (g - xn (xn.g)) / |x|        with g  = s * sum_c dl[b][c] wn[c]
+//   dW[:,c] = (gw - wn (wn.gw)) / |w_c|  with gw = s * sum_b dl[b][c] xn[b]
+__global__ __launch_bounds__(256) void head_bwd_am_kernel(const HeadArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item < p.B) {                      // one wave per sample: dfeat
+        const int b = (int)item;
+        const float* x = p.feat + (long)b * p.D;
+        float xx = 0.f;
+        for (int d = lane; d < p.D; d += 64) xx += x[d] * x[d];
+        const float nx = fmaxf(sqrtf(wave_sum(xx)), 1e-12f);
+        float xg = 0.f;
+        for (int d = lane; d < p.D; d += 64) {
+            float g = 0.f;
+            for (int c = 0; c < p.C; ++c) {
+                // inverse column norms 1/|w_c| are cached in scratch[0..C) by am_norms_kernel
+                g += p.dlogits[(long)b * p.C + c] * p.W[(long)d * p.C + c] * p.scratch[c];
+            }
+            g *= p.am_scale;
+            xg += (x[d] / nx) * g;
+        }
+        xg = wave_sum(xg);
+        for (int d = lane; d < p.D; d += 64) {
+            float g = 0.f;
+            for (int c = 0; c < p.C; ++c) g += p.dlogits[(long)b * p.C + c] * p.W[(long)d * p.C + c] * p.scratch[c];
+            g *= p.am_scale;
+            p.dfeat[(long)b * p.D + d] = (g - (x[d] / nx) * xg) / nx;
+        }
+    } else if (item < (long)p.B + p.C) {   // one wave per class: dW[:, c]
+        const int c = (int)(item - p.B);
+        const float inw = p.scratch[c];    // 1/|w_c|
+        float wg = 0.f;
+        for (int d = lane; d < p.D; d += 64) {
+            float g = 0.f;
+            for (int b = 0; b < p.B; ++b) g += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d] * p.scratch[p.C + b];
+            g *= p.am_scale;
+            wg += p.W[(long)d * p.C + c] * inw * g;
+        }
+        wg = wave_sum(wg);
+        for (int d = lane; d < p.D; d += 64) {
+            float g = 0.f;
+            for (int b = 0; b < p.B; ++b) g += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d] * p.scratch[p.C + b];
+            g *= p.am_scale;
+            atomic_add_f32(p.dW + (long)d * p.C + c, (g - p.W[(long)d * p.C + c] * inw * wg) * inw);
+        }
+    }
+}
+
+// inverse norms for the AM-softmax backward: inv_w[c] = 1/max(|W[:,c]|,eps), inv_x[b] = 1/max(|x_b|,eps)
+__global__ __launch_bounds__(256) void am_norms_kernel(const HeadArgs p, float* inv_w, float* inv_x) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item < p.C) {
+        float s = 0.f;
+        for (int d = lane; d < p.D; d += 64) { const float w = p.W[(long)d * p.C + item]; s += w * w; }
+        s = wave_sum(s);
+        if (lane == 0) inv_w[item] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    } else if (item < (long)p.C + p.B) {
+        const long b = item - p.C;
+        float s = 0.f;
+        for (int d = lane; d < p.D; d += 64) { const float x = p.feat[b * p.D + d]; s += x * x; }
+        s = wave_sum(s);
+        if (lane == 0) inv_x[b] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- cross entropy
+__global__ void ce_den_kernel(const CeArgs p) {   // loss[0] = 0, loss[1] = sum_b w[t_b]  (or rows)
+    __shared__ float part[256];
+    float s = 0.f;
+    if (p.weight) for (long r = threadIdx.x; r < p.rows; r += 256) s += p.weight[p.target[r]];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { p.loss[0] = 0.f; p.loss[1] = p.weight ? part[0] : (float)p.rows; }
+}
+__global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one wave per row
+    const int lane = threadIdx.x & 63;
+    const long nw = (long)gridDim.x * 4;
+    const float den = p.loss[1];
+    float acc = 0.f;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.rows; row += nw) {
+        const float* l = p.logits + row * p.C;
+        float m = -INFINITY;
+        for (int c = lane; c < p.C; c += 64) m = fmaxf(m, l[c]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < p.C; c += 64) s += expf(l[c] - m);
+        s = wave_sum(s);
+        const long t = p.target[row];
+        const float w = p.weight ? p.weight[t] : 1.f;
+        const float lse = m + logf(s);
+        acc += w * (lse - l[t]);
+        if (p.dlogits)
+            for (int c = lane; c < p.C; c += 64)
+                p.dlogits[row * p.C + c] = p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den;
+    }
+    if (lane == 0 && acc != 0.f) atomic_add_f32(p.loss, acc / den);
+}
+
+// ------------------------------------------------------------------------------------------- Adam
+__global__ void adam_prelude_kernel(AdamState* st) {
+    st->step += 1;
+    const double b1 = st->beta1, b2 = st->beta2;
+    const double bc1 = 1.0 - pow(b1, (double)st->step);
+    const double bc2 = 1.0 - pow(b2, (double)st->step);
+    st->step_size = (float)((double)st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, bf16_t* __restrict__ hi,
+                                                   bf16_t* __restrict__ lo, long n4, const AdamState* st, int zero_grad) {
+    const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
+    const float step_size = st->step_size, bc2s = st->bc2_sqrt;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gs, G.y * gs, G.z * gs, G.w * gs};
+        float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
+        union { uint2 u; bf16_t h[4]; } H, L;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = mm[k] * b1 + (1.f - b1) * gg[k];
+            vv[k] = vv[k] * b2 + (1.f - b2) * gg[k] * gg[k];
+            const float denom = sqrtf(vv[k]) / bc2s + eps;
+            pp[k] -= step_size * (mm[k] / denom);
+            split_bf16(pp[k], H.h[k], L.h[k]);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hi) reinterpret_cast<uint2*>(hi)[i] = H.u;
+        if (lo) reinterpret_cast<uint2*>(lo)[i] = L.u;
+    }
+}
+
+}  // namespace
+
+int s3d_launch_fold(const FoldArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.V % 2 == 0 && a.P * a.c <= a.V, "fold: V=%d must be even and P*c=%d <= V", a.V, a.P * a.c);
+    const int lds = a.V * a.V * 4;
+    S3D_REQUIRE(lds <= 160 * 1024, "fold: V=%d slab does not fit LDS", a.V);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)(a.B * a.P * a.c)), dim3(256), lds, s, a);
+    S3D_CHECK_LAUNCH("fold");
+    return 0;
+}
+
+int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
+    long gs = (a.groups + 63) / 64;        // group slices per token
+    if (gs > 64) gs = 64;
+    if (gs < 1) gs = 1;
+    const long gchunk = (a.groups + gs - 1) / gs;
+    const int threads = a.D >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(posgrad_kernel, dim3(a.ntok, (unsigned)gs), dim3(threads), 0, s, a, gchunk);
+    S3D_CHECK_LAUNCH("posgrad");
+    return 0;
+}
+
+int s3d_launch_split(const float* src, bf16_t* hi, bf16_t* lo, long rows, long cols, long ld_out, hipStream_t s) {
+    const long n = rows * cols;
+    if (n <= 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(split_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, hi, lo, rows, cols, ld_out);
+    S3D_CHECK_LAUNCH("split");
+    return 0;
+}
+
+int s3d_launch_head_fwd(const HeadArgs& a, hipStream_t s) {
+    const long items = (long)a.B * a.C;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("head_fwd");
+    return 0;
+}
+
+int s3d_launch_head_bwd(const HeadArgs& a, hipStream_t s) {
+    if (!a.am_softmax) {
+        const long n = (long)a.B * a.D + (long)a.C * a.D + a.C;
+        hipLaunchKernelGGL(head_bwd_linear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        S3D_CHECK_LAUNCH("head_bwd");
+        return 0;
+    }
+    S3D_REQUIRE(a.scratch != nullptr, "head_bwd(am): needs scratch of C + B floats");
+    const long items = (long)a.B + a.C;
+    hipLaunchKernelGGL(am_norms_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a, a.scratch, a.scratch + a.C);
+    hipLaunchKernelGGL(head_bwd_am_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("head_bwd_am");
+    return 0;
+}
+
+int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(ce_den_kernel, dim3(1), dim3(256), 0, s, a);
+    long blocks = (a.rows + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(ce_main_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("cross_entropy");
+    return 0;
+}
+
+int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
+                    int zero_grad, hipStream_t s) {
+    S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
+    hipLaunchKernelGGL(adam_prelude_kernel, dim3(1), dim3(1), 0, s, st);
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad);
+    S3D_CHECK_LAUNCH("adam");
+    return 0;
+}

@@ -1,0 +1,422 @@
+"""VoxelEngine: host-side orchestration of the Simple3D-Former voxel training step on one MI355X.
+
+Owns a flat fp32 parameter arena (+ gradient / Adam-moment arenas and split-bf16 weight planes of the same layout),
+pre-allocated activation workspaces, and enqueues the whole forward / backward / optimizer step through the C ABI
+of libs3d_hip.so on torch's current HIP stream.  PyTorch is used for device memory, streams and (in parallel.py)
+torch.distributed only -- all arithmetic of the path runs in the hand-written gfx950 kernels.
+
+Reference call sites this replaces: Feature3D_ViT2D_V2.forward_features/forward
+(models/vit_3d_2d_pretrain.py:453-526), F.cross_entropy + loss.backward() + optimizer.step()
+(train_cls_voxel.py:277-288)."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BACKBONES = {  # models/vit_3d_2d_pretrain.py:279-325 -- deit_base is built with num_heads=3 (reference quirk)
+    'deit_tiny_patch16_224': dict(embed_dim=192, depth=12, num_heads=3),
+    'deit_small_patch16_224': dict(embed_dim=384, depth=12, num_heads=6),
+    'deit_base_patch16_224': dict(embed_dim=768, depth=12, num_heads=3),
+    'deit_base_distilled_patch16_224': dict(embed_dim=768, depth=12, num_heads=3),
+    'vit_base_patch16_224_21k': dict(embed_dim=768, depth=12, num_heads=3),
+}
+LN_EPS = 1e-6
+FOLD_MODE = {'VoxelEmbed': 0, 'VoxelNaiveProjection': 1, 'VoxelEmbed_no_average': 2}
+BLOCK_PARAM_ORDER = ['norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight',
+                     'attn.proj.bias', 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias',
+                     'mlp.fc2.weight', 'mlp.fc2.bias']
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_embedding='default', head='default'):
+    """Ordered {state_dict key: shape} of the parameters the voxel forward touches (forward order, so that
+    gradient buckets complete back-to-front during backward)."""
+    cfg = BACKBONES[backbone]
+    D, depth = cfg['embed_dim'], cfg['depth']
+    c = cell
+    shapes = {}
+    if embed_layer == 'VoxelNaiveProjection':
+        shapes['voxel_embed.proj.conv2d_1.weight'] = (D, 1, c, c)
+        shapes['voxel_embed.proj.conv2d_1.bias'] = (D,)
+        ntok = patch ** 2 + 1
+    else:
+        shapes['voxel_embed.proj.conv3d_1.weight'] = (D, 1, c, c, c)
+        shapes['voxel_embed.proj.conv3d_1.bias'] = (D,)
+        ntok = (patch ** 2 if embed_layer == 'VoxelEmbed' else patch ** 3) + 1
+    if pos_embedding == 'group_embed':
+        raise NotImplementedError('group_embed is built on GroupVoxelEngine')
+    shapes['cls_token'] = (1, 1, D)
+    shapes['voxel_pos_embed'] = (1, ntok, D)
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        shapes[p + 'norm1.weight'] = (D,); shapes[p + 'norm1.bias'] = (D,)
+        shapes[p + 'attn.qkv.weight'] = (3 * D, D); shapes[p + 'attn.qkv.bias'] = (3 * D,)
+        shapes[p + 'attn.proj.weight'] = (D, D); shapes[p + 'attn.proj.bias'] = (D,)
+        shapes[p + 'norm2.weight'] = (D,); shapes[p + 'norm2.bias'] = (D,)
+        shapes[p + 'mlp.fc1.weight'] = (4 * D, D); shapes[p + 'mlp.fc1.bias'] = (4 * D,)
+        shapes[p + 'mlp.fc2.weight'] = (D, 4 * D); shapes[p + 'mlp.fc2.bias'] = (D,)
+    shapes['norm.weight'] = (D,); shapes['norm.bias'] = (D,)
+    if head == 'AMSoftmax':
+        shapes['voxel_head.W'] = (D, n_classes)
+    else:
+        shapes['voxel_head.weight'] = (n_classes, D)
+        shapes['voxel_head.bias'] = (n_classes,)
+    return shapes
+
+
+class ParamArena:
+    """Flat fp32 arena + same-layout gradient / moment arenas + split-bf16 (hi, lo) planes."""
+
+    def __init__(self, shapes, device):
+        self.shapes = dict(shapes)
+        self.offsets = {}
+        off = 0
+        for k, shp in self.shapes.items():
+            self.offsets[k] = off
+            off = _round_up(off + int(np.prod(shp)), 8)       # 16-byte aligned bf16 planes, 32-byte aligned fp32
+        self.numel = _round_up(off, 8)
+        self.device = device
+        self.p = torch.zeros(self.numel, dtype=torch.float32, device=device)
+        self.g = torch.zeros_like(self.p)
+        self.m = torch.zeros_like(self.p)
+        self.v = torch.zeros_like(self.p)
+        self.hi = torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
+        self.lo = torch.zeros_like(self.hi)
+
+    def _view(self, flat, k):
+        o, shp = self.offsets[k], self.shapes[k]
+        return flat[o:o + int(np.prod(shp))].view(shp)
+
+    def param(self, k): return self._view(self.p, k)
+    def grad(self, k): return self._view(self.g, k)
+    def hi_of(self, k): return self._view(self.hi, k)
+    def lo_of(self, k): return self._view(self.lo, k)
+
+    def load(self, sd):
+        with torch.no_grad():
+            for k in self.shapes:
+                self.param(k).copy_(sd[k].to(self.device, torch.float32).reshape(self.shapes[k]))
+
+    def state_dict(self):
+        return {k: self.param(k).detach().clone() for k in self.shapes}
+
+    def refresh_planes(self):
+        """fp32 arena -> split-bf16 planes (needed whenever the parameters were changed outside s3d_adam_step)."""
+        lib = L.lib()
+        L.check(lib.s3d_split_bf16(L.ptr(self.p), L.ptr(self.hi), L.ptr(self.lo), ctypes.c_long(1),
+                                   ctypes.c_long(self.numel), ctypes.c_long(self.numel), L.current_stream()), 'split_bf16')
+
+
+class _BlockWorkspace:
+    """Saved activations of `depth` consecutive blocks on M = Bb*N rows, plus the ctypes act table."""
+
+    def __init__(self, depth, Bb, N, D, H, hidden, device, split):
+        M = Bb * N
+        f32 = dict(dtype=torch.float32, device=device)
+        b16 = dict(dtype=torch.bfloat16, device=device)
+        self.depth, self.Bb, self.N, self.M = depth, Bb, N, M
+        self.x = [torch.empty(M, D, **f32) for _ in range(depth + 1)]
+        self.x_mid = [torch.empty(M, D, **f32) for _ in range(depth)]
+        self.stats = torch.empty(depth, 4, M, **f32)
+        self.lse = torch.empty(depth, Bb * H * N, **f32)
+        self.xn1 = torch.empty(depth, 2, M, D, **b16)
+        self.qkv = torch.empty(depth, 2, M, 3 * D, **b16)
+        self.att = torch.empty(depth, 2, M, D, **b16)
+        self.xn2 = torch.empty(depth, 2, M, D, **b16)
+        self.hpre = torch.empty(depth, M, hidden, **b16)
+        self.hact = torch.empty(depth, 2, M, hidden, **b16)
+        self.acts = (L.S3dBlockActs * depth)()
+        for i in range(depth):
+            L.fill(self.acts[i], x_in=self.x[i], x_mid=self.x_mid[i], x_out=self.x[i + 1],
+                   mean1=self.stats[i, 0], rstd1=self.stats[i, 1], mean2=self.stats[i, 2], rstd2=self.stats[i, 3],
+                   lse=self.lse[i], xn1_hi=self.xn1[i, 0], xn1_lo=self.xn1[i, 1], qkv_hi=self.qkv[i, 0],
+                   qkv_lo=self.qkv[i, 1], att_hi=self.att[i, 0], att_lo=self.att[i, 1], xn2_hi=self.xn2[i, 0],
+                   xn2_lo=self.xn2[i, 1], hpre=self.hpre[i], hact_hi=self.hact[i, 0], hact_lo=self.hact[i, 1])
+        self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0)
+
+
+class _BlockScratch:
+    def __init__(self, M, D, H, hidden, BHN, device):
+        f32 = dict(dtype=torch.float32, device=device)
+        b16 = dict(dtype=torch.bfloat16, device=device)
+        self.dxn = torch.empty(M, D, **f32)
+        self.dx_a = torch.empty(M, D, **f32)
+        self.dx_b = torch.empty(M, D, **f32)
+        self.dx_a_bf = torch.empty(M, D, **b16)
+        self.dx_b_bf = torch.empty(M, D, **b16)
+        self.dh = torch.empty(M, hidden, **b16)
+        self.dqkv = torch.empty(M, 3 * D, **b16)
+        self.datt = torch.empty(M, D, **b16)
+        self.delta = torch.empty(BHN, **f32)
+        self.c = L.S3dBlockScratch()
+        L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
+               dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
+
+
+class VoxelEngine:
+    """deit_* backbone + VoxelEmbed / VoxelNaiveProjection / VoxelEmbed_no_average tokenizer with the `default`
+    positional embedding (vit_3d_2d_pretrain.py:455-470) and Linear / AM-softmax head."""
+
+    def __init__(self, *, backbone, embed_layer, voxel_size, cell, patch, n_classes, pos_embedding='default',
+                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        if backbone not in BACKBONES:
+            raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
+        if pos_embedding not in (None, 'default'):
+            raise ValueError("Unknown positional embedding scheme!")         # vit_3d_2d_pretrain.py:389
+        if embed_layer not in FOLD_MODE:
+            raise ValueError(f'unknown embed layer {embed_layer!r}')         # train_cls_voxel.py:138-142
+        self.lib = L.lib()                                                    # raises if the HIP library is missing
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('VoxelEngine runs on an MI355X (cuda/HIP device) only; the CPU reference lives in oracle/')
+        cfg = BACKBONES[backbone]
+        self.cfg = dict(backbone=backbone, embed_layer=embed_layer, voxel_size=voxel_size, cell=cell, patch=patch,
+                        n_classes=n_classes, pos_embedding='default', head=head)
+        self.D, self.depth, self.H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
+        self.hidden = 4 * self.D
+        self.V, self.c, self.P, self.C = voxel_size, cell, patch, n_classes
+        assert (voxel_size - cell) // cell + 1 == patch, 'patch_size must equal floor((V-c)/c)+1'
+        self.embed_layer = embed_layer
+        self.fold_mode = FOLD_MODE[embed_layer]
+        self.ntok = (patch ** 3 if embed_layer == 'VoxelEmbed_no_average' else patch ** 2) + 1
+        self.Kc = cell ** 2 if embed_layer == 'VoxelNaiveProjection' else cell ** 3
+        self.Kpad = _round_up(self.Kc, 8)
+        self.am = head == 'AMSoftmax'
+        self.split = bool(split)
+        self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
+        self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
+                                         n_classes=n_classes, head=head)
+        self.arena = ParamArena(self.shapes, self.device)
+        self._build_param_tables()
+        if self.Kpad != self.Kc:   # padded conv-weight planes (row pitch Kpad) refreshed from the arena each step
+            self.conv_hi = torch.zeros(self.D, self.Kpad, dtype=torch.bfloat16, device=self.device)
+            self.conv_lo = torch.zeros_like(self.conv_hi)
+            self.conv_gpad = torch.zeros(self.D, self.Kpad, dtype=torch.float32, device=self.device)
+        self.adam_state = torch.zeros(9, dtype=torch.int32, device=self.device)
+        self.set_optimizer(lr=lr, betas=betas, eps=eps)
+        self._ws = {}
+        self._graphs = {}
+        self.world_size = 1
+
+    # ------------------------------------------------------------------ parameters
+    def _build_param_tables(self):
+        a = self.arena
+        self.bparams = (L.S3dBlockParams * self.depth)()
+        self.bgrads = (L.S3dBlockGrads * self.depth)()
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            L.fill(self.bparams[i], ln1_w=a.param(p + 'norm1.weight'), ln1_b=a.param(p + 'norm1.bias'),
+                   ln2_w=a.param(p + 'norm2.weight'), ln2_b=a.param(p + 'norm2.bias'),
+                   qkv_b=a.param(p + 'attn.qkv.bias'), proj_b=a.param(p + 'attn.proj.bias'),
+                   fc1_b=a.param(p + 'mlp.fc1.bias'), fc2_b=a.param(p + 'mlp.fc2.bias'),
+                   qkv_w_hi=a.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=a.lo_of(p + 'attn.qkv.weight'),
+                   proj_w_hi=a.hi_of(p + 'attn.proj.weight'), proj_w_lo=a.lo_of(p + 'attn.proj.weight'),
+                   fc1_w_hi=a.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=a.lo_of(p + 'mlp.fc1.weight'),
+                   fc2_w_hi=a.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=a.lo_of(p + 'mlp.fc2.weight'))
+            L.fill(self.bgrads[i], ln1_w=a.grad(p + 'norm1.weight'), ln1_b=a.grad(p + 'norm1.bias'),
+                   ln2_w=a.grad(p + 'norm2.weight'), ln2_b=a.grad(p + 'norm2.bias'),
+                   qkv_w=a.grad(p + 'attn.qkv.weight'), qkv_b=a.grad(p + 'attn.qkv.bias'),
+                   proj_w=a.grad(p + 'attn.proj.weight'), proj_b=a.grad(p + 'attn.proj.bias'),
+                   fc1_w=a.grad(p + 'mlp.fc1.weight'), fc1_b=a.grad(p + 'mlp.fc1.bias'),
+                   fc2_w=a.grad(p + 'mlp.fc2.weight'), fc2_b=a.grad(p + 'mlp.fc2.bias'))
+
+    def load_state_dict(self, sd):
+        self.arena.load(sd)
+        self.refresh_weight_planes()
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def refresh_weight_planes(self):
+        self.arena.refresh_planes()
+        self._refresh_conv_planes()
+
+    def _refresh_conv_planes(self):
+        if self.Kpad != self.Kc:
+            w = self.arena.param(self.conv_key + '.weight')
+            L.check(self.lib.s3d_split_bf16(L.ptr(w), L.ptr(self.conv_hi), L.ptr(self.conv_lo), ctypes.c_long(self.D),
+                                            ctypes.c_long(self.Kc), ctypes.c_long(self.Kpad), L.current_stream()), 'split conv')
+
+    def set_optimizer(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, step=None):
+        """torch.optim.Adam hyper-parameters (train_cls_voxel.py:195); lives on the device so graph replays see it."""
+        cur_step = int(self.adam_state[7].item()) if step is None else int(step)
+        st = np.zeros(9, dtype=np.int32)
+        st[:7] = np.array([lr, betas[0], betas[1], eps, grad_scale, 0.0, 0.0], dtype=np.float32).view(np.int32)
+        st[7] = cur_step
+        self.adam_state.copy_(torch.from_numpy(st))
+
+    def set_lr(self, lr):
+        self.adam_state[0:1].copy_(torch.tensor([lr], dtype=torch.float32).view(torch.int32))
+
+    # ------------------------------------------------------------------ workspaces
+    def workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev, D = self.device, self.D
+        M = B * self.ntok
+        ws = type('WS', (), {})()
+        ws.B, ws.M = B, M
+        ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
+        ws.blocks = _BlockWorkspace(self.depth, B, self.ntok, D, self.H, self.hidden, dev, self.split)
+        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, B * self.H * self.ntok, dev)
+        ws.fstats = torch.empty(2, B, dtype=torch.float32, device=dev)
+        ws.feat = torch.empty(B, D, dtype=torch.float32, device=dev)
+        ws.logits = torch.empty(B, self.C, dtype=torch.float32, device=dev)
+        ws.dlogits = torch.empty(B, self.C, dtype=torch.float32, device=dev)
+        ws.dfeat = torch.empty(B, D, dtype=torch.float32, device=dev)
+        ws.loss = torch.zeros(2, dtype=torch.float32, device=dev)
+        ws.head_scratch = torch.empty(self.C + B, dtype=torch.float32, device=dev)
+        self._ws[B] = ws
+        return ws
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        """x: [B,1,V,V,V] float32 on the device (the trainer's voxel.float(), train_cls_voxel.py:276) -> logits."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(), 'voxel grid must be a contiguous fp32 device tensor'
+        B, Cc, H, W, V = x.shape
+        assert Cc == 1 and H == self.V and W == self.V and V == self.V, \
+            f"Input voxel size ({H}*{W}*{V}) doesn't match model ({self.V}*{self.V}*{self.V})."   # embed_layer_3d_modality.py:36
+        ws = self.workspace(B)
+        lib, s, a = self.lib, L.current_stream(), self.arena
+        fa = L.fill(L.S3dFoldArgs(), x=x, a_hi=ws.a[0], a_lo=ws.a[1], lda=self.Kpad, B=B, V=self.V, c=self.c, P=self.P,
+                    mode=self.fold_mode)
+        L.check(lib.s3d_voxel_fold(ctypes.byref(fa), s), 'voxel_fold')
+        ck = self.conv_key
+        if self.Kpad != self.Kc:
+            w_hi, w_lo = self.conv_hi, self.conv_lo
+        else:
+            w_hi, w_lo = a.hi_of(ck + '.weight'), a.lo_of(ck + '.weight')
+        g = L.fill(L.S3dGemmArgs(), A_hi=ws.a[0], A_lo=ws.a[1], lda=self.Kpad, B_hi=w_hi, B_lo=w_lo, ldb=self.Kpad,
+                   M=ws.M, N=self.D, K=self.Kpad, bias=a.param(ck + '.bias'), C=ws.blocks.x[0], ldc=self.D,
+                   alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0), cls=a.param('cls_token'),
+                   pos=a.param('voxel_pos_embed'), ntok=self.ntok)
+        L.check(lib.s3d_gemm(0, 0, 1 if self.split else 0, 3, ctypes.byref(g), 1, s), 'tokenizer gemm')
+        L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, s), 'blocks_fwd')
+        ln = L.fill(L.S3dLnArgs(), x=ws.blocks.x[self.depth], ldx=self.ntok * self.D, rows=B, D=self.D, eps=LN_EPS,
+                    gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
+                    mean=ws.fstats[0], rstd=ws.fstats[1])
+        L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
+        L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
+        return ws.logits
+
+    def _head_args(self, ws):
+        a = self.arena
+        h = L.S3dHeadArgs()
+        if self.am:
+            L.fill(h, feat=ws.feat, B=ws.B, D=self.D, C=self.C, W=a.param('voxel_head.W'), logits=ws.logits,
+                   am_softmax=1, am_scale=30.0, dlogits=ws.dlogits, dfeat=ws.dfeat, dW=a.grad('voxel_head.W'),
+                   scratch=ws.head_scratch)
+        else:
+            L.fill(h, feat=ws.feat, B=ws.B, D=self.D, C=self.C, W=a.param('voxel_head.weight'),
+                   bias=a.param('voxel_head.bias'), logits=ws.logits, am_softmax=0, am_scale=1.0, dlogits=ws.dlogits,
+                   dfeat=ws.dfeat, dW=a.grad('voxel_head.weight'), dbias=a.grad('voxel_head.bias'),
+                   scratch=ws.head_scratch)
+        return h
+
+    # ------------------------------------------------------------------ loss
+    def cross_entropy(self, B, target, weight=None, grad_scale=1.0):
+        """F.cross_entropy(logits, target[, weight]) (train_cls_voxel.py:282-285) on the logits of the last forward;
+        fills ws.loss[0] and ws.dlogits."""
+        ws = self.workspace(B)
+        assert target.dtype == torch.int64 and target.is_cuda
+        ce = L.fill(L.S3dCeArgs(), logits=ws.logits, target=target, weight=weight, rows=B, C=self.C, loss=ws.loss,
+                    dlogits=ws.dlogits, grad_scale=grad_scale)
+        L.check(self.lib.s3d_cross_entropy(ctypes.byref(ce), L.current_stream()), 'cross_entropy')
+        return ws.loss[0]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, B, dlogits=None, *, blocks_hook=None):
+        """Accumulates d(loss)/d(param) into the gradient arena, given d(loss)/d(logits) (ws.dlogits by default)."""
+        ws = self.workspace(B)
+        lib, s, a, D = self.lib, L.current_stream(), self.arena, self.D
+        if dlogits is not None and dlogits.data_ptr() != ws.dlogits.data_ptr():
+            ws.dlogits.copy_(dlogits)
+        L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
+        sc = ws.scratch
+        sc.dx_a.zero_()
+        sc.dx_a_bf.zero_()
+        lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
+                    mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
+                    dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
+                    rows=B, D=D)
+        L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd')
+        if blocks_hook is None:
+            L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
+                                       ctypes.byref(sc.c), self.depth - 1, 0, s), 'blocks_bwd')
+        else:
+            blocks_hook(ws)
+        self._tokenizer_backward(ws)
+
+    def blocks_backward_range(self, ws, first, last):
+        L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
+                                        ctypes.byref(ws.scratch.c), first, last, L.current_stream()), 'blocks_bwd')
+
+    def _tokenizer_backward(self, ws):
+        lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
+        ck = self.conv_key
+        padded = self.Kpad != self.Kc
+        gw = self.conv_gpad if padded else a.grad(ck + '.weight')
+        if padded:
+            self.conv_gpad.zero_()
+        g = L.fill(L.S3dGemmArgs(), A_hi=sc.dx_a_bf, lda=D, B_hi=ws.a[0], ldb=self.Kpad, M=D, N=self.Kpad, K=ws.M,
+                   C=gw, ldc=self.Kpad, alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0))
+        L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), 'tokenizer wgrad')
+        if padded:
+            a.grad(ck + '.weight').view(D, self.Kc).add_(self.conv_gpad[:, :self.Kc])
+        pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=ws.B, ntok=self.ntok, D=D, dpos=a.grad('voxel_pos_embed'),
+                    dcls=a.grad('cls_token'), dbias=a.grad(ck + '.bias'))
+        L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'token grads')
+
+    # ------------------------------------------------------------------ optimizer
+    def adam_step(self, zero_grad=True):
+        a = self.arena
+        L.check(self.lib.s3d_adam_step(L.ptr(a.p), L.ptr(a.g), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
+                                       ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                       L.current_stream()), 'adam')
+        self._refresh_conv_planes()
+
+    def zero_grad(self):
+        self.arena.g.zero_()
+
+    # ------------------------------------------------------------------ fused training step
+    def train_step(self, x, target, weight=None):
+        """zero_grad -> model(voxel) -> F.cross_entropy -> backward -> Adam  (train_cls_voxel.py:277-288), all on the
+        HIP path.  Gradients are zeroed by the previous step's Adam kernel.  Returns the loss as a device scalar."""
+        B = x.shape[0]
+        self.forward(x)
+        loss = self.cross_entropy(B, target, weight)
+        self.backward(B)
+        self.adam_step(zero_grad=True)
+        return loss
+
+    def capture_train_step(self, B, weight=None):
+        """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""
+        key = (B, None if weight is None else weight.data_ptr())
+        if key in self._graphs:
+            return self._graphs[key]
+        sx = torch.zeros(B, 1, self.V, self.V, self.V, dtype=torch.float32, device=self.device)
+        sy = torch.zeros(B, dtype=torch.int64, device=self.device)
+        # warm-up on a side stream (sets kernel attributes, allocates workspaces); state is restored afterwards
+        snap = [t.clone() for t in (self.arena.p, self.arena.m, self.arena.v, self.arena.g, self.adam_state)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.train_step(sx, sy, weight)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t, sv in zip((self.arena.p, self.arena.m, self.arena.v, self.arena.g, self.adam_state), snap):
+            t.copy_(sv)
+        self.refresh_weight_planes()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.train_step(sx, sy, weight)
+        self._graphs[key] = (graph, sx, sy, loss)
+        return self._graphs[key]

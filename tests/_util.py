@@ -1,0 +1,62 @@
+"""Shared helpers for the parity tests (golden loading, parameter regeneration)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import voxel_oracle as vo
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+MODEL_KEYS = ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')
+FWD_KEYS = ('backbone', 'embed_layer', 'cell', 'patch', 'pos_embedding')
+
+VOXEL_CASES = ['cfg1_small_v30_b8', 'cfg2_small_v32_b4', 'tiny_v12_default_b3', 'tiny_v12_noavg_default_b2',
+               'tiny_v12_naive_b2', 'small_v30_amsoftmax_b4', 'tiny_v12_group_b3', 'cfg3_base_v128_group_b1']
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    cfg = json.loads(str(z['cfg']))
+    return z, cfg
+
+
+def rebuild_inputs(cfg, z=None):
+    """Regenerates the exact parameter dict + synthetic batch the golden generator used and,
+    when the fixture is given, proves it via the stored parameter fingerprint."""
+    sd = vo.init_state_dict(seed=9, exercise_all=True, **{k: cfg[k] for k in MODEL_KEYS})
+    if z is not None:
+        keys = sorted(sd)
+        fp = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in keys])
+        np.testing.assert_allclose(fp, z['fingerprint'], rtol=1e-9, atol=1e-9,
+                                   err_msg='regenerated parameters differ from the golden run (RNG drift?)')
+    x, y = vo.synthetic_batch(cfg['batch'], cfg['voxel_size'], cfg['n_classes'], seed=9)
+    return sd, x, y
+
+
+def fwd_kwargs(cfg):
+    return {k: cfg[k] for k in FWD_KEYS}
+
+
+def check_grads_against_golden(z, grads, rtol, atol, names=None):
+    """grads: {name: tensor}.  Compares norm / sampled entries / full small tensors."""
+    gold_names = json.loads(str(z['grad_names']))
+    worst = 0.0
+    for k in (names or gold_names):
+        assert k in grads, f'missing gradient for {k}'
+        g = grads[k].detach().float().cpu().flatten()
+        ref_norm = float(z['gnorm/' + k])
+        idx = torch.from_numpy(z['gidx/' + k])
+        got = g[idx].numpy()
+        ref = z['gval/' + k]
+        scale = max(ref_norm / max(g.numel(), 1) ** 0.5, 1e-12)     # rms of the reference grad
+        err = np.abs(got - ref).max()
+        worst = max(worst, err / scale)
+        assert err <= atol + rtol * scale * 10, f'{k}: sampled grad max err {err:.3e} (rms {scale:.3e})'
+        assert abs(float(g.double().norm()) - ref_norm) <= atol + rtol * ref_norm * 10 + 1e-12, \
+            f'{k}: grad norm {float(g.norm()):.6e} vs {ref_norm:.6e}'
+        if ('gfull/' + k) in z.files:
+            np.testing.assert_allclose(grads[k].detach().float().cpu().numpy().reshape(z['gfull/' + k].shape),
+                                       z['gfull/' + k], rtol=rtol * 10, atol=atol + rtol * scale * 10,
+                                       err_msg=k)
+    return worst

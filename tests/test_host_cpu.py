@@ -1,0 +1,123 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol, struct mirrors match,
+the drop-in modules keep the reference's API / state_dict contract, and the product refuses to run without the HIP
+path (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import simple3d_former_amd as s3d
+from simple3d_former_amd import _lib as L
+from simple3d_former_amd.engine import ParamArena, voxel_param_shapes
+from oracle import voxel_oracle as vo
+
+
+@pytest.fixture(scope='module')
+def built():
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return L.lib()
+
+
+def test_library_exports_every_declared_symbol(built):
+    assert len(L.DECLARED_FUNCTIONS) >= 18
+    for fn in L.DECLARED_FUNCTIONS:
+        assert hasattr(built, fn), fn
+    assert built.s3d_version() >= 100
+    assert built.s3d_sizeof(b'NoSuchStruct') == 0
+    for n, S in L.STRUCTS.items():
+        assert built.s3d_sizeof(n.encode()) == ctypes.sizeof(S), n
+
+
+def test_header_parser_handles_every_struct():
+    assert {'S3dGemmArgs', 'S3dAttnArgs', 'S3dBlockActs', 'S3dAdamState'} <= set(L.STRUCTS)
+    f = dict(L.S3dGemmArgs._fields_)
+    assert f['A_hi'] is ctypes.c_void_p and f['lda'] is ctypes.c_long and f['alpha'] is ctypes.c_float
+    assert dict(L.S3dCeArgs._fields_)['target'] is ctypes.c_void_p
+    assert ctypes.sizeof(L.S3dAdamState) == 36
+
+
+def test_null_args_fail_loudly_not_abort(built):
+    rc = built.s3d_gemm(0, 0, 0, 0, None, 1, None)
+    assert rc != 0 and b'null' in built.s3d_last_error_string()
+    with pytest.raises(RuntimeError):
+        L.check(rc, 'gemm')
+
+
+@pytest.mark.parametrize('kind,npatch', [('VoxelEmbed', 25), ('VoxelEmbed_no_average', 125), ('VoxelNaiveProjection', 25)])
+def test_tokenizer_module_api(kind, npatch):
+    m = getattr(s3d, kind)(voxel_size=30, cell_size=6, patch_size=5, embed_dim=384)
+    assert m.voxel_size == (30, 30, 30) and m.cell_size == (6, 6, 6) and m.patch_size == 5
+    assert m.num_patches == npatch and m.embed_dim == 384
+    conv = 'conv2d_1' if kind == 'VoxelNaiveProjection' else 'conv3d_1'
+    assert set(m.state_dict()) == {f'proj.{conv}.weight', f'proj.{conv}.bias'}
+    with pytest.raises(AssertionError, match=r"Input voxel size \(32\*32\*32\) doesn't match model \(30\*30\*30\)"):
+        m(torch.zeros(1, 1, 32, 32, 32))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(1, 1, 30, 30, 30))
+
+
+@pytest.mark.parametrize('head', ['default', 'AMSoftmax'])
+def test_model_state_dict_contract_matches_reference_keys(head):
+    kw = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=30, cell=6, patch=5, n_classes=40, head=head)
+    sd = vo.init_state_dict(**kw)          # key set verified against the reference (strict load) by make_golden.py
+    model = s3d.Feature3D_ViT2D_V2(embed_layer=s3d.VoxelEmbed(voxel_size=30, cell_size=6, patch_size=5, embed_dim=384),
+                                   n_classes=40, transformer_backbone='deit_small_patch16_224', pretrained=False,
+                                   pos_embedding='default', head=head)
+    model.load_state_dict(sd, strict=True)
+    assert sum(p.numel() for p in model.parameters()) == (22159376 if head == 'default' else 22159336)
+    blk = model.blocks[0]
+    assert blk.attn.num_heads == 6 and abs(blk.attn.scale - 64 ** -0.5) < 1e-12 and blk.attn.qkv.weight.shape == (1152, 384)
+    assert float(model.voxel_pos_embed.abs().sum()) == 0.0       # zeros, never random-initialised (reference quirk)
+    assert model.norm.eps == 1e-6
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(1, 1, 30, 30, 30))
+
+
+def test_reference_error_conventions():
+    te = s3d.VoxelEmbed(voxel_size=12, cell_size=4, patch_size=3, embed_dim=192)
+    with pytest.raises(ValueError, match='Unknown transformer backbone name!'):
+        s3d.Feature3D_ViT2D_V2(embed_layer=te, transformer_backbone='resnet50', pretrained=False)
+    with pytest.raises(ValueError, match='Unknown positional embedding scheme!'):
+        s3d.Feature3D_ViT2D_V2(embed_layer=te, transformer_backbone='deit_tiny_patch16_224', pretrained=False,
+                               pos_embedding='bogus')
+    with pytest.raises(RuntimeError, match='no network'):
+        s3d.Feature3D_ViT2D_V2(embed_layer=te, transformer_backbone='deit_tiny_patch16_224', pretrained=True)
+    m = s3d.Feature3D_ViT2D_V2(embed_layer=te, transformer_backbone='deit_base_patch16_224', pretrained=False)
+    assert m.num_heads == 3 and m.embed_dim == 768                 # deit_base is built with 3 heads (reference quirk)
+
+
+def test_param_arena_layout_and_used_parameter_set():
+    kw = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', cell=6, patch=5, n_classes=40)
+    shapes = voxel_param_shapes(**kw)
+    sd = vo.init_state_dict(voxel_size=30, **kw)
+    assert set(shapes) == set(vo.used_param_names(sd))              # exactly the parameters the voxel forward touches
+    assert sum(int(torch.tensor(s).prod()) for s in shapes.values()) == 21403432
+    arena = ParamArena(shapes, torch.device('cpu'))
+    offs = [arena.offsets[k] for k in shapes]
+    assert offs == sorted(offs) and all(o % 8 == 0 for o in offs) and arena.numel % 8 == 0
+    arena.load(sd)
+    for k in shapes:
+        assert torch.equal(arena.param(k), sd[k].reshape(shapes[k]))
+    # blocks are laid out in forward order => gradient buckets complete back-to-front
+    assert arena.offsets['blocks.0.norm1.weight'] < arena.offsets['blocks.11.mlp.fc2.bias'] < arena.offsets['norm.weight']
+
+
+def test_engine_requires_the_gpu():
+    with pytest.raises(RuntimeError, match='MI355X'):
+        s3d.VoxelEngine(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed', voxel_size=12, cell=4, patch=3,
+                        n_classes=10, device='cpu')
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure; the shipped package must not reference it."""
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'simple3d-former_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
+                assert 'timm_shim' not in src, f
