@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Headline benchmark: voxel-grids/s of the full training step (zero_grad -> forward -> cross-entropy -> backward ->
+gradient all-reduce -> Adam) on BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed (32^3 grid, cell 6,
+patch 5, 40 classes), batch 64 per GPU, synthetic 10 %-occupancy grids, random-init weights (reference init).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel (the MFMA GEMM instantiation with the largest total time), algorithmic 2*M*N*K flops per
+                launch / its average launch duration measured with HIP events on the launch stream in an instrumented
+                eager pass of the same steps, against the 2.5 PFLOP/s dense bf16 MFMA peak
+  cpu_baseline  the CPU oracle's full training step (PyTorch fp32 restatement of the reference, same batch) timed on the
+                host cores of this box, rank 0 at N=1 only, bounded to ~10-20 s
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5, n_classes=40)
+BATCH_PER_GPU = 64
+TRAIN_FLOPS_PER_SAMPLE = 3.39e9          # BASELINE.md section 2 (fwd 1.137 G, train = 3x fwd - tokenizer dgrad)
+MFMA_BF16_PEAK_TFLOPS = 2500.0           # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
+EPI_NAMES = {0: 'bf16_bias', 1: 'gelu', 2: 'resid', 3: 'token', 4: 'f32', 5: 'dgelu', 6: 'atomic', 7: 'relu', 8: 'drelu'}
+
+
+def kernel_name(key):
+    key = int(key)
+    bm, ta, tb, sp, epi = key // 100000, (key // 10000) % 10, (key // 1000) % 10, (key // 100) % 10, key % 100
+    bn = 128 if bm == 128 else 64
+    return f'gemm_kernel<{bm},{bn},{"T" if ta else "N"}{"T" if not tb else "N"},{"split3" if sp else "bf16"},{EPI_NAMES.get(epi, epi)}>'
+
+
+def cpu_baseline(x, y, budget_s=15.0):
+    """The oracle's training step (forward + CE + autograd backward + Adam on every used parameter) on host cores."""
+    from oracle import voxel_oracle as vo
+    sd = vo.init_state_dict(seed=9, voxel_size=CFG['voxel_size'], **{k: CFG[k] for k in ('backbone', 'embed_layer', 'cell', 'patch', 'n_classes')})
+    names = vo.used_param_names(sd)
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    kw = dict(backbone=CFG['backbone'], embed_layer=CFG['embed_layer'], cell=CFG['cell'], patch=CFG['patch'])
+    threads = torch.get_num_threads()
+
+    def one(step):
+        _, loss, grads = vo.loss_and_grads(sd, x, y, **kw)
+        for k, g in grads.items():
+            vo.adam_step(sd[k], g, m[k], v[k], step)
+        return float(loss)
+
+    one(1)                                                     # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return dict(value=round(n * x.shape[0] / el, 2), unit='voxels/sec', cores=threads, kind='port',
+                sample=f'{n} full training steps (fwd+bwd+Adam) of the fp32 PyTorch-CPU oracle at batch {x.shape[0]}, '
+                       f'{threads} threads, {el:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
+    ap.add_argument('--plain-bf16', action='store_true', help='one-MFMA forward (fails the 1e-3 logit bar; for comparison only)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--buckets', type=int, default=3)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    import simple3d_former_amd as s3d
+    from simple3d_former_amd import _lib as L
+    from simple3d_former_amd.parallel import DataParallelTrainer
+    from oracle import voxel_oracle as vo                      # synthetic-input recipe + cpu_baseline leg only
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+
+    # model + optimizer state (reference init, seed 9), per-rank synthetic shard of the global batch
+    eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, **CFG)
+    sd = vo.init_state_dict(seed=9, **CFG)
+    eng.load_state_dict(sd)
+    x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
+    x, y = x_cpu.to(dev), y_cpu.to(dev)
+    trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs)
+    trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if not args.no_graphs:
+        cap = trainer.capture(BATCH_PER_GPU)
+        cap['x'].copy_(x); cap['y'].copy_(y)
+        step = trainer.step_graph
+    else:
+        step = lambda: trainer.step_eager(x, y)
+
+    first_loss = None
+    for i in range(args.warmup):
+        l = step()
+        if i == 0:
+            first_loss = float(l)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    final_loss = float(loss)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    value = world * BATCH_PER_GPU * args.steps / elapsed
+
+    out = {
+        'metric': 'voxels/sec (train, whole node) deit_small VoxelEmbed 32^3 b64', 'value': round(value, 1),
+        'unit': 'voxels/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if args.plain_bf16 else 'bf16 (split-bf16 x3 MFMA forward, bf16 backward, fp32 accumulate/residual/Adam)',
+        'data': 'synthetic (seeded 10%-occupancy 32^3 grids, random-init weights of the reference architecture)',
+        'config': {'workload': 'BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed(voxel 32, cell 6, patch 5), '
+                               '40 classes, full train step incl. Adam', 'batch_per_gpu': BATCH_PER_GPU,
+                   'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
+                   'launch': 'eager' if args.no_graphs else 'hipGraph replay',
+                   'grad_buckets': len(trainer.slices)},
+        'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
+        'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
+        'loss_first_step': round(first_loss, 5) if first_loss is not None else None, 'loss_last_step': round(final_loss, 5),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        # instrumented eager pass: HIP events around every GEMM launch, on the launch stream
+        lib = L.lib()
+        n_inst = max(3, min(10, args.steps))
+        lib.s3d_prof_enable(1)
+        for _ in range(n_inst):
+            eng.train_step(x, y)          # engine-only step (no collective): rank-0 kernel timing
+        torch.cuda.synchronize()
+        import ctypes
+        rows = (ctypes.c_double * (4 * 64))()
+        n = lib.s3d_prof_collect(rows, 64)
+        lib.s3d_prof_enable(0)
+        ks = [(rows[4 * i], rows[4 * i + 1], rows[4 * i + 2], rows[4 * i + 3]) for i in range(min(n, 64))]
+        if ks:
+            tot_ms = sum(k[2] for k in ks)
+            dom = max(ks, key=lambda k: k[2])
+            avg_us = dom[2] / dom[1] * 1e3
+            achieved = dom[3] / (dom[2] * 1e-3) / 1e12                       # algorithmic TFLOP/s of the dominant kernel
+            all_ach = sum(k[3] for k in ks) / (tot_ms * 1e-3) / 1e12
+            out['roofline'] = {
+                'bound': 'mfma', 'kernel': kernel_name(dom[0]), 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None,
+                'avg_launch_us': round(avg_us, 3), 'launches_per_step': round(dom[1] / n_inst, 1),
+                'flops_per_launch': round(dom[3] / dom[1], 0),
+                'mfma_issue_factor': 3 if '(split3' in kernel_name(dom[0]) or 'split3' in kernel_name(dom[0]) else 1,
+                'all_gemm_kernels': {'achieved': round(all_ach, 2), 'ms_per_step': round(tot_ms / n_inst, 4),
+                                     'share_of_step': round(tot_ms / n_inst / ms, 3)},
+                'per_kernel': [{'kernel': kernel_name(k[0]), 'launches_per_step': round(k[1] / n_inst, 1),
+                                'avg_us': round(k[2] / k[1] * 1e3, 3), 'tflops': round(k[3] / (k[2] * 1e-3) / 1e12, 2)}
+                               for k in sorted(ks, key=lambda k: -k[2])],
+            }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(x_cpu, y_cpu)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

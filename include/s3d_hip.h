@@ -57,6 +57,13 @@ typedef struct S3dGemmArgs {
  * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
 
+/* Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
+ * launch stream.  s3d_prof_collect synchronises those events and fills rows of 4 doubles
+ * {kernel key, launches, total ms, total algorithmic flops (2*M*N*K)}; key = BM*100000 + ta*10000 + tb*1000 +
+ * split*100 + epilogue.  Returns the number of distinct kernels.  Must be off during graph capture. */
+int s3d_prof_enable(int on);
+int s3d_prof_collect(double* rows, int cap);
+
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps=1e-6) of timm Block.norm1/.norm2 and VisionTransformer.norm (vit_3d_2d_pretrain.py:287,469). */
 typedef struct S3dLnArgs {

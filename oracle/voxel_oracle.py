@@ -245,8 +245,29 @@ def adam_step(p, g, m, v, step, lr=1e-3, b1=0.9, b2=0.999, eps=1e-8):
     p.addcdiv_(m, denom, value=-(lr / bc1))
 
 
+_MASK64 = (1 << 64) - 1
+
+
+def portable_uniform(shape, seed, stream):
+    """Machine-independent U[0,1) tensor: splitmix64 of (seed, stream, element index) in numpy uint64 arithmetic.
+    torch's CPU samplers (normal_/trunc_normal_) differ by an ulp between CPU ISAs (vectorised erfinv), which would
+    make golden fixtures unreproducible on the GPU box's host; integer hashing does not."""
+    import numpy as np
+    n = 1
+    for d in shape:
+        n *= int(d)
+    with np.errstate(over='ignore'):
+        key = np.uint64((seed * 0x9E3779B97F4A7C15 + stream * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & _MASK64)
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + key
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return torch.from_numpy(u.reshape(tuple(shape) if len(shape) else ()))
+
+
 def init_state_dict(*, backbone, embed_layer, voxel_size, cell, patch, n_classes,
-                    pos_embedding='default', head='default', seed=9, exercise_all=False):
+                    pos_embedding='default', head='default', seed=9, exercise_all=False, portable=False):
     """Random-init parameter dict with the reference's key names, shapes and init
     distributions (timm _init_weights: Linear trunc_normal std .02 / bias 0, LayerNorm 1/0;
     cls_token/pos_embed trunc_normal .02; voxel_pos_embed / group tokens zeros -- the reference
@@ -258,12 +279,22 @@ def init_state_dict(*, backbone, embed_layer, voxel_size, cell, patch, n_classes
     D, depth = cfg['embed_dim'], cfg['depth']
     sd = {}
 
+    stream = [0]
+
+    def pu(shape):                       # portable U[0,1), one hash stream per tensor
+        stream[0] += 1
+        return portable_uniform(shape, seed, stream[0])
+
     def tn(*shape):
+        if portable:                     # same std (.02) as the trunc-normal init, uniform shape
+            return ((pu(shape) * 2 - 1) * (0.02 * math.sqrt(3.0))).float()
         t = torch.empty(*shape)
         return torch.nn.init.trunc_normal_(t, std=.02, a=-2., b=2., generator=g)
 
     def uni(shape, fan_in):
         bound = 1.0 / math.sqrt(fan_in)
+        if portable:
+            return ((pu(shape) * 2 - 1) * bound).float()
         return (torch.rand(*shape, generator=g) * 2 - 1) * bound
 
     sd['cls_token'] = tn(1, 1, D)
@@ -288,7 +319,10 @@ def init_state_dict(*, backbone, embed_layer, voxel_size, cell, patch, n_classes
         sd['voxel_embed.proj.conv3d_1.weight'] = uni((D, 1, c, c, c), c ** 3)
         sd['voxel_embed.proj.conv3d_1.bias'] = uni((D,), c ** 3)
     if head == 'AMSoftmax':
-        sd['voxel_head.W'] = torch.randn(D, n_classes, generator=g) * math.sqrt(2.0 / (D + n_classes))
+        if portable:
+            sd['voxel_head.W'] = ((pu((D, n_classes)) * 2 - 1) * math.sqrt(6.0 / (D + n_classes))).float()
+        else:
+            sd['voxel_head.W'] = torch.randn(D, n_classes, generator=g) * math.sqrt(2.0 / (D + n_classes))
     else:
         sd['voxel_head.weight'] = uni((n_classes, D), D)
         sd['voxel_head.bias'] = uni((n_classes,), D)
@@ -314,13 +348,21 @@ def init_state_dict(*, backbone, embed_layer, voxel_size, cell, patch, n_classes
         for k in sorted(sd):
             t = sd[k]
             if bool((t == 0).all()) or bool((t == 1).all()):
-                sd[k] = t + torch.empty_like(t).normal_(0, 0.05, generator=g)
+                if portable:
+                    sd[k] = t + ((pu(tuple(t.shape)) * 2 - 1) * (0.05 * math.sqrt(3.0))).float()
+                else:
+                    sd[k] = t + torch.empty_like(t).normal_(0, 0.05, generator=g)
     return sd
 
 
-def synthetic_batch(batch, voxel_size, n_classes, seed=9, occupancy=0.10):
+def synthetic_batch(batch, voxel_size, n_classes, seed=9, occupancy=0.10, portable=False):
     """SURVEY.md section 8(d) synthetic inputs: seeded 10 %-occupancy binary grid, int32 in the
     dataset (data/modelnet40.py:40), cast to float by the trainer (train_cls_voxel.py:276)."""
+    if portable:
+        V = voxel_size
+        x = (portable_uniform((batch, 1, V, V, V), seed, 1001) < occupancy).to(torch.int32)
+        y = (portable_uniform((batch,), seed, 1002) * n_classes).long().clamp_(max=n_classes - 1)
+        return x.float(), y
     g = torch.Generator().manual_seed(seed)
     x = (torch.rand(batch, 1, voxel_size, voxel_size, voxel_size, generator=g) < occupancy).to(torch.int32)
     y = torch.randint(0, n_classes, (batch,), generator=g)

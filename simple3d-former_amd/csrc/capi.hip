@@ -148,6 +148,9 @@ size_t s3d_sizeof(const char* n) {
     return 0;
 }
 
+int s3d_prof_enable(int on) { s3d_gemm_prof_enable(on != 0); return 0; }
+int s3d_prof_collect(double* rows, int cap) { return s3d_gemm_prof_collect(rows, cap); }
+
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int splitk, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");
     return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));

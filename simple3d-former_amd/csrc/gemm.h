@@ -19,3 +19,7 @@ typedef S3dGemmArgs GemmArgs;
 
 // ta/tb: operand stored k-major.  splitk <= 0: automatic (wgrad only).  Returns 0 on success.
 int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a, int splitk, hipStream_t stream);
+
+// bench-only timing of every GEMM launch with HIP events on the launch stream (see gemm.hip)
+void s3d_gemm_prof_enable(bool on);
+int s3d_gemm_prof_collect(double* rows, int cap);

@@ -12,6 +12,39 @@
 //   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
 #include "gemm.h"
 
+#include <array>
+#include <map>
+#include <vector>
+
+// ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch, keyed by kernel
+// instantiation.  Off by default; never active during graph capture.
+namespace {
+struct ProfSlot { int key; double flops; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfSlot> g_prof;
+}  // namespace
+void s3d_gemm_prof_enable(bool on) {
+    if (on) { for (auto& sl : g_prof) { (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); } g_prof.clear(); }
+    g_prof_on = on;
+}
+// fills up to `cap` rows of {key, launches, total_ms, total_flops}; returns the number of distinct keys
+int s3d_gemm_prof_collect(double* rows, int cap) {
+    std::map<int, std::array<double, 3>> agg;
+    for (auto& sl : g_prof) {
+        float ms = 0.f;
+        if (hipEventSynchronize(sl.e1) == hipSuccess && hipEventElapsedTime(&ms, sl.e0, sl.e1) == hipSuccess) {
+            auto& a = agg[sl.key];
+            a[0] += 1; a[1] += ms; a[2] += sl.flops;
+        }
+    }
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n < cap) { rows[4 * n] = kv.first; rows[4 * n + 1] = kv.second[0]; rows[4 * n + 2] = kv.second[1]; rows[4 * n + 3] = kv.second[2]; }
+        ++n;
+    }
+    return n;
+}
+
 namespace {
 
 template <int BR, bool T>
@@ -263,7 +296,19 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splitk);
-    hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+    if (g_prof_on) {
+        ProfSlot sl;
+        // key = BM*100000 + TA*10000 + TB*1000 + SPLIT*100 + EPI ; flops = algorithmic 2*M*N*K
+        sl.key = BM * 100000 + (TA ? 10000 : 0) + (TB ? 1000 : 0) + (SPLIT ? 100 : 0) + EPI;
+        sl.flops = 2.0 * a.M * a.N * a.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+    }
     S3D_CHECK_LAUNCH("gemm");
     return 0;
 }

@@ -332,8 +332,8 @@ class VoxelEngine:
         return ws.loss[0]
 
     # ------------------------------------------------------------------ backward
-    def backward(self, B, dlogits=None, *, blocks_hook=None):
-        """Accumulates d(loss)/d(param) into the gradient arena, given d(loss)/d(logits) (ws.dlogits by default)."""
+    def backward_begin(self, B, dlogits=None):
+        """head backward + final-norm backward: leaves d(loss)/d(x_final) in the scratch ping-pong buffer."""
         ws = self.workspace(B)
         lib, s, a, D = self.lib, L.current_stream(), self.arena, self.D
         if dlogits is not None and dlogits.data_ptr() != ws.dlogits.data_ptr():
@@ -347,12 +347,38 @@ class VoxelEngine:
                     dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
                     rows=B, D=D)
         L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd')
-        if blocks_hook is None:
-            L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
-                                       ctypes.byref(sc.c), self.depth - 1, 0, s), 'blocks_bwd')
-        else:
-            blocks_hook(ws)
-        self._tokenizer_backward(ws)
+        return ws
+
+    def backward_segment(self, ws, first, last, with_tokenizer):
+        self.blocks_backward_range(ws, first, last)
+        if with_tokenizer:
+            self._tokenizer_backward(ws)
+
+    def backward(self, B, dlogits=None, *, segments=None, on_segment=None):
+        """Accumulates d(loss)/d(param) into the gradient arena, given d(loss)/d(logits) (ws.dlogits by default).
+        `segments` = [(first_block, last_block), ...] in backward order; on_segment(i) fires when every gradient of
+        segment i is complete (the last one includes the tokenizer) -- the data-parallel reducer hooks in there."""
+        ws = self.backward_begin(B, dlogits)
+        segs = segments or [(self.depth - 1, 0)]
+        for i, (first, last) in enumerate(segs):
+            self.backward_segment(ws, first, last, i == len(segs) - 1)
+            if on_segment is not None:
+                on_segment(i)
+
+    def grad_buckets(self, n_buckets=3):
+        """Splits the backward into `n_buckets` block ranges and returns (segments, [(start, end) arena slices]) such
+        that slice i holds exactly the gradients that are final once segment i has run (arena is in forward order)."""
+        n = max(1, min(n_buckets, self.depth))
+        bounds = [round(self.depth * k / n) for k in range(n + 1)]            # 0 .. depth
+        segments, slices = [], []
+        end = self.arena.numel
+        for k in range(n, 0, -1):
+            lo_blk, hi_blk = bounds[k - 1], bounds[k] - 1
+            start = self.arena.offsets[f'blocks.{lo_blk}.norm1.weight'] if lo_blk > 0 else 0
+            segments.append((hi_blk, lo_blk))
+            slices.append((start, end))
+            end = start
+        return segments, slices
 
     def blocks_backward_range(self, ws, first, last):
         L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,

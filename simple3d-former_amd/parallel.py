@@ -1,0 +1,147 @@
+"""Data-parallel training of the voxel path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
+ROCm; "gloo" in the CPU tests), replicated parameters, per-step gradient all-reduce.
+
+Reference behaviour reproduced (train_cls_voxel.py): DDP constructor broadcast of rank-0 parameters (:155-159), mean
+all-reduce of gradients overlapped with backward (:287), DistributedSampler's index partition without set_epoch
+(:160-164).  MI355X-first differences: gradients live in ONE flat arena laid out in forward order, so each bucket is a
+contiguous slice that completes back-to-front during backward -- no bucket copy-in/out; the 1/world averaging is folded
+into the fused Adam kernel; backward is replayed as HIP-graph segments with the RCCL call of the previous bucket in
+flight (RCCL's stream) while the next segment computes."""
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_samples, world_size, rank, seed=0, shuffle=True):
+    """torch.utils.data.DistributedSampler's rule with epoch fixed at 0 (the reference never calls set_epoch):
+    seeded permutation, padded by wrap-around to a multiple of world_size, then indices[rank::world_size]."""
+    if shuffle:
+        g = torch.Generator().manual_seed(seed)
+        idx = torch.randperm(n_samples, generator=g).tolist()
+    else:
+        idx = list(range(n_samples))
+    total = (n_samples + world_size - 1) // world_size * world_size
+    pad = total - len(idx)
+    if pad:
+        idx += (idx * ((pad + len(idx) - 1) // len(idx)))[:pad]
+    return idx[rank:total:world_size]
+
+
+class BucketedGradReducer:
+    """Sum-all-reduce of contiguous slices of one flat gradient tensor, launched asynchronously bucket by bucket."""
+
+    def __init__(self, flat_grad, slices, group=None, force=False):
+        self.flat, self.slices, self.group = flat_grad, list(slices), group
+        self.force = force                   # issue the collective even at world size 1 (exercises the RCCL path)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._works = []
+        covered = sorted(self.slices)
+        assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel() and \
+            all(a[1] == b[0] for a, b in zip(covered, covered[1:])), 'buckets must tile the arena exactly'
+
+    def launch(self, i):
+        if self.world == 1 and not self.force:
+            return
+        s, e = self.slices[i]
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()            # makes the current stream wait for the collective (no host block on GPU backends)
+        self._works = []
+
+
+def broadcast_parameters(flat_param, src=0, group=None):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat_param, src=src, group=group)
+
+
+class DataParallelTrainer:
+    """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
+
+    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False):
+        self.eng = engine
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        broadcast_parameters(engine.arena.p, 0, group)                 # DDP-constructor broadcast (C2)
+        engine.refresh_weight_planes()
+        self.segments, self.slices = engine.grad_buckets(n_buckets if (self.world > 1 or force_collectives) else 1)
+        self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives)
+        self._hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+        engine.set_optimizer(grad_scale=1.0 / self.world, **self._hp)
+        self.use_graphs = use_graphs
+        self._cap = None
+
+    def set_optimizer(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self._hp = dict(lr=lr, betas=betas, eps=eps)
+        self.eng.set_optimizer(grad_scale=1.0 / self.world, **self._hp)
+
+    # ---- eager step -------------------------------------------------------------------------------------------
+    def step_eager(self, x, y, weight=None):
+        eng, B = self.eng, x.shape[0]
+        eng.forward(x)
+        loss = eng.cross_entropy(B, y, weight)
+        eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
+        self.reducer.wait()
+        eng.adam_step(zero_grad=True)
+        return loss
+
+    # ---- HIP-graph step ---------------------------------------------------------------------------------------
+    def _phase(self, k, B, sx, sy, weight):
+        eng = self.eng
+        if k == 0:
+            eng.forward(sx)
+            eng.cross_entropy(B, sy, weight)
+            ws = eng.backward_begin(B)
+        else:
+            ws = eng.workspace(B)
+        first, last = self.segments[k]
+        eng.backward_segment(ws, first, last, k == len(self.segments) - 1)
+
+    def capture(self, B, weight=None):
+        eng = self.eng
+        sx = torch.zeros(B, 1, eng.V, eng.V, eng.V, dtype=torch.float32, device=eng.device)
+        sy = torch.zeros(B, dtype=torch.int64, device=eng.device)
+        state = (eng.arena.p, eng.arena.m, eng.arena.v, eng.arena.g, eng.adam_state)
+        snap = [t.clone() for t in state]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                   # warm-up: kernel attributes, workspaces
+            for k in range(len(self.segments)):
+                self._phase(k, B, sx, sy, weight)
+            eng.adam_step(zero_grad=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t, sv in zip(state, snap):
+            t.copy_(sv)
+        eng.refresh_weight_planes()
+        torch.cuda.synchronize()
+        graphs = []
+        for k in range(len(self.segments)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._phase(k, B, sx, sy, weight)
+            graphs.append(g)
+        g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_opt):
+            eng.adam_step(zero_grad=True)
+        self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss)
+        return self._cap
+
+    def step_graph(self):
+        """Replays the captured step on the static buffers (cap['x'], cap['y'] must already hold the batch)."""
+        cap = self._cap
+        for k, g in enumerate(cap['graphs']):
+            g.replay()
+            self.reducer.launch(k)          # RCCL all-reduce of bucket k overlaps the next segment's replay
+        self.reducer.wait()
+        cap['opt'].replay()
+        return cap['loss'][0]
+
+    def step(self, x, y, weight=None):
+        if not self.use_graphs:
+            return self.step_eager(x, y, weight)
+        if self._cap is None or self._cap['B'] != x.shape[0]:
+            self.capture(x.shape[0], weight)
+        self._cap['x'].copy_(x, non_blocking=True)
+        self._cap['y'].copy_(y, non_blocking=True)
+        return self.step_graph()

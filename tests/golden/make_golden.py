@@ -81,11 +81,11 @@ def build_reference_model(cfg):
 def run_case(name, cfg):
     kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes',
                               'pos_embedding', 'head')}
-    sd = vo.init_state_dict(seed=9, exercise_all=True, **kw)
+    sd = vo.init_state_dict(seed=9, exercise_all=True, portable=True, **kw)
     model = build_reference_model(cfg)
     model.load_state_dict(sd, strict=True)           # key names + shapes are part of the contract
     model.eval()                                     # only matters for group_embed's dropout(0.1)
-    x, y = vo.synthetic_batch(cfg['batch'], cfg['voxel_size'], cfg['n_classes'], seed=9)
+    x, y = vo.synthetic_batch(cfg['batch'], cfg['voxel_size'], cfg['n_classes'], seed=9, portable=True)
     logits = model(x)
     loss = torch.nn.functional.cross_entropy(logits, y)
     loss.backward()
@@ -116,18 +116,23 @@ def run_case(name, cfg):
 def tokenizer_cases():
     from models import embed_layer_3d_modality as ref_embed
     out = {}
-    g = torch.Generator().manual_seed(11)
+    sid = [0]
+
+    def pu(shape):
+        sid[0] += 1
+        return vo.portable_uniform(tuple(shape), 11, sid[0]).float()
+
     for tag, cls, V, c, P, D, B in [('ve30', 'VoxelEmbed', 30, 6, 5, 384, 2), ('ve32', 'VoxelEmbed', 32, 6, 5, 384, 2),
                                     ('na128', 'VoxelEmbed_no_average', 128, 9, 14, 768, 1),
                                     ('np30', 'VoxelNaiveProjection', 30, 6, 5, 384, 2),
                                     ('ve128', 'VoxelEmbed', 128, 16, 8, 768, 1)]:
         m = getattr(ref_embed, cls)(voxel_size=V, cell_size=c, patch_size=P, embed_dim=D)
         conv = m.proj[0]
-        w = (torch.rand(conv.weight.shape, generator=g) - 0.5) * 0.2
-        b = (torch.rand(conv.bias.shape, generator=g) - 0.5) * 0.2
+        w = (pu(conv.weight.shape) - 0.5) * 0.2
+        b = (pu(conv.bias.shape) - 0.5) * 0.2
         with torch.no_grad():
             conv.weight.copy_(w); conv.bias.copy_(b)
-        x = (torch.rand(B, 1, V, V, V, generator=g) < 0.1).float()
+        x = (pu((B, 1, V, V, V)) < 0.1).float()
         y = m(x).detach()
         flat = y.flatten()
         idx = sample_idx(flat.numel(), 4096)

