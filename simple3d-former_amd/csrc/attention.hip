@@ -20,9 +20,12 @@ __device__ __forceinline__ int slot_key(int s2, int h2, int j) {   // key (or qu
 }
 __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r >> 2) + 4 * h2; }
 
-__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p, bool ok) {
+// Fragment loads are unconditional: callers clamp token rows to N-1 (finite data) instead of predicating the load --
+// a `cond ? *p : 0` load makes hipcc branch and wait per load, serialising the latencies.  Out-of-range keys are
+// masked in the score tile and out-of-range queries are never stored, so clamped duplicates are harmless.
+__device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) {
     U128 u;
-    u.u = ok ? *reinterpret_cast<const uint4*>(p) : make_uint4(0, 0, 0, 0);
+    u.u = *reinterpret_cast<const uint4*>(p);
     return u.v;
 }
 
@@ -35,10 +38,9 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
     for (int i = 0; i < (32 * CPR) / 64; ++i) {
         const int c = lane + 64 * i;
         const int r = c / CPR, cc = c % CPR;
-        const int t = t0 + r;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (t < N) v = *reinterpret_cast<const uint4*>(g + row0_off + (long)t * st_ld + cc * 8);
-        *reinterpret_cast<uint4*>(lds + r * HD + cc * 8) = v;
+        const int t = min(t0 + r, N - 1);
+        *reinterpret_cast<uint4*>(lds + r * HD + cc * 8) =
+            *reinterpret_cast<const uint4*>(g + row0_off + (long)t * st_ld + cc * 8);
     }
 }
 
@@ -73,14 +75,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const long base = (long)b * p.sb * p.ld + h * HD;           // + t*st_ld + which*D + d
     const int q0 = qt * 32, qrow = q0 + l31;
     const bool qok = qrow < p.N;
+    const int qrow_c = min(qrow, p.N - 1);
 
     bf16x8 qh[NS], ql[SPLIT ? NS : 1];
     {
-        const long off = base + (long)qrow * st_ld + h2 * 8;
+        const long off = base + (long)qrow_c * st_ld + h2 * 8;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            qh[s] = ld_frag(p.qkv_hi + off + 16 * s, qok);
-            if constexpr (SPLIT) ql[s] = ld_frag(p.qkv_lo + off + 16 * s, qok);
+            qh[s] = ld_frag(p.qkv_hi + off + 16 * s);
+            if constexpr (SPLIT) ql[s] = ld_frag(p.qkv_lo + off + 16 * s);
         }
     }
     f32x16 o[NDB];
@@ -97,17 +100,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         stage_tile<HD>(ldsV, p.qkv_hi, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
         if constexpr (SPLIT) stage_tile<HD>(ldsV + 32 * HD, p.qkv_lo, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
 
-        const int krow = k0 + l31;
-        const bool kok = krow < p.N;
+        const int krow = min(k0 + l31, p.N - 1);
         const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const bf16x8 kh = ld_frag(p.qkv_hi + koff + 16 * s, kok);
+            const bf16x8 kh = ld_frag(p.qkv_hi + koff + 16 * s);
             if constexpr (SPLIT) {
-                const bf16x8 kl = ld_frag(p.qkv_lo + koff + 16 * s, kok);
+                const bf16x8 kl = ld_frag(p.qkv_lo + koff + 16 * s);
                 sacc = MFMA32(kl, qh[s], sacc);
                 sacc = MFMA32(kh, ql[s], sacc);
             }
@@ -201,28 +203,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     const long base = (long)b * p.sb * p.ld + h * HD;
     const int q0 = qt * 32, qrow = q0 + l31;
     const bool qok = qrow < p.N;
-    const long tokrow = (long)b * p.sb + (long)qrow * p.st;
+    const int qrow_c = min(qrow, p.N - 1);
+    const long tokrow = (long)b * p.sb + (long)qrow_c * p.st;
 
     bf16x8 qf[NS], dof[NS];
     float delta = 0.f;
     {
-        const long off = base + (long)qrow * st_ld + h2 * 8;
+        const long off = base + (long)qrow_c * st_ld + h2 * 8;
         const long doff = tokrow * p.lddo + h * HD + h2 * 8;
         const long ooff = tokrow * p.ldo + h * HD + h2 * 8;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            qf[s] = ld_frag(p.qkv_hi + off + 16 * s, qok);
-            dof[s] = ld_frag(p.dout + doff + 16 * s, qok);
+            qf[s] = ld_frag(p.qkv_hi + off + 16 * s);
+            dof[s] = ld_frag(p.dout + doff + 16 * s);
             U128 a, ol, d;
-            a.v = ld_frag(p.out_hi + ooff + 16 * s, qok);
-            ol.v = ld_frag(p.out_lo ? p.out_lo + ooff + 16 * s : p.out_hi, qok && p.out_lo != nullptr);
+            a.v = ld_frag(p.out_hi + ooff + 16 * s);
+            ol.v = ld_frag((p.out_lo ? p.out_lo : p.out_hi) + ooff + 16 * s);
             d.v = dof[s];
+            const float lo_on = p.out_lo ? 1.f : 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + bf2f(ol.h[j]));
+            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
         }
         delta += __shfl_xor(delta, 32, 64);
     }
-    const float lse_q = qok ? p.lse[(long)bh * p.N + qrow] : 0.f;
+    const float lse_q = p.lse[(long)bh * p.N + qrow_c];
     if (active && qok && h2 == 0) p.delta[(long)bh * p.N + qrow] = delta;
 
     f32x16 dq[NDB];
@@ -236,8 +240,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         const int k0 = kt * 32;
         __syncthreads();
         stage_tile<HD>(ldsK, p.qkv_hi, p.ld, base + p.D, st_ld, k0, p.N, lane);
-        const int krow = k0 + l31;
-        const bool kok = krow < p.N;
+        const int krow = min(k0 + l31, p.N - 1);
         const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
         const long voff = base + 2 * p.D + (long)krow * st_ld + h2 * 8;
         f32x16 sacc, dpacc;
@@ -245,8 +248,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            sacc = MFMA32(ld_frag(p.qkv_hi + koff + 16 * s, kok), qf[s], sacc);      // S^T  = K . Q^T
-            dpacc = MFMA32(ld_frag(p.qkv_hi + voff + 16 * s, kok), dof[s], dpacc);   // dP^T = V . dO^T
+            sacc = MFMA32(ld_frag(p.qkv_hi + koff + 16 * s), qf[s], sacc);      // S^T  = K . Q^T
+            dpacc = MFMA32(ld_frag(p.qkv_hi + voff + 16 * s), dof[s], dpacc);   // dP^T = V . dO^T
         }
         U128 dsf[2];
 #pragma unroll
@@ -303,14 +306,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     const long base = (long)b * p.sb * p.ld + h * HD;
     const int k0 = kt * 32, krow = k0 + l31;
     const bool kok = krow < p.N;
+    const int krow_c = min(krow, p.N - 1);
 
     bf16x8 kf[NS], vf[NS];
     {
-        const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
+        const long koff = base + p.D + (long)krow_c * st_ld + h2 * 8;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            kf[s] = ld_frag(p.qkv_hi + koff + 16 * s, kok);
-            vf[s] = ld_frag(p.qkv_hi + koff + p.D + 16 * s, kok);
+            kf[s] = ld_frag(p.qkv_hi + koff + 16 * s);
+            vf[s] = ld_frag(p.qkv_hi + koff + p.D + 16 * s);
         }
     }
     f32x16 dk[NDB], dv[NDB];
@@ -327,8 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         __syncthreads();
         stage_tile<HD>(ldsQ, p.qkv_hi, p.ld, base, st_ld, q0, p.N, lane);
         stage_tile<HD>(ldsDO, p.dout, p.lddo, dobase, st_lddo, q0, p.N, lane);
-        const int qrow = q0 + l31;
-        const bool qok = qrow < p.N;
+        const int qrow = min(q0 + l31, p.N - 1);
         const long qoff = base + (long)qrow * st_ld + h2 * 8;
         const long dooff = dobase + (long)qrow * st_lddo + h2 * 8;
         f32x16 sacc, dpacc;
@@ -336,8 +339,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            sacc = MFMA32(ld_frag(p.qkv_hi + qoff + 16 * s, qok), kf[s], sacc);     // S  = Q . K^T   (col = key)
-            dpacc = MFMA32(ld_frag(p.dout + dooff + 16 * s, qok), vf[s], dpacc);    // dP = dO . V^T
+            sacc = MFMA32(ld_frag(p.qkv_hi + qoff + 16 * s), kf[s], sacc);     // S  = Q . K^T   (col = key)
+            dpacc = MFMA32(ld_frag(p.dout + dooff + 16 * s), vf[s], dpacc);    // dP = dO . V^T
         }
         U128 pf[2], dsf[2];
 #pragma unroll
@@ -347,8 +350,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 const int r = 8 * s2 + j;
                 const int q = q0 + acc_row(r, h2);
                 const bool ok = kok && (q < p.N);
-                const float lse_r = ok ? p.lse[(long)bh * p.N + q] : 0.f;
-                const float del_r = ok ? p.delta[(long)bh * p.N + q] : 0.f;
+                const int qc = min(q, p.N - 1);
+                const float lse_r = p.lse[(long)bh * p.N + qc];
+                const float del_r = p.delta[(long)bh * p.N + qc];
                 const float pr = ok ? expf(sacc[r] * p.scale - lse_r) : 0.f;
                 pf[s2].h[j] = f2bf(pr);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] - del_r) * p.scale);

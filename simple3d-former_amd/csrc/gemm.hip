@@ -53,6 +53,10 @@ struct Stager {
     static constexpr int NT = T ? (BR * 4 + 255) / 256 : BR / 32;       // tasks per thread
     static constexpr int NV = T ? 2 * NT : NT;                          // 16-byte vectors per plane per thread
 
+    // Loads are UNCONDITIONAL (clamped addresses) and zero-filled by a select afterwards: a `cond ? *p : 0` load makes
+    // hipcc branch around every load and wait for each one separately, which serialises the HBM/L2 latencies.
+    // Rows beyond R only feed out-of-range outputs (never stored), so they are clamped, not zeroed; k beyond kend
+    // must read as zero.
     __device__ static __forceinline__ void load(uint4 (&v)[NV], const bf16_t* __restrict__ base, long ld, int r0,
                                                 int k0, int R, int kend, int tid) {
         const uint4 zero = make_uint4(0, 0, 0, 0);
@@ -60,19 +64,27 @@ struct Stager {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int r = (tid >> 3) + i * 32, kc = tid & 7;
-                const int gr = r0 + r, gk = k0 + kc * 8;
-                v[i] = (gr < R && gk < kend) ? *reinterpret_cast<const uint4*>(base + (long)gr * ld + gk) : zero;
+                const int gr = min(r0 + r, R - 1), gk = k0 + kc * 8;
+                const bool ok = gk < kend;
+                const uint4 t = *reinterpret_cast<const uint4*>(base + (long)gr * ld + (ok ? gk : 0));
+                v[i] = ok ? t : zero;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int q = tid + j * 256;
                 const int rc = q % CH, kp = q / CH;
-                const int gk = k0 + 2 * kp, gr = r0 + rc * 8;
-                const bool ok = (q < CH * 32) && (gr < R);
-                v[2 * j] = (ok && gk < kend) ? *reinterpret_cast<const uint4*>(base + (long)gk * ld + gr) : zero;
-                v[2 * j + 1] =
-                    (ok && gk + 1 < kend) ? *reinterpret_cast<const uint4*>(base + (long)(gk + 1) * ld + gr) : zero;
+                const int gk = k0 + 2 * kp, gr = min(r0 + rc * 8, R - 8);
+                if (NT * 256 == CH * 32 || q < CH * 32) {      // wave-uniform (only BR = 32 leaves waves idle)
+                    const bool ok0 = gk < kend, ok1 = gk + 1 < kend;
+                    const uint4 t0 = *reinterpret_cast<const uint4*>(base + (long)(ok0 ? gk : 0) * ld + gr);
+                    const uint4 t1 = *reinterpret_cast<const uint4*>(base + (long)(ok1 ? gk + 1 : 0) * ld + gr);
+                    v[2 * j] = ok0 ? t0 : zero;
+                    v[2 * j + 1] = ok1 ? t1 : zero;
+                } else {
+                    v[2 * j] = zero;
+                    v[2 * j + 1] = zero;
+                }
             }
         }
     }

@@ -39,7 +39,10 @@ def fwd_kwargs(cfg):
 
 
 def check_grads_against_golden(z, grads, rtol, atol, names=None):
-    """grads: {name: tensor}.  Compares norm / sampled entries / full small tensors."""
+    """grads: {name: tensor}.  For every parameter compares (a) the gradient norm, (b) the RMS error over the sampled
+    entries and (c) the worst sampled entry, all relative to the rms of the reference gradient:
+        |norm - ref| <= 10*rtol*ref,   rms_err <= 10*rtol*rms,   max_err <= 40*rtol*rms   (+ atol)
+    (rtol=3e-3 -> 3 % / 3 % / 12 %: the plain-bf16 backward bar; rtol=1e-4 for the fp32 oracle)."""
     gold_names = json.loads(str(z['grad_names']))
     worst = 0.0
     for k in (names or gold_names):
@@ -47,16 +50,19 @@ def check_grads_against_golden(z, grads, rtol, atol, names=None):
         g = grads[k].detach().float().cpu().flatten()
         ref_norm = float(z['gnorm/' + k])
         idx = torch.from_numpy(z['gidx/' + k])
-        got = g[idx].numpy()
-        ref = z['gval/' + k]
+        got = g[idx].numpy().astype(np.float64)
+        ref = z['gval/' + k].astype(np.float64)
         scale = max(ref_norm / max(g.numel(), 1) ** 0.5, 1e-12)     # rms of the reference grad
-        err = np.abs(got - ref).max()
-        worst = max(worst, err / scale)
-        assert err <= atol + rtol * scale * 10, f'{k}: sampled grad max err {err:.3e} (rms {scale:.3e})'
+        diff = np.abs(got - ref)
+        rms_err, max_err = float(np.sqrt((diff ** 2).mean())), float(diff.max())
+        worst = max(worst, max_err / scale)
+        assert rms_err <= atol + 10 * rtol * scale, f'{k}: sampled grad rms err {rms_err:.3e} (grad rms {scale:.3e})'
+        assert max_err <= atol + 40 * rtol * scale, f'{k}: sampled grad max err {max_err:.3e} (grad rms {scale:.3e})'
         assert abs(float(g.double().norm()) - ref_norm) <= atol + rtol * ref_norm * 10 + 1e-12, \
             f'{k}: grad norm {float(g.norm()):.6e} vs {ref_norm:.6e}'
         if ('gfull/' + k) in z.files:
-            np.testing.assert_allclose(grads[k].detach().float().cpu().numpy().reshape(z['gfull/' + k].shape),
-                                       z['gfull/' + k], rtol=rtol * 10, atol=atol + rtol * scale * 10,
-                                       err_msg=k)
+            full = grads[k].detach().float().cpu().numpy().reshape(z['gfull/' + k].shape).astype(np.float64)
+            d = np.abs(full - z['gfull/' + k])
+            assert float(np.sqrt((d ** 2).mean())) <= atol + 10 * rtol * scale, f'{k}: full-tensor rms err'
+            assert float(d.max()) <= atol + 40 * rtol * scale, f'{k}: full-tensor max err {d.max():.3e} (rms {scale:.3e})'
     return worst
