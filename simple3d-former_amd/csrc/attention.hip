@@ -25,7 +25,7 @@ __device__ __forceinline__ int acc_row(int r, int h2) { return (r & 3) + 8 * (r 
 // masked in the score tile and out-of-range queries are never stored, so clamped duplicates are harmless.
 __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) {
     U128 u;
-    u.u = *reinterpret_cast<const uint4*>(p);
+    u.u = *reinterpret_cast<const u32x4*>(p);
     return u.v;
 }
 
@@ -39,8 +39,8 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
         const int c = lane + 64 * i;
         const int r = c / CPR, cc = c % CPR;
         const int t = min(t0 + r, N - 1);
-        *reinterpret_cast<uint4*>(lds + r * HD + cc * 8) =
-            *reinterpret_cast<const uint4*>(g + row0_off + (long)t * st_ld + cc * 8);
+        *reinterpret_cast<u32x4*>(lds + r * HD + cc * 8) =
+            *reinterpret_cast<const u32x4*>(g + row0_off + (long)t * st_ld + cc * 8);
     }
 }
 

@@ -8,6 +8,11 @@ typedef uint16_t bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+// NOTE: use these native vectors (not HIP's uint4/float4 structs) wherever a value is selected with ?: -- a ternary on
+// the struct types lowers to a select between ADDRESSES (one of them a stack temporary) and drags the operands into
+// scratch memory (measured: 80-300 B/lane of scratch and 3-5x slower GEMMs).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define S3D_WAVE 64
 
@@ -26,7 +31,7 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 }
 
 union U128 {
-    uint4 u;
+    u32x4 u;
     bf16x8 v;
     bf16_t h[8];
     uint32_t w[4];

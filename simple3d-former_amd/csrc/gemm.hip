@@ -57,16 +57,16 @@ struct Stager {
     // hipcc branch around every load and wait for each one separately, which serialises the HBM/L2 latencies.
     // Rows beyond R only feed out-of-range outputs (never stored), so they are clamped, not zeroed; k beyond kend
     // must read as zero.
-    __device__ static __forceinline__ void load(uint4 (&v)[NV], const bf16_t* __restrict__ base, long ld, int r0,
+    __device__ static __forceinline__ void load(u32x4 (&v)[NV], const bf16_t* __restrict__ base, long ld, int r0,
                                                 int k0, int R, int kend, int tid) {
-        const uint4 zero = make_uint4(0, 0, 0, 0);
+        const u32x4 zero = {0u, 0u, 0u, 0u};
         if constexpr (!T) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int r = (tid >> 3) + i * 32, kc = tid & 7;
                 const int gr = min(r0 + r, R - 1), gk = k0 + kc * 8;
                 const bool ok = gk < kend;
-                const uint4 t = *reinterpret_cast<const uint4*>(base + (long)gr * ld + (ok ? gk : 0));
+                const u32x4 t = *reinterpret_cast<const u32x4*>(base + (long)gr * ld + (ok ? gk : 0));
                 v[i] = ok ? t : zero;
             }
         } else {
@@ -77,8 +77,8 @@ struct Stager {
                 const int gk = k0 + 2 * kp, gr = min(r0 + rc * 8, R - 8);
                 if (NT * 256 == CH * 32 || q < CH * 32) {      // wave-uniform (only BR = 32 leaves waves idle)
                     const bool ok0 = gk < kend, ok1 = gk + 1 < kend;
-                    const uint4 t0 = *reinterpret_cast<const uint4*>(base + (long)(ok0 ? gk : 0) * ld + gr);
-                    const uint4 t1 = *reinterpret_cast<const uint4*>(base + (long)(ok1 ? gk + 1 : 0) * ld + gr);
+                    const u32x4 t0 = *reinterpret_cast<const u32x4*>(base + (long)(ok0 ? gk : 0) * ld + gr);
+                    const u32x4 t1 = *reinterpret_cast<const u32x4*>(base + (long)(ok1 ? gk + 1 : 0) * ld + gr);
                     v[2 * j] = ok0 ? t0 : zero;
                     v[2 * j + 1] = ok1 ? t1 : zero;
                 } else {
@@ -89,13 +89,13 @@ struct Stager {
         }
     }
 
-    __device__ static __forceinline__ void store(const uint4 (&v)[NV], unsigned char* lds, int tid) {
+    __device__ static __forceinline__ void store(const u32x4 (&v)[NV], unsigned char* lds, int tid) {
         if constexpr (!T) {
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int r = (tid >> 3) + i * 32, kc = tid & 7;
                 const int sw = (r ^ (r >> 3)) & 7;
-                *reinterpret_cast<uint4*>(lds + r * 128 + ((kc ^ sw) << 4)) = v[i];
+                *reinterpret_cast<u32x4*>(lds + r * 128 + ((kc ^ sw) << 4)) = v[i];
             }
         } else {
 #pragma unroll
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int kend = min(p.K, kbeg + p.kchunk);
     const int ntiles = (kend - kbeg + 63) >> 6;
 
-    uint4 va_hi[SA::NV], vb_hi[SB::NV];
-    uint4 va_lo[SPLIT ? SA::NV : 1], vb_lo[SPLIT ? SB::NV : 1];
+    u32x4 va_hi[SA::NV], vb_hi[SB::NV];
+    u32x4 va_lo[SPLIT ? SA::NV : 1], vb_lo[SPLIT ? SB::NV : 1];
 
     f32x4 acc[FM][FN];
 #pragma unroll

@@ -17,7 +17,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int col = c * 256 + lane * 4;
-        v[c] = (col < p.D) ? *reinterpret_cast<const float4*>(x + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 t = *reinterpret_cast<const float4*>(x + min(col, p.D - 4));      // unconditional, clamped
+        const float keep = (col < p.D) ? 1.f : 0.f;
+        v[c] = make_float4(t.x * keep, t.y * keep, t.z * keep, t.w * keep);
         s += v[c].x + v[c].y + v[c].z + v[c].w;
     }
     const float mean = wave_sum(s) / p.D;
