@@ -12,6 +12,8 @@
 //   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
 #include "gemm.h"
 
+#include <stdlib.h>
+
 #include <array>
 #include <map>
 #include <vector>
@@ -124,9 +126,13 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int r, int
     return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((kc ^ sw) << 4));
 }
 
+// PD = register prefetch distance (tiles of global loads in flight per thread).  These GEMMs are small (M = 1664
+// rows at cfg-2) and latency-bound: bytes in flight per CU / memory latency sets the rate, so the loads of tile
+// t+PD are issued before tile t is consumed.
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int PD = (BM * BN >= 128 * 128) ? 2 : 3;
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
@@ -136,13 +142,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile mapping: the dispatcher places consecutive workgroups on consecutive XCDs (private L2 each).
+    // Give every XCD a contiguous run of row-major tile ids so workgroups that share an A row-panel (and the B
+    // panel walk) hit the same L2 instead of fetching the panel once per XCD.  Pure speed; any placement is correct.
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    {
+        const int ntile = gridDim.x * gridDim.y;
+        const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any ntile
+    }
+    const int m0 = (tile_id / gridDim.x) * BM, n0 = (tile_id % gridDim.x) * BN;
     const int kbeg = blockIdx.z * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int ntiles = (kend - kbeg + 63) >> 6;
 
-    u32x4 va_hi[SA::NV], vb_hi[SB::NV];
-    u32x4 va_lo[SPLIT ? SA::NV : 1], vb_lo[SPLIT ? SB::NV : 1];
+    u32x4 va_hi[PD][SA::NV], vb_hi[PD][SB::NV];
+    u32x4 va_lo[PD][SPLIT ? SA::NV : 1], vb_lo[PD][SPLIT ? SB::NV : 1];
 
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // bias-gradient partials (TN only): row sums of the A operand over k, taken from the staged registers
     float bsum[TA ? SA::NT : 1][8];
-    const bool want_bsum = TA && (EPI == EPI_ATOMIC) && p.bias_grad != nullptr && blockIdx.x == 0;
+    const bool want_bsum = TA && (EPI == EPI_ATOMIC) && p.bias_grad != nullptr && (tile_id % gridDim.x) == 0;
     if constexpr (TA) {
 #pragma unroll
         for (int j = 0; j < SA::NT; ++j)
@@ -160,120 +175,170 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < 8; ++i) bsum[j][i] = 0.f;
     }
 
-    auto gload = [&](int t) {
-        const int k0 = kbeg + t * 64;
-        SA::load(va_hi, p.A_hi, p.lda, m0, k0, p.M, kend, tid);
-        SB::load(vb_hi, p.B_hi, p.ldb, n0, k0, p.N, kend, tid);
-        if constexpr (SPLIT) {
-            SA::load(va_lo, p.A_lo, p.lda, m0, k0, p.M, kend, tid);
-            SB::load(vb_lo, p.B_lo, p.ldb, n0, k0, p.N, kend, tid);
-        }
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* s = smem + buf * STAGE;
-        SA::store(va_hi, s, tid);
-        if constexpr (SPLIT) SA::store(va_lo, s + A_BYTES, tid);
-        SB::store(vb_hi, s + NPL * A_BYTES, tid);
-        if constexpr (SPLIT) SB::store(vb_lo, s + NPL * A_BYTES + B_BYTES, tid);
-        if constexpr (TA) {
-            if (want_bsum) {
-#pragma unroll
-                for (int j = 0; j < SA::NT; ++j) {
-                    U128 a, b;
-                    a.u = va_hi[2 * j];
-                    b.u = va_hi[2 * j + 1];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) bsum[j][i] += bf2f(a.h[i]) + bf2f(b.h[i]);
-                }
-            }
-        }
-    };
+#define GLOAD(SET, T)                                                                     \
+    do {                                                                                  \
+        const int k0__ = kbeg + (T) * 64;                                                 \
+        SA::load(va_hi[SET], p.A_hi, p.lda, m0, k0__, p.M, kend, tid);                    \
+        SB::load(vb_hi[SET], p.B_hi, p.ldb, n0, k0__, p.N, kend, tid);                    \
+        if constexpr (SPLIT) {                                                            \
+            SA::load(va_lo[SET], p.A_lo, p.lda, m0, k0__, p.M, kend, tid);                \
+            SB::load(vb_lo[SET], p.B_lo, p.ldb, n0, k0__, p.N, kend, tid);                \
+        }                                                                                 \
+    } while (0)
+#define LSTORE(SET, BUF)                                                                  \
+    do {                                                                                  \
+        unsigned char* s__ = smem + (BUF) * STAGE;                                        \
+        SA::store(va_hi[SET], s__, tid);                                                  \
+        if constexpr (SPLIT) SA::store(va_lo[SET], s__ + A_BYTES, tid);                   \
+        SB::store(vb_hi[SET], s__ + NPL * A_BYTES, tid);                                  \
+        if constexpr (SPLIT) SB::store(vb_lo[SET], s__ + NPL * A_BYTES + B_BYTES, tid);   \
+        if constexpr (TA) {                                                               \
+            if (want_bsum) {                                                              \
+                _Pragma("unroll") for (int j = 0; j < SA::NT; ++j) {                      \
+                    U128 a__, b__;                                                        \
+                    a__.u = va_hi[SET][2 * j];                                            \
+                    b__.u = va_hi[SET][2 * j + 1];                                        \
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i)                         \
+                        bsum[j][i] += bf2f(a__.h[i]) + bf2f(b__.h[i]);                    \
+                }                                                                         \
+            }                                                                             \
+        }                                                                                 \
+    } while (0)
 
-    if (ntiles > 0) {
-        gload(0);
-        lstore(0);
-    }
+    // prologue: tiles 0 .. PD-1 in flight, tile 0 staged into LDS buffer 0
+#pragma unroll
+    for (int u = 0; u < PD; ++u)
+        if (u < ntiles) GLOAD(u, u);
+    if (ntiles > 0) LSTORE(0, 0);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
-        const bool more = (t + 1 < ntiles);
-        if (more) gload(t + 1);
-        const unsigned char* s = smem + (t & 1) * STAGE;
-        const unsigned char* sA = s;
-        const unsigned char* sB = s + NPL * A_BYTES;
+    for (int t0 = 0; t0 < ntiles; t0 += PD) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kc = ks * 4 + (lane >> 4);
-            bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
+        for (int u = 0; u < PD; ++u) {
+            const int t = t0 + u;
+            if (t < ntiles) {                                  // block-uniform
+                // register set u held tile t (already staged) -> refill it with tile t+PD
+                if (t + PD < ntiles) GLOAD(u, t + PD);
+                const unsigned char* s = smem + (t & 1) * STAGE;
+                const unsigned char* sA = s;
+                const unsigned char* sB = s + NPL * A_BYTES;
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int r = wm * (BM / 2) + i * 16 + (lane & 15);
-                a_hi[i] = read_frag(sA, r, kc);
-                if constexpr (SPLIT) a_lo[i] = read_frag(sA + A_BYTES, r, kc);
-            }
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int kc = ks * 4 + (lane >> 4);
+                    bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int r = wn * (BN / 2) + j * 16 + (lane & 15);
-                b_hi[j] = read_frag(sB, r, kc);
-                if constexpr (SPLIT) b_lo[j] = read_frag(sB + B_BYTES, r, kc);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    if constexpr (SPLIT) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < FM; ++i) {
+                        const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+                        a_hi[i] = read_frag(sA, r, kc);
+                        if constexpr (SPLIT) a_lo[i] = read_frag(sA + A_BYTES, r, kc);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int r = wn * (BN / 2) + j * 16 + (lane & 15);
+                        b_hi[j] = read_frag(sB, r, kc);
+                        if constexpr (SPLIT) b_lo[j] = read_frag(sB + B_BYTES, r, kc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            if constexpr (EPI == EPI_ATOMIC) {     // natural order: lanes 0-15 = consecutive n
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                            } else {                               // swapped order: 4 consecutive n per lane
+                                if constexpr (SPLIT) {
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0);
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0);
+                                }
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+                            }
+                        }
                 }
+                // stage tile t+1 (register set (u+1)%PD) into the other LDS buffer
+                if (t + 1 < ntiles) LSTORE((u + 1) % PD, (t + 1) & 1);
+                __syncthreads();
+            }
         }
-        if (more) lstore((t + 1) & 1);
-        __syncthreads();
     }
+#undef GLOAD
+#undef LSTORE
 
     // ---------------------------------------------------------------- epilogue
-    // C/D layout of v_mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // The MFMAs are issued with the operand roles swapped (B fragment first), i.e. they produce the TRANSPOSED tile
+    // D'[n][m]; in the 16x16 C/D layout (col = lane & 15, row = (lane >> 4) * 4 + reg) each lane therefore owns row
+    // m = lane & 15 and FOUR CONSECUTIVE columns n = (lane >> 4) * 4 + reg of the row-major output: 8-byte (bf16) /
+    // 16-byte (fp32) vector stores instead of four scattered 2-byte ones.  The split-K wgrad epilogue keeps the natural
+    // order instead: its fp32 atomics resolve beyond the per-XCD L2 and are ~2.4x faster when the 16 lanes of a quarter
+    // wave hit one 64-byte line (measured 15 us vs 37 us per wgrad launch).
+    if constexpr (EPI == EPI_ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < p.M && n < p.N) atomic_add_f32(&p.C[(long)m * p.ldc + n], acc[i][j][r] * p.alpha);
+                }
+            }
+    } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
-                if (m >= p.M || n >= p.N) continue;
-                float v = acc[i][j][r];
-                if constexpr (EPI == EPI_BF16_BIAS) {
-                    v = v * p.alpha + (p.bias ? p.bias[n] : 0.f);
-                    bf16_t hi, lo;
-                    split_bf16(v, hi, lo);
-                    p.O_hi[(long)m * p.ldo + n] = hi;
-                    if (p.O_lo) p.O_lo[(long)m * p.ldo + n] = lo;
-                } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
-                    v += p.bias[n];
-                    if (p.aux) p.aux[(long)m * p.ldaux + n] = f2bf(v);
-                    const float a = (EPI == EPI_GELU) ? gelu_erf(v) : fmaxf(v, 0.f);
-                    bf16_t hi, lo;
-                    split_bf16(a, hi, lo);
-                    p.O_hi[(long)m * p.ldo + n] = hi;
-                    if (p.O_lo) p.O_lo[(long)m * p.ldo + n] = lo;
-                } else if constexpr (EPI == EPI_RESID) {
-                    p.C[(long)m * p.ldc + n] = v + p.bias[n] + p.R[(long)m * p.ldr + n];
-                } else if constexpr (EPI == EPI_TOKEN) {
-                    const int t = m % p.ntok;
-                    p.C[(long)m * p.ldc + n] = v * p.alpha + (t == 0 ? p.cls[n] : p.bias[n]) + p.pos[(long)t * p.N + n];
-                } else if constexpr (EPI == EPI_F32) {
-                    p.C[(long)m * p.ldc + n] = v * p.alpha + (p.bias ? p.bias[n] : 0.f);
-                } else if constexpr (EPI == EPI_DGELU) {
-                    p.O_hi[(long)m * p.ldo + n] = f2bf(v * gelu_erf_grad(bf2f(p.aux[(long)m * p.ldaux + n])));
-                } else if constexpr (EPI == EPI_DRELU) {
-                    p.O_hi[(long)m * p.ldo + n] = f2bf(bf2f(p.aux[(long)m * p.ldaux + n]) > 0.f ? v : 0.f);
-                } else if constexpr (EPI == EPI_ATOMIC) {
-                    atomic_add_f32(&p.C[(long)m * p.ldc + n], v * p.alpha);
+            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
+            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
+            if (m >= p.M || n >= p.N) continue;                 // N % 4 == 0: the quad is all-in or all-out
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float bq[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI != EPI_ATOMIC && EPI != EPI_DGELU && EPI != EPI_DRELU) {
+                if (p.bias) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    bq[0] = t[0]; bq[1] = t[1]; bq[2] = t[2]; bq[3] = t[3];
                 }
             }
+            union { u32x2 u; bf16_t h[4]; } hi, lo, ax;
+            if constexpr (EPI == EPI_BF16_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) split_bf16(v[r] * p.alpha + bq[r], hi.h[r], lo.h[r]);
+                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
+                if (p.O_lo) *reinterpret_cast<u32x2*>(p.O_lo + (long)m * p.ldo + n) = lo.u;
+            } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = v[r] + bq[r];
+                    ax.h[r] = f2bf(pre);
+                    split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f), hi.h[r], lo.h[r]);
+                }
+                if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (long)m * p.ldaux + n) = ax.u;
+                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
+                if (p.O_lo) *reinterpret_cast<u32x2*>(p.O_lo + (long)m * p.ldo + n) = lo.u;
+            } else if constexpr (EPI == EPI_RESID) {
+                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + n);
+                f32x4 o = {v[0] + bq[0] + rr[0], v[1] + bq[1] + rr[1], v[2] + bq[2] + rr[2], v[3] + bq[3] + rr[3]};
+                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
+            } else if constexpr (EPI == EPI_TOKEN) {
+                const int t = m % p.ntok;
+                const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (long)t * p.N + n);
+                const f32x4 cl = *reinterpret_cast<const f32x4*>(p.cls + n);
+                f32x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha + (t == 0 ? cl[r] : bq[r]) + ps[r];
+                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
+            } else if constexpr (EPI == EPI_F32) {
+                f32x4 o = {v[0] * p.alpha + bq[0], v[1] * p.alpha + bq[1], v[2] * p.alpha + bq[2], v[3] * p.alpha + bq[3]};
+                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
+            } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+                ax.u = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = bf2f(ax.h[r]);
+                    hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] : 0.f));
+                }
+                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
+            }
         }
+    }
 
     if constexpr (TA && EPI == EPI_ATOMIC) {
         if (want_bsum) {   // block-uniform
@@ -349,7 +414,15 @@ int launch_nt(int epi, int tile, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+// tuning overrides (tools/gemm_bench.py): S3D_GEMM_TILE=0|1|2, S3D_GEMM_SPLITK=n
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : -1;
+}
+
 int s3d_gemm_pick_tile(int M, int N, int splitk) {
+    static const int forced = env_int("S3D_GEMM_TILE");
+    if (forced >= 0) return forced;
     auto count = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splitk; };
     if (count(128, 128) >= 512) return 2;
     if (count(64, 64) >= 384) return 1;
@@ -362,12 +435,15 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     S3D_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 (got %ld %ld)", a.lda, a.ldb);
     if (!ta) S3D_REQUIRE((a.K % 8) == 0, "gemm: K=%d must be a multiple of 8 for a k-contiguous A", a.K);
     if (!tb) S3D_REQUIRE((a.K % 8) == 0, "gemm: K=%d must be a multiple of 8 for a k-contiguous B", a.K);
+    S3D_REQUIRE((a.N % 4) == 0, "gemm: N=%d must be a multiple of 4 (vectorised epilogue)", a.N);
     if (ta) S3D_REQUIRE((a.M % 8) == 0, "gemm: M=%d must be a multiple of 8 for a k-major A", a.M);
     if (tb) S3D_REQUIRE((a.N % 8) == 0, "gemm: N=%d must be a multiple of 8 for a k-major B", a.N);
     if (split) S3D_REQUIRE(a.A_lo && a.B_lo, "gemm: split mode needs lo planes");
 
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
         S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");
+        static const int forced_sk = env_int("S3D_GEMM_SPLITK");
+        if (forced_sk > 0) splitk = forced_sk;
         if (splitk <= 0) {
             const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             splitk = (int)((512 + tiles64 - 1) / tiles64);

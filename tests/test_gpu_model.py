@@ -194,6 +194,6 @@ def test_dp_trainer_segmented_graphs_and_rccl_path():
             l_dp = float(tr.step(x.to(DEV), y.to(DEV)))
             assert abs(l_ref - l_dp) <= 2e-3, f'step {step}: {l_ref} vs {l_dp}'
         d = (eng.arena.p - ref.arena.p).abs().max()
-        assert float(d) <= 2.5e-3          # 3 Adam steps of lr 1e-3; fp32-atomic ordering may flip near-zero grads
+        assert float(d) <= 6.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
         dist.destroy_process_group()
