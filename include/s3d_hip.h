@@ -203,6 +203,42 @@ int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, con
                    const S3dBlockActs* acts, const S3dBlockScratch* scratch, int first, int last,
                    s3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ group_embed
+ * nn.TransformerEncoderLayer(d_model=D, dim_feedforward=D, nhead=4) exactly as the reference builds and feeds it
+ * (models/vit_3d_2d_pretrain.py:381, :479): default batch_first=False and post-norm, so for the (G, Nb, D) input
+ * (G = B*P*P groups, Nb = P+1 tokens per group) self-attention runs over the G axis for each of the Nb positions, i.e.
+ * ACROSS the samples of the batch; ReLU feed-forward D -> Dff -> D; LayerNorm eps 1e-5.  Rows are r = g*Nb + t.
+ * Dropout (p = 0.1, four sites) is the identity here: eval-mode semantics. */
+typedef struct S3dEncShape {
+    int G, Nb, D, H, Dff;
+    float eps;
+    int split;
+} S3dEncShape;
+typedef struct S3dEncParams {
+    const float *in_b, *out_b, *l1_b, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+    const uint16_t *in_w_hi, *in_w_lo, *out_w_hi, *out_w_lo, *l1_w_hi, *l1_w_lo, *l2_w_hi, *l2_w_lo;
+} S3dEncParams;
+typedef struct S3dEncGrads {
+    float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+} S3dEncGrads;
+typedef struct S3dEncActs {      /* M = G*Nb rows */
+    float *x_in, *s1, *x1, *s2, *x_out;            /* fp32 [M][D] */
+    float *mean1, *rstd1, *mean2, *rstd2, *lse;    /* [M] x4, [Nb*H*G] */
+    uint16_t *xin_hi, *xin_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *x1_hi, *x1_lo;
+    uint16_t *fpre, *f_hi, *f_lo;                  /* [M][Dff] */
+} S3dEncActs;
+int s3d_encoder_layer_fwd(const S3dEncShape* shape, const S3dEncParams* params, const S3dEncActs* acts,
+                          s3d_stream_t stream);
+/* in: d(x_out) in scratch->dx_a; out: d(x_in) in scratch->dx_b (fp32) and scratch->dx_b_bf (bf16 copy). */
+int s3d_encoder_layer_bwd(const S3dEncShape* shape, const S3dEncParams* params, const S3dEncGrads* grads,
+                          const S3dEncActs* acts, const S3dBlockScratch* scratch, s3d_stream_t stream);
+
+/* pass-2 token assembly of group_embed (vit_3d_2d_pretrain.py:485-491): out[b*(n+1)+t] = (t==0 ? cls : src[b*n+t-1]) + pos[t]
+ * and the row gather of its backward: dsrc[b*n+j] = dout[b*(n+1)+1+j]. */
+int s3d_assemble_tokens(const float* src, const float* cls, const float* pos, float* out, long B, int n, int D,
+                        s3d_stream_t stream);
+int s3d_assemble_tokens_bwd(const float* dout, float* dsrc, long B, int n, int D, s3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -35,8 +35,8 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
                                            int N, int lane) {
     constexpr int CPR = HD / 8;                 // 16-byte chunks per row
 #pragma unroll
-    for (int i = 0; i < (32 * CPR) / 64; ++i) {
-        const int c = lane + 64 * i;
+    for (int i = 0; i < (32 * CPR + 63) / 64; ++i) {
+        const int c = min(lane + 64 * i, 32 * CPR - 1);
         const int r = c / CPR, cc = c % CPR;
         const int t = min(t0 + r, N - 1);
         *reinterpret_cast<u32x4*>(lds + r * HD + cc * 8) =
@@ -47,8 +47,9 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
 template <int HD>
 __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2, int col) {
     U128 u;
+    const int c = (HD % 32 == 0) ? col : min(col, HD - 1);   // partial last d-block: clamp (those outputs are dropped)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) u.h[j] = lds[slot_key(s2, h2, j) * HD + col];
+    for (int j = 0; j < 8; ++j) u.h[j] = lds[slot_key(s2, h2, j) * HD + c];
     return u.v;
 }
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2,
 template <int HD, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NS = HD / 16, NDB = HD / 32, NPL = SPLIT ? 2 : 1;
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     bf16_t* ldsV = reinterpret_cast<bf16_t*>(smem) + wave * (NPL * 32 * HD);
@@ -174,7 +175,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
                 union { uint2 u; bf16_t h[4]; } hi, lo;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) split_bf16(o[d][4 * c + i] * inv, hi.h[i], lo.h[i]);
-                const long off = orow + d * 32 + 8 * c + 4 * h2;
+                const int dcol = d * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                const long off = orow + dcol;
                 *reinterpret_cast<uint2*>(p.out_hi + off) = hi.u;
                 if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
             }
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NS = HD / 16, NDB = HD / 32;
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     bf16_t* ldsK = reinterpret_cast<bf16_t*>(smem) + wave * (32 * HD);
@@ -277,7 +280,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 union { uint2 u; bf16_t h[4]; } v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
-                *reinterpret_cast<uint2*>(p.dqkv + orow + d * 32 + 8 * c + 4 * h2) = v.u;
+                const int dcol = d * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                *reinterpret_cast<uint2*>(p.dqkv + orow + dcol) = v.u;
             }
     }
 }
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 template <int HD, int DSPLIT>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NS = HD / 16, NDB = HD / 32 / DSPLIT;
+    constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     bf16_t* ldsQ = reinterpret_cast<bf16_t*>(smem) + wave * (2 * 32 * HD);
@@ -376,7 +381,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 union { uint2 u; bf16_t h[4]; } a, v;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
-                const long off = orow + (dblk0 + d) * 32 + 8 * c + 4 * h2;
+                const int dcol = (dblk0 + d) * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                const long off = orow + dcol;
                 *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
                 *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
             }
@@ -428,7 +435,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
 int check(const AttnArgs& a) {
     S3D_REQUIRE(a.H > 0 && a.D % a.H == 0, "attention: D=%d not divisible by H=%d", a.D, a.H);
     const int hd = a.D / a.H;
-    S3D_REQUIRE(hd == 64 || hd == 192 || hd == 256, "attention: head dim %d not built (64/192/256)", hd);
+    S3D_REQUIRE(hd == 48 || hd == 64 || hd == 96 || hd == 192 || hd == 256, "attention: head dim %d not built (48/64/96/192/256)", hd);
     S3D_REQUIRE(a.N > 0 && a.Bb > 0, "attention: empty problem");
     S3D_REQUIRE(a.ld % 8 == 0 && a.ldo % 8 == 0, "attention: leading dims must be multiples of 8");
     return 0;
@@ -440,7 +447,9 @@ int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s) {
     if (int e = check(a)) return e;
     if (split) S3D_REQUIRE(a.qkv_lo != nullptr, "attention: split mode needs the lo plane");
     switch (a.D / a.H) {
+        case 48: return fwd_hd<48>(a, split, s);
         case 64: return fwd_hd<64>(a, split, s);
+        case 96: return fwd_hd<96>(a, split, s);
         case 192: return fwd_hd<192>(a, split, s);
         default: return fwd_hd<256>(a, split, s);
     }
@@ -450,7 +459,9 @@ int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
     if (int e = check(a)) return e;
     S3D_REQUIRE(a.lddo % 8 == 0 && a.lddq % 8 == 0, "attention: leading dims must be multiples of 8");
     switch (a.D / a.H) {
+        case 48: return bwd_hd<48, 1>(a, s);
         case 64: return bwd_hd<64, 1>(a, s);
+        case 96: return bwd_hd<96, 1>(a, s);
         case 192: return bwd_hd<192, 2>(a, s);
         default: return bwd_hd<256, 2>(a, s);
     }

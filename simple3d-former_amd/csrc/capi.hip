@@ -131,6 +131,87 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     return 0;
 }
 
+// ---- seq-first post-norm encoder layer (group_embed) ----
+int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, hipStream_t s) {
+    const long M = (long)sh.G * sh.Nb;
+    const int D = sh.D, F = sh.Dff;
+    const bool split = sh.split != 0;
+    S3D_REQUIRE(M < (1L << 31), "encoder layer: too many rows");
+    S3D_TRY(s3d_launch_split(a.x_in, a.xin_hi, split ? a.xin_lo : nullptr, M, D, D, s));
+    GemmArgs g = gemm_zero();                       // qkv = x @ Win^T + b
+    g.A_hi = a.xin_hi; g.A_lo = a.xin_lo; g.lda = D; g.B_hi = p.in_w_hi; g.B_lo = p.in_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = 3 * D; g.K = D; g.bias = p.in_b; g.O_hi = a.qkv_hi; g.O_lo = split ? a.qkv_lo : nullptr; g.ldo = 3 * D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_BF16_BIAS, g, 1, s));
+    AttnArgs at;                                    // attention over the group axis: row(b=t, token=g) = t + g*Nb
+    memset(&at, 0, sizeof(at));
+    at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = split ? a.att_lo : nullptr;
+    at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    S3D_TRY(s3d_launch_attention_fwd(at, split, s));
+    g = gemm_zero();                                // s1 = x + att @ Wo^T + bo
+    g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.out_w_hi; g.B_lo = p.out_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = D; g.K = D; g.bias = p.out_b; g.R = a.x_in; g.ldr = D; g.C = a.s1; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    LnArgs ln;                                      // x1 = LN1(s1)
+    memset(&ln, 0, sizeof(ln));
+    ln.x = a.s1; ln.ldx = D; ln.rows = M; ln.D = D; ln.eps = sh.eps; ln.gamma = p.n1_w; ln.beta = p.n1_b;
+    ln.out_hi = a.x1_hi; ln.out_lo = split ? a.x1_lo : nullptr; ln.out_f32 = a.x1; ln.ldo = D; ln.mean = a.mean1; ln.rstd = a.rstd1;
+    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    g = gemm_zero();                                // f = relu(x1 @ W1^T + b1)
+    g.A_hi = a.x1_hi; g.A_lo = a.x1_lo; g.lda = D; g.B_hi = p.l1_w_hi; g.B_lo = p.l1_w_lo; g.ldb = D;
+    g.M = (int)M; g.N = F; g.K = D; g.bias = p.l1_b; g.aux = a.fpre; g.ldaux = F; g.O_hi = a.f_hi; g.O_lo = split ? a.f_lo : nullptr; g.ldo = F;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RELU, g, 1, s));
+    g = gemm_zero();                                // s2 = x1 + f @ W2^T + b2
+    g.A_hi = a.f_hi; g.A_lo = a.f_lo; g.lda = F; g.B_hi = p.l2_w_hi; g.B_lo = p.l2_w_lo; g.ldb = F;
+    g.M = (int)M; g.N = D; g.K = F; g.bias = p.l2_b; g.R = a.x1; g.ldr = D; g.C = a.s2; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    ln.x = a.s2; ln.gamma = p.n2_w; ln.beta = p.n2_b; ln.out_hi = nullptr; ln.out_lo = nullptr; ln.out_f32 = a.x_out;
+    ln.mean = a.mean2; ln.rstd = a.rstd2;           // x_out = LN2(s2)
+    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    return 0;
+}
+
+int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr, const S3dEncActs& a,
+            const S3dBlockScratch& w, hipStream_t s) {
+    const long M = (long)sh.G * sh.Nb;
+    const int D = sh.D, F = sh.Dff;
+    LnBwdArgs lb;                                   // ds2 = LN2'(dx_out)            -> dx_b (+bf16)
+    memset(&lb, 0, sizeof(lb));
+    lb.dy = w.dx_a; lb.lddy = D; lb.x = a.s2; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.n2_w;
+    lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D; lb.dgamma = gr.n2_w; lb.dbeta = gr.n2_b; lb.rows = M; lb.D = D;
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    S3D_TRY(wgrad(w.dx_b_bf, D, a.f_hi, F, M, gr.l2_w, gr.l2_b, s));
+    GemmArgs g = gemm_zero();                       // df = (ds2 @ W2) * relu'(fpre)   -> dh
+    g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.l2_w_hi; g.ldb = F; g.M = (int)M; g.N = F; g.K = D;
+    g.aux = a.fpre; g.ldaux = F; g.O_hi = w.dh; g.ldo = F;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DRELU, g, 1, s));
+    S3D_TRY(wgrad(w.dh, F, a.x1_hi, D, M, gr.l1_w, gr.l1_b, s));
+    g = gemm_zero();                                // g1 = df @ W1 + ds2              -> dxn
+    g.A_hi = w.dh; g.lda = F; g.B_hi = p.l1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = F; g.R = w.dx_b; g.ldr = D;
+    g.C = w.dxn; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_RESID, g, 1, s));
+    lb.dy = w.dxn; lb.x = a.s1; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.n1_w; lb.dx = w.dx_a; lb.dx_bf = w.dx_a_bf;
+    lb.dgamma = gr.n1_w; lb.dbeta = gr.n1_b;        // ds1 = LN1'(g1)                  -> dx_a (+bf16)
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    S3D_TRY(wgrad(w.dx_a_bf, D, a.att_hi, D, M, gr.out_w, gr.out_b, s));
+    g = gemm_zero();                                // datt = ds1 @ Wo
+    g.A_hi = w.dx_a_bf; g.lda = D; g.B_hi = p.out_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_BF16_BIAS, g, 1, s));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
+    at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+    S3D_TRY(s3d_launch_attention_bwd(at, s));
+    S3D_TRY(wgrad(w.dqkv, 3 * D, a.xin_hi, D, M, gr.in_w, gr.in_b, s));
+    g = gemm_zero();                                // dx = dqkv @ Win + ds1           -> dx_b (+bf16 copy)
+    g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.in_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.R = w.dx_a; g.ldr = D;
+    g.C = w.dx_b; g.ldc = D; g.O_hi = w.dx_b_bf; g.ldo = D;
+    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_RESID, g, 1, s));
+    return 0;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- extern "C"
@@ -143,7 +224,7 @@ size_t s3d_sizeof(const char* n) {
 #define SZ(T) if (strcmp(n, #T) == 0) return sizeof(T)
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
-    SZ(S3dBlockActs); SZ(S3dBlockScratch);
+    SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs);
 #undef SZ
     return 0;
 }
@@ -218,6 +299,22 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     S3D_REQUIRE(sh && p && g && a && w, "s3d_blocks_bwd: null args");
     for (int i = first; i >= last; --i) S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s)));
     return 0;
+}
+
+int s3d_encoder_layer_fwd(const S3dEncShape* sh, const S3dEncParams* p, const S3dEncActs* a, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && a, "s3d_encoder_layer_fwd: null args");
+    return enc_fwd(*sh, *p, *a, st(s));
+}
+int s3d_encoder_layer_bwd(const S3dEncShape* sh, const S3dEncParams* p, const S3dEncGrads* g, const S3dEncActs* a,
+                          const S3dBlockScratch* w, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && g && a && w, "s3d_encoder_layer_bwd: null args");
+    return enc_bwd(*sh, *p, *g, *a, *w, st(s));
+}
+int s3d_assemble_tokens(const float* src, const float* cls, const float* pos, float* out, long B, int n, int D, s3d_stream_t s) {
+    return s3d_launch_assemble(src, cls, pos, out, B, n, D, st(s));
+}
+int s3d_assemble_tokens_bwd(const float* dout, float* dsrc, long B, int n, int D, s3d_stream_t s) {
+    return s3d_launch_assemble_bwd(dout, dsrc, B, n, D, st(s));
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@
 enum {
     EPI_BF16_BIAS = S3D_EPI_BF16_BIAS,  // O_hi/O_lo = split(acc*alpha + bias[n])                     (qkv, generic linear)
     EPI_GELU = S3D_EPI_GELU,            // pre = acc + bias; aux = bf16(pre); O = split(gelu(pre))    (mlp.fc1)
-    EPI_RESID = S3D_EPI_RESID,          // C = acc + bias[n] + R[m][n]                                (attn.proj, mlp.fc2)
+    EPI_RESID = S3D_EPI_RESID,          // C = acc (+ bias[n]) + R[m][n]; optional bf16 copy in O_hi  (attn.proj, mlp.fc2, residual dgrads)
     EPI_TOKEN = S3D_EPI_TOKEN,          // C = acc*alpha + (m%ntok==0 ? cls[n] : bias[n]) + pos[(m%ntok)*N+n]
     EPI_F32 = S3D_EPI_F32,              // C = acc*alpha (+ bias[n])                                  (dgrad -> LayerNorm bwd)
     EPI_DGELU = S3D_EPI_DGELU,          // O_hi = bf16(acc * gelu'(aux[m][n]))                        (mlp.fc2 dgrad)

@@ -317,6 +317,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + n);
                 f32x4 o = {v[0] + bq[0] + rr[0], v[1] + bq[1] + rr[1], v[2] + bq[2] + rr[2], v[3] + bq[3] + rr[3]};
                 *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
+                if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hi.h[r] = f2bf(o[r]);
+                    *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
+                }
             } else if constexpr (EPI == EPI_TOKEN) {
                 const int t = m % p.ntok;
                 const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (long)t * p.N + n);
@@ -466,6 +471,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
             case EPI_F32: return launch_tiles<false, true, false, EPI_F32>(tile, a, 1, stream);
             case EPI_DGELU: return launch_tiles<false, true, false, EPI_DGELU>(tile, a, 1, stream);
             case EPI_DRELU: return launch_tiles<false, true, false, EPI_DRELU>(tile, a, 1, stream);
+            case EPI_RESID: return launch_tiles<false, true, false, EPI_RESID>(tile, a, 1, stream);
             case EPI_BF16_BIAS: return launch_tiles<false, true, false, EPI_BF16_BIAS>(tile, a, 1, stream);
             default: s3d_set_error("gemm: epilogue %d not available for NN", epi); return 2;
         }

@@ -17,6 +17,10 @@ int s3d_launch_fold(const FoldArgs& a, hipStream_t s);
 typedef S3dPosGradArgs PosGradArgs;
 int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s);
 
+// pass-2 token assembly of group_embed: out = cat(cls, src) + pos  (and the gather of its backward)
+int s3d_launch_assemble(const float* src, const float* cls, const float* pos, float* out, long B, int n, int D, hipStream_t s);
+int s3d_launch_assemble_bwd(const float* dout, float* dsrc, long B, int n, int D, hipStream_t s);
+
 // fp32 [rows][cols] -> split-bf16 planes with row pitch ld_out (pad columns untouched)
 int s3d_launch_split(const float* src, bf16_t* hi, bf16_t* lo, long rows, long cols, long ld_out, hipStream_t s);
 

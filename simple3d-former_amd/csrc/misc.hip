@@ -70,6 +70,34 @@ __global__ void posgrad_kernel(const PosGradArgs p, long gchunk) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- token assemble (pass 2)
+// out[b*(n+1) + t][:] = (t == 0 ? cls : src[b*n + t - 1]) + pos[t]      ('(b px py) c -> b (px py) c' + cat cls + pos add,
+// vit_3d_2d_pretrain.py:485-491);  bwd: dsrc[b*n + j] = dout[b*(n+1) + 1 + j]
+__global__ void assemble_tokens_kernel(const float* __restrict__ src, const float* __restrict__ cls,
+                                       const float* __restrict__ pos, float* __restrict__ out, long B, int n, int D) {
+    const long total = B * (n + 1) * (long)(D / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d4 = (int)(i % (D / 4));
+        const long row = i / (D / 4);
+        const int t = (int)(row % (n + 1));
+        const long b = row / (n + 1);
+        const f32x4 p4 = reinterpret_cast<const f32x4*>(pos + (long)t * D)[d4];
+        const f32x4 s4 = (t == 0) ? reinterpret_cast<const f32x4*>(cls)[d4]
+                                  : reinterpret_cast<const f32x4*>(src + (b * n + t - 1) * D)[d4];
+        reinterpret_cast<f32x4*>(out + row * D)[d4] = s4 + p4;
+    }
+}
+__global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc, long B, int n, int D) {
+    const long total = B * n * (long)(D / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d4 = (int)(i % (D / 4));
+        const long row = i / (D / 4);
+        const long b = row / n;
+        const int j = (int)(row % n);
+        reinterpret_cast<f32x4*>(dsrc + row * D)[d4] = reinterpret_cast<const f32x4*>(dout + (b * (n + 1) + 1 + j) * D)[d4];
+    }
+}
+
 // ------------------------------------------------------------------------------------------- fp32 -> split bf16
 __global__ void split_kernel(const float* __restrict__ src, bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long rows,
                              long cols, long ld) {
@@ -290,6 +318,22 @@ int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
     const int threads = a.D >= 256 ? 256 : 64;
     hipLaunchKernelGGL(posgrad_kernel, dim3(a.ntok, (unsigned)gs), dim3(threads), 0, s, a, gchunk);
     S3D_CHECK_LAUNCH("posgrad");
+    return 0;
+}
+
+int s3d_launch_assemble(const float* src, const float* cls, const float* pos, float* out, long B, int n, int D, hipStream_t s) {
+    S3D_REQUIRE(D % 4 == 0, "assemble: D must be a multiple of 4");
+    long blocks = (B * (n + 1) * (long)(D / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, cls, pos, out, B, n, D);
+    S3D_CHECK_LAUNCH("assemble_tokens");
+    return 0;
+}
+int s3d_launch_assemble_bwd(const float* dout, float* dsrc, long B, int n, int D, hipStream_t s) {
+    long blocks = (B * n * (long)(D / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(assemble_tokens_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dout, dsrc, B, n, D);
+    S3D_CHECK_LAUNCH("assemble_tokens_bwd");
     return 0;
 }
 

@@ -49,8 +49,19 @@ def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_emb
         shapes['voxel_embed.proj.conv3d_1.weight'] = (D, 1, c, c, c)
         shapes['voxel_embed.proj.conv3d_1.bias'] = (D,)
         ntok = (patch ** 2 if embed_layer == 'VoxelEmbed' else patch ** 3) + 1
-    if pos_embedding == 'group_embed':
-        raise NotImplementedError('group_embed is built on GroupVoxelEngine')
+    if pos_embedding == 'group_embed':      # vit_3d_2d_pretrain.py:377-383 (forward order: tokens -> encoder layer -> blocks)
+        if embed_layer != 'VoxelEmbed_no_average':
+            raise ValueError('group_embed needs the 5-D VoxelEmbed_no_average tokenizer (vit_3d_2d_pretrain.py:473-474)')
+        shapes['group_cls_token'] = (1, 1, D)
+        shapes['group_pos_embed'] = (1, patch + 1, D)
+        g = 'group_embed.'
+        shapes[g + 'self_attn.in_proj_weight'] = (3 * D, D); shapes[g + 'self_attn.in_proj_bias'] = (3 * D,)
+        shapes[g + 'self_attn.out_proj.weight'] = (D, D); shapes[g + 'self_attn.out_proj.bias'] = (D,)
+        shapes[g + 'linear1.weight'] = (D, D); shapes[g + 'linear1.bias'] = (D,)
+        shapes[g + 'linear2.weight'] = (D, D); shapes[g + 'linear2.bias'] = (D,)
+        shapes[g + 'norm1.weight'] = (D,); shapes[g + 'norm1.bias'] = (D,)
+        shapes[g + 'norm2.weight'] = (D,); shapes[g + 'norm2.bias'] = (D,)
+        ntok = patch ** 2 + 1
     shapes['cls_token'] = (1, 1, D)
     shapes['voxel_pos_embed'] = (1, ntok, D)
     for i in range(depth):
@@ -167,7 +178,7 @@ class VoxelEngine:
                  head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
-        if pos_embedding not in (None, 'default'):
+        if pos_embedding not in (None, 'default', 'group_embed'):
             raise ValueError("Unknown positional embedding scheme!")         # vit_3d_2d_pretrain.py:389
         if embed_layer not in FOLD_MODE:
             raise ValueError(f'unknown embed layer {embed_layer!r}')         # train_cls_voxel.py:138-142
@@ -176,8 +187,9 @@ class VoxelEngine:
         if self.device.type != 'cuda':
             raise RuntimeError('VoxelEngine runs on an MI355X (cuda/HIP device) only; the CPU reference lives in oracle/')
         cfg = BACKBONES[backbone]
+        self.group = pos_embedding == 'group_embed'
         self.cfg = dict(backbone=backbone, embed_layer=embed_layer, voxel_size=voxel_size, cell=cell, patch=patch,
-                        n_classes=n_classes, pos_embedding='default', head=head)
+                        n_classes=n_classes, pos_embedding='group_embed' if self.group else 'default', head=head)
         self.D, self.depth, self.H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
         self.hidden = 4 * self.D
         self.V, self.c, self.P, self.C = voxel_size, cell, patch, n_classes
@@ -185,13 +197,18 @@ class VoxelEngine:
         self.embed_layer = embed_layer
         self.fold_mode = FOLD_MODE[embed_layer]
         self.ntok = (patch ** 3 if embed_layer == 'VoxelEmbed_no_average' else patch ** 2) + 1
+        if self.group:                      # pass 1: B*P*P groups of P+1 tokens; pass 2: B sequences of P*P+1 tokens
+            self.fold_mode = 3
+            self.ntok = patch + 1
+            self.ntok2 = patch ** 2 + 1
+            self.enc_heads = 4              # nn.TransformerEncoderLayer(nhead=4), vit_3d_2d_pretrain.py:381
         self.Kc = cell ** 2 if embed_layer == 'VoxelNaiveProjection' else cell ** 3
         self.Kpad = _round_up(self.Kc, 8)
         self.am = head == 'AMSoftmax'
         self.split = bool(split)
         self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
         self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
-                                         n_classes=n_classes, head=head)
+                                         n_classes=n_classes, head=head, pos_embedding=self.cfg['pos_embedding'])
         self.arena = ParamArena(self.shapes, self.device)
         self._build_param_tables()
         if self.Kpad != self.Kc:   # padded conv-weight planes (row pitch Kpad) refreshed from the arena each step
@@ -225,6 +242,22 @@ class VoxelEngine:
                    proj_w=a.grad(p + 'attn.proj.weight'), proj_b=a.grad(p + 'attn.proj.bias'),
                    fc1_w=a.grad(p + 'mlp.fc1.weight'), fc1_b=a.grad(p + 'mlp.fc1.bias'),
                    fc2_w=a.grad(p + 'mlp.fc2.weight'), fc2_b=a.grad(p + 'mlp.fc2.bias'))
+        if self.group:
+            g = 'group_embed.'
+            self.eparams = L.fill(L.S3dEncParams(), in_b=a.param(g + 'self_attn.in_proj_bias'), out_b=a.param(g + 'self_attn.out_proj.bias'),
+                                  l1_b=a.param(g + 'linear1.bias'), l2_b=a.param(g + 'linear2.bias'),
+                                  n1_w=a.param(g + 'norm1.weight'), n1_b=a.param(g + 'norm1.bias'),
+                                  n2_w=a.param(g + 'norm2.weight'), n2_b=a.param(g + 'norm2.bias'),
+                                  in_w_hi=a.hi_of(g + 'self_attn.in_proj_weight'), in_w_lo=a.lo_of(g + 'self_attn.in_proj_weight'),
+                                  out_w_hi=a.hi_of(g + 'self_attn.out_proj.weight'), out_w_lo=a.lo_of(g + 'self_attn.out_proj.weight'),
+                                  l1_w_hi=a.hi_of(g + 'linear1.weight'), l1_w_lo=a.lo_of(g + 'linear1.weight'),
+                                  l2_w_hi=a.hi_of(g + 'linear2.weight'), l2_w_lo=a.lo_of(g + 'linear2.weight'))
+            self.egrads = L.fill(L.S3dEncGrads(), in_w=a.grad(g + 'self_attn.in_proj_weight'), in_b=a.grad(g + 'self_attn.in_proj_bias'),
+                                 out_w=a.grad(g + 'self_attn.out_proj.weight'), out_b=a.grad(g + 'self_attn.out_proj.bias'),
+                                 l1_w=a.grad(g + 'linear1.weight'), l1_b=a.grad(g + 'linear1.bias'),
+                                 l2_w=a.grad(g + 'linear2.weight'), l2_b=a.grad(g + 'linear2.bias'),
+                                 n1_w=a.grad(g + 'norm1.weight'), n1_b=a.grad(g + 'norm1.bias'),
+                                 n2_w=a.grad(g + 'norm2.weight'), n2_b=a.grad(g + 'norm2.bias'))
 
     def load_state_dict(self, sd):
         self.arena.load(sd)
@@ -260,13 +293,38 @@ class VoxelEngine:
         if ws is not None:
             return ws
         dev, D = self.device, self.D
-        M = B * self.ntok
+        G = B * self.P * self.P if self.group else B          # sequences in the (first) block pass
+        M = G * self.ntok
         ws = type('WS', (), {})()
-        ws.B, ws.M = B, M
+        ws.B, ws.M, ws.G = B, M, G
         ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
-        ws.blocks = _BlockWorkspace(self.depth, B, self.ntok, D, self.H, self.hidden, dev, self.split)
-        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, B * self.H * self.ntok, dev)
+        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split)
+        bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
+                  (B * self.H * self.ntok2) if self.group else 0)
+        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev)
+        if self.group:
+            f32 = dict(dtype=torch.float32, device=dev)
+            b16 = dict(dtype=torch.bfloat16, device=dev)
+            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split)
+            ws.M2 = B * self.ntok2
+            e = type('ENC', (), {})()
+            e.x_in = torch.empty(M, D, **f32); e.s1 = torch.empty(M, D, **f32); e.x1 = torch.empty(M, D, **f32)
+            e.s2 = torch.empty(M, D, **f32); e.stats = torch.empty(4, M, **f32)
+            e.lse = torch.empty(self.ntok * self.enc_heads * G, **f32)
+            e.xin = torch.empty(2, M, D, **b16); e.qkv = torch.empty(2, M, 3 * D, **b16); e.att = torch.empty(2, M, D, **b16)
+            e.x1p = torch.empty(2, M, D, **b16); e.fpre = torch.empty(M, D, **b16); e.f = torch.empty(2, M, D, **b16)
+            e.acts = L.fill(L.S3dEncActs(), x_in=e.x_in, s1=e.s1, x1=e.x1, s2=e.s2, x_out=ws.blocks.x[0], mean1=e.stats[0],
+                            rstd1=e.stats[1], mean2=e.stats[2], rstd2=e.stats[3], lse=e.lse, xin_hi=e.xin[0], xin_lo=e.xin[1],
+                            qkv_hi=e.qkv[0], qkv_lo=e.qkv[1], att_hi=e.att[0], att_lo=e.att[1], x1_hi=e.x1p[0], x1_lo=e.x1p[1],
+                            fpre=e.fpre, f_hi=e.f[0], f_lo=e.f[1])
+            e.shape = L.S3dEncShape(G=G, Nb=self.ntok, D=D, H=self.enc_heads, Dff=D, eps=1e-5, split=1 if self.split else 0)
+            ws.enc = e
+            ws.gstats = torch.empty(2, G, **f32)              # final-norm statistics of the pass-1 cls rows
+            ws.gfeat = torch.empty(G, D, **f32)               # norm(x)[:, 0] of pass 1  -> tokens of pass 2
+            ws.dgfeat = torch.empty(G, D, **f32)
         ws.fstats = torch.empty(2, B, dtype=torch.float32, device=dev)
+        ws.last = ws.blocks2 if self.group else ws.blocks      # the block pass whose cls rows feed the head
+        ws.ntok_last = self.ntok2 if self.group else self.ntok
         ws.feat = torch.empty(B, D, dtype=torch.float32, device=dev)
         ws.logits = torch.empty(B, self.C, dtype=torch.float32, device=dev)
         ws.dlogits = torch.empty(B, self.C, dtype=torch.float32, device=dev)
@@ -293,13 +351,28 @@ class VoxelEngine:
             w_hi, w_lo = self.conv_hi, self.conv_lo
         else:
             w_hi, w_lo = a.hi_of(ck + '.weight'), a.lo_of(ck + '.weight')
+        tok_out = ws.enc.x_in if self.group else ws.blocks.x[0]
         g = L.fill(L.S3dGemmArgs(), A_hi=ws.a[0], A_lo=ws.a[1], lda=self.Kpad, B_hi=w_hi, B_lo=w_lo, ldb=self.Kpad,
-                   M=ws.M, N=self.D, K=self.Kpad, bias=a.param(ck + '.bias'), C=ws.blocks.x[0], ldc=self.D,
-                   alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0), cls=a.param('cls_token'),
-                   pos=a.param('voxel_pos_embed'), ntok=self.ntok)
+                   M=ws.M, N=self.D, K=self.Kpad, bias=a.param(ck + '.bias'), C=tok_out, ldc=self.D,
+                   alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0),
+                   cls=a.param('group_cls_token' if self.group else 'cls_token'),
+                   pos=a.param('group_pos_embed' if self.group else 'voxel_pos_embed'), ntok=self.ntok)
         L.check(lib.s3d_gemm(0, 0, 1 if self.split else 0, 3, ctypes.byref(g), 1, s), 'tokenizer gemm')
+        if self.group:
+            # seq-first encoder layer over the B*P*P axis, then pass 1 of the blocks on (B*P*P, P+1, D)
+            L.check(lib.s3d_encoder_layer_fwd(ctypes.byref(ws.enc.shape), ctypes.byref(self.eparams),
+                                              ctypes.byref(ws.enc.acts), s), 'encoder_layer_fwd')
         L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, s), 'blocks_fwd')
-        ln = L.fill(L.S3dLnArgs(), x=ws.blocks.x[self.depth], ldx=self.ntok * self.D, rows=B, D=self.D, eps=LN_EPS,
+        if self.group:
+            # norm(x)[:, 0] of every group -> '(b px py) c -> b (px py) c' + cls + voxel_pos_embed -> pass 2 (same blocks)
+            ln1 = L.fill(L.S3dLnArgs(), x=ws.blocks.x[self.depth], ldx=self.ntok * self.D, rows=ws.G, D=self.D, eps=LN_EPS,
+                         gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.gfeat, ldo=self.D,
+                         mean=ws.gstats[0], rstd=ws.gstats[1])
+            L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln1), s), 'pass-1 final norm')
+            L.check(lib.s3d_assemble_tokens(L.ptr(ws.gfeat), L.ptr(a.param('cls_token')), L.ptr(a.param('voxel_pos_embed')),
+                                            L.ptr(ws.blocks2.x[0]), ctypes.c_long(B), self.P * self.P, self.D, s), 'assemble')
+            L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks2.shape), self.bparams, ws.blocks2.acts, self.depth, s), 'blocks_fwd 2')
+        ln = L.fill(L.S3dLnArgs(), x=ws.last.x[self.depth], ldx=ws.ntok_last * self.D, rows=B, D=self.D, eps=LN_EPS,
                     gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
                     mean=ws.fstats[0], rstd=ws.fstats[1])
         L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
@@ -342,17 +415,46 @@ class VoxelEngine:
         sc = ws.scratch
         sc.dx_a.zero_()
         sc.dx_a_bf.zero_()
-        lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
-                    mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
-                    dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
+        nt = ws.ntok_last
+        lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.last.x[self.depth], ldx=nt * D,
+                    mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=nt * D,
+                    dx_bf=sc.dx_a_bf, lddxbf=nt * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
                     rows=B, D=D)
         L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd')
         return ws
 
     def backward_segment(self, ws, first, last, with_tokenizer):
+        if self.group and first == self.depth - 1:
+            self._group_pass2_backward(ws)              # pass-2 blocks, token assembly, pass-1 final norm
         self.blocks_backward_range(ws, first, last)
         if with_tokenizer:
-            self._tokenizer_backward(ws)
+            if self.group:
+                sc = ws.scratch
+                L.check(self.lib.s3d_encoder_layer_bwd(ctypes.byref(ws.enc.shape), ctypes.byref(self.eparams),
+                                                       ctypes.byref(self.egrads), ctypes.byref(ws.enc.acts),
+                                                       ctypes.byref(sc.c), L.current_stream()), 'encoder_layer_bwd')
+                self._tokenizer_backward(ws, dx=sc.dx_b, dx_bf=sc.dx_b_bf)
+            else:
+                self._tokenizer_backward(ws)
+
+    def _group_pass2_backward(self, ws):
+        """Backward of the second application of the shared blocks (gradients ACCUMULATE into the same arena slots,
+        vit_3d_2d_pretrain.py:481-484 vs :493-496), of the token assembly and of the pass-1 final norm."""
+        lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
+        L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks2.shape), self.bparams, self.bgrads, ws.blocks2.acts,
+                                   ctypes.byref(sc.c), self.depth - 1, 0, s), 'blocks_bwd pass 2')
+        pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=ws.B, ntok=self.ntok2, D=D, dpos=a.grad('voxel_pos_embed'),
+                    dcls=a.grad('cls_token'))
+        L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'pass-2 token grads')
+        L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.dgfeat), ctypes.c_long(ws.B), self.P * self.P, D, s),
+                'assemble bwd')
+        sc.dx_a.zero_()
+        sc.dx_a_bf.zero_()
+        lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dgfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
+                    mean=ws.gstats[0], rstd=ws.gstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
+                    dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
+                    rows=ws.G, D=D)
+        L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'pass-1 final norm bwd')
 
     def backward(self, B, dlogits=None, *, segments=None, on_segment=None):
         """Accumulates d(loss)/d(param) into the gradient arena, given d(loss)/d(logits) (ws.dlogits by default).
@@ -384,20 +486,23 @@ class VoxelEngine:
         L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
                                         ctypes.byref(ws.scratch.c), first, last, L.current_stream()), 'blocks_bwd')
 
-    def _tokenizer_backward(self, ws):
+    def _tokenizer_backward(self, ws, dx=None, dx_bf=None):
         lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
+        dx = sc.dx_a if dx is None else dx
+        dx_bf = sc.dx_a_bf if dx_bf is None else dx_bf
         ck = self.conv_key
         padded = self.Kpad != self.Kc
         gw = self.conv_gpad if padded else a.grad(ck + '.weight')
         if padded:
             self.conv_gpad.zero_()
-        g = L.fill(L.S3dGemmArgs(), A_hi=sc.dx_a_bf, lda=D, B_hi=ws.a[0], ldb=self.Kpad, M=D, N=self.Kpad, K=ws.M,
+        g = L.fill(L.S3dGemmArgs(), A_hi=dx_bf, lda=D, B_hi=ws.a[0], ldb=self.Kpad, M=D, N=self.Kpad, K=ws.M,
                    C=gw, ldc=self.Kpad, alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0))
         L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), 'tokenizer wgrad')
         if padded:
             a.grad(ck + '.weight').view(D, self.Kc).add_(self.conv_gpad[:, :self.Kc])
-        pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=ws.B, ntok=self.ntok, D=D, dpos=a.grad('voxel_pos_embed'),
-                    dcls=a.grad('cls_token'), dbias=a.grad(ck + '.bias'))
+        pg = L.fill(L.S3dPosGradArgs(), dx=dx, groups=ws.G, ntok=self.ntok, D=D,
+                    dpos=a.grad('group_pos_embed' if self.group else 'voxel_pos_embed'),
+                    dcls=a.grad('group_cls_token' if self.group else 'cls_token'), dbias=a.grad(ck + '.bias'))
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'token grads')
 
     # ------------------------------------------------------------------ optimizer

@@ -208,12 +208,11 @@ class Feature3D_ViT2D_V2(VisionTransformer):
         device = torch.device(device) if device is not None else next(self.parameters()).device
         if self._engine is not None and self._engine.device == device:
             return self._engine
-        if self.pos_embed_type == 'group_embed':
-            raise NotImplementedError('group_embed runs on GroupVoxelEngine (cfg-3), not wired into this module yet')
         te = self.voxel_embed
         eng = VoxelEngine(backbone=self.transformer_backbone, embed_layer=type(te).__name__,
                           voxel_size=te.voxel_size[0], cell=te.cell_size[0], patch=te.patch_size,
-                          n_classes=self.n_classes, head=self.head_type, device=device)
+                          n_classes=self.n_classes, head=self.head_type, device=device,
+                          pos_embedding='group_embed' if self.pos_embed_type == 'group_embed' else 'default')
         own = dict(self.named_parameters())
         eng.load_state_dict({k: own[k].detach() for k in eng.shapes})
         for k in eng.shapes:                      # same Parameter objects (optimizers keep working), new storage

@@ -355,3 +355,77 @@ def test_block_fwd_bwd_matches_oracle(D, H, N, Bb):
     for k in shapes:
         e = rms_err(arena.grad(k), leaf[k].grad)
         assert e < 3e-2, f'{k}: grad rms err {e:.3e}'
+
+
+@pytest.mark.parametrize('D,G,Nb', [(192, 27, 4), (768, 40, 15), (384, 50, 6)])
+def test_group_encoder_layer_fwd_bwd_matches_oracle(D, G, Nb):
+    """nn.TransformerEncoderLayer(d_model=D, dim_feedforward=D, nhead=4), seq-first as fed at vit_3d_2d_pretrain.py:479,
+    through s3d_encoder_layer_fwd/bwd vs autograd on the oracle restatement (eval-mode dropout)."""
+    from oracle import voxel_oracle as vo
+    from simple3d_former_amd.engine import ParamArena, _BlockScratch
+    g = torch.Generator().manual_seed(11)
+    M = G * Nb
+    ge = 'group_embed.'
+    shapes = {ge + 'self_attn.in_proj_weight': (3 * D, D), ge + 'self_attn.in_proj_bias': (3 * D,),
+              ge + 'self_attn.out_proj.weight': (D, D), ge + 'self_attn.out_proj.bias': (D,),
+              ge + 'linear1.weight': (D, D), ge + 'linear1.bias': (D,), ge + 'linear2.weight': (D, D), ge + 'linear2.bias': (D,),
+              ge + 'norm1.weight': (D,), ge + 'norm1.bias': (D,), ge + 'norm2.weight': (D,), ge + 'norm2.bias': (D,)}
+    sd = {k: (1 + 0.1 * torch.randn(shp, generator=g)) if ('norm' in k and k.endswith('weight')) else torch.randn(shp, generator=g) * 0.06
+          for k, shp in shapes.items()}
+    x = torch.randn(G, Nb, D, generator=g)
+    dy = torch.randn(G, Nb, D, generator=g) * 0.1
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    y_ref = vo.group_encoder_layer(xr, leaf)
+    y_ref.backward(dy)
+
+    arena = ParamArena(shapes, torch.device(DEV)); arena.load(sd); arena.refresh_planes()
+    f32 = dict(dtype=torch.float32, device=DEV); b16 = dict(dtype=torch.bfloat16, device=DEV)
+    t = {n: torch.empty(M, D, **f32) for n in ('x_in', 's1', 'x1', 's2', 'x_out')}
+    stats = torch.empty(4, M, **f32); lse = torch.empty(Nb * 4 * G, **f32)
+    pl = {n: torch.empty(2, M, w, **b16) for n, w in (('xin', D), ('qkv', 3 * D), ('att', D), ('x1p', D), ('f', D))}
+    fpre = torch.empty(M, D, **b16)
+    acts = L.fill(L.S3dEncActs(), x_in=t['x_in'], s1=t['s1'], x1=t['x1'], s2=t['s2'], x_out=t['x_out'], mean1=stats[0], rstd1=stats[1],
+                  mean2=stats[2], rstd2=stats[3], lse=lse, xin_hi=pl['xin'][0], xin_lo=pl['xin'][1], qkv_hi=pl['qkv'][0],
+                  qkv_lo=pl['qkv'][1], att_hi=pl['att'][0], att_lo=pl['att'][1], x1_hi=pl['x1p'][0], x1_lo=pl['x1p'][1], fpre=fpre,
+                  f_hi=pl['f'][0], f_lo=pl['f'][1])
+    shape = L.S3dEncShape(G=G, Nb=Nb, D=D, H=4, Dff=D, eps=1e-5, split=1)
+    P = lambda k: arena.param(ge + k)
+    ep = L.fill(L.S3dEncParams(), in_b=P('self_attn.in_proj_bias'), out_b=P('self_attn.out_proj.bias'), l1_b=P('linear1.bias'),
+                l2_b=P('linear2.bias'), n1_w=P('norm1.weight'), n1_b=P('norm1.bias'), n2_w=P('norm2.weight'), n2_b=P('norm2.bias'),
+                in_w_hi=arena.hi_of(ge + 'self_attn.in_proj_weight'), in_w_lo=arena.lo_of(ge + 'self_attn.in_proj_weight'),
+                out_w_hi=arena.hi_of(ge + 'self_attn.out_proj.weight'), out_w_lo=arena.lo_of(ge + 'self_attn.out_proj.weight'),
+                l1_w_hi=arena.hi_of(ge + 'linear1.weight'), l1_w_lo=arena.lo_of(ge + 'linear1.weight'),
+                l2_w_hi=arena.hi_of(ge + 'linear2.weight'), l2_w_lo=arena.lo_of(ge + 'linear2.weight'))
+    Gd = lambda k: arena.grad(ge + k)
+    eg = L.fill(L.S3dEncGrads(), in_w=Gd('self_attn.in_proj_weight'), in_b=Gd('self_attn.in_proj_bias'), out_w=Gd('self_attn.out_proj.weight'),
+                out_b=Gd('self_attn.out_proj.bias'), l1_w=Gd('linear1.weight'), l1_b=Gd('linear1.bias'), l2_w=Gd('linear2.weight'),
+                l2_b=Gd('linear2.bias'), n1_w=Gd('norm1.weight'), n1_b=Gd('norm1.bias'), n2_w=Gd('norm2.weight'), n2_b=Gd('norm2.bias'))
+    t['x_in'].copy_(x.reshape(M, D))
+    L.check(L.lib().s3d_encoder_layer_fwd(ctypes.byref(shape), ctypes.byref(ep), ctypes.byref(acts), L.current_stream()), 'enc fwd')
+    e = rel_err(t['x_out'], y_ref.detach().reshape(M, D))
+    assert e < 1e-4, f'encoder fwd rel err {e:.3e}'
+    sc = _BlockScratch(M, D, 4, 4 * D, Nb * 4 * G, DEV)
+    sc.dx_a.copy_(dy.reshape(M, D))
+    L.check(L.lib().s3d_encoder_layer_bwd(ctypes.byref(shape), ctypes.byref(ep), ctypes.byref(eg), ctypes.byref(acts),
+                                          ctypes.byref(sc.c), L.current_stream()), 'enc bwd')
+    e = rms_err(sc.dx_b, xr.grad.reshape(M, D))
+    assert e < 2e-2, f'encoder dx rms err {e:.3e}'
+    assert rms_err(sc.dx_b_bf.float(), xr.grad.reshape(M, D)) < 2e-2
+    for k in shapes:
+        e = rms_err(arena.grad(k), leaf[k].grad)
+        assert e < 3e-2, f'{k}: grad rms err {e:.3e}'
+
+
+def test_assemble_tokens_fwd_bwd():
+    B, n, D = 3, 9, 192
+    g = torch.Generator().manual_seed(12)
+    src = torch.randn(B * n, D, generator=g).to(DEV); cls = torch.randn(D, generator=g).to(DEV)
+    pos = torch.randn(n + 1, D, generator=g).to(DEV)
+    out = torch.empty(B * (n + 1), D, device=DEV)
+    L.check(L.lib().s3d_assemble_tokens(L.ptr(src), L.ptr(cls), L.ptr(pos), L.ptr(out), ctypes.c_long(B), n, D, L.current_stream()), 'asm')
+    ref = torch.cat((cls.expand(B, 1, D), src.view(B, n, D)), dim=1) + pos
+    assert torch.equal(out.view(B, n + 1, D), ref)
+    back = torch.empty_like(src)
+    L.check(L.lib().s3d_assemble_tokens_bwd(L.ptr(out), L.ptr(back), ctypes.c_long(B), n, D, L.current_stream()), 'asm bwd')
+    assert torch.equal(back.view(B, n, D), ref[:, 1:])

@@ -21,7 +21,8 @@ from tests._util import MODEL_KEYS, check_grads_against_golden, fwd_kwargs, load
 DEV = 'cuda'
 LOGIT_TOL = 1e-3
 DEFAULT_CASES = ['cfg1_small_v30_b8', 'cfg2_small_v32_b4', 'tiny_v12_default_b3', 'tiny_v12_noavg_default_b2',
-                 'tiny_v12_naive_b2', 'small_v30_amsoftmax_b4']
+                 'tiny_v12_naive_b2', 'small_v30_amsoftmax_b4',
+                 'tiny_v12_group_b3', 'cfg3_base_v128_group_b1']     # group_embed (eval-mode dropout), cfg-3 real geometry
 
 
 def make_engine(cfg, sd, **kw):
