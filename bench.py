@@ -24,7 +24,21 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CFG = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5, n_classes=40)
+CONFIGS = {
+    # BASELINE.json configs[1] -- the configuration the headline metric is quoted on (default)
+    'cfg2': dict(cfg=dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5,
+                          n_classes=40), pos_embedding='default', batch=64, train_flops=3.39e9,
+                 metric='voxels/sec (train, whole node) deit_small VoxelEmbed 32^3 b64',
+                 workload='BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed(voxel 32, cell 6, patch 5), 40 classes, '
+                          'full train step incl. Adam'),
+    # BASELINE.json configs[2] (secondary; eval-mode dropout in the group encoder layer)
+    'cfg3': dict(cfg=dict(backbone='deit_base_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=128, cell=9,
+                          patch=14, n_classes=55), pos_embedding='group_embed', batch=64, train_flops=2.0e12,
+                 metric='voxels/sec (train, whole node) deit_base(H=3) VoxelEmbed_no_average 128^3 group_embed b64',
+                 workload='BASELINE.json configs[2]: deit_base_patch16_224 (3 heads) + VoxelEmbed_no_average(voxel 128, cell 9, '
+                          'patch 14) + group_embed, 55 classes, full train step incl. Adam'),
+}
+CFG = CONFIGS['cfg2']['cfg']
 BATCH_PER_GPU = 64
 TRAIN_FLOPS_PER_SAMPLE = 3.39e9          # BASELINE.md section 2 (fwd 1.137 G, train = 3x fwd - tokenizer dgrad)
 MFMA_BF16_PEAK_TFLOPS = 2500.0           # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16
@@ -78,7 +92,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--buckets', type=int, default=3)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
     args = ap.parse_args()
+    global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE
+    conf = CONFIGS[args.config]
+    CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
+    if args.config != 'cfg2':
+        args.no_cpu_baseline = True
 
     import torch.distributed as dist
     import simple3d_former_amd as s3d
@@ -97,8 +118,8 @@ def main():
         dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
 
     # model + optimizer state (reference init, seed 9), per-rank synthetic shard of the global batch
-    eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, **CFG)
-    sd = vo.init_state_dict(seed=9, **CFG)
+    eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, pos_embedding=conf['pos_embedding'], **CFG)
+    sd = vo.init_state_dict(seed=9, pos_embedding=conf['pos_embedding'], **CFG)
     eng.load_state_dict(sd)
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
     x, y = x_cpu.to(dev), y_cpu.to(dev)
@@ -138,13 +159,12 @@ def main():
     value = world * BATCH_PER_GPU * args.steps / elapsed
 
     out = {
-        'metric': 'voxels/sec (train, whole node) deit_small VoxelEmbed 32^3 b64', 'value': round(value, 1),
+        'metric': conf['metric'], 'value': round(value, 1),
         'unit': 'voxels/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16' if args.plain_bf16 else 'bf16 (split-bf16 x3 MFMA forward, bf16 backward, fp32 accumulate/residual/Adam)',
         'data': 'synthetic (seeded 10%-occupancy 32^3 grids, random-init weights of the reference architecture)',
-        'config': {'workload': 'BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed(voxel 32, cell 6, patch 5), '
-                               '40 classes, full train step incl. Adam', 'batch_per_gpu': BATCH_PER_GPU,
+        'config': {'workload': conf['workload'], 'batch_per_gpu': BATCH_PER_GPU,
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
                    'grad_buckets': len(trainer.slices)},

@@ -1,0 +1,100 @@
+"""Golden-vector generator for the point-cloud path (run ONLY in the build container, where /root/reference exists):
+
+    python tests/golden/make_golden_points.py
+
+Runs the reference's unmodified models/3DViT/model.py (PointTransformerCls / PointTransformerSeg) and
+data/pointnet_util.py on CPU in TRAIN mode (BatchNorm batch statistics), on top of oracle/timm_shim, with the `data`
+package stubbed (data/__init__.py imports modules that do not exist) and torch.randint patched to hand out recorded FPS
+start indices.  Stores logits, loss, gradient summaries, updated BatchNorm running statistics, eval-mode logits."""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'oracle', 'timm_shim'))
+sys.path.insert(1, '/root/reference')
+
+from oracle import point_oracle as po  # noqa: E402
+from tests.golden.make_golden import sample_idx  # noqa: E402
+
+CASES = {
+    'pts_cls_tiny_n64_b3': dict(task='cls', backbone='deit_tiny_patch16_224', n_points=64, d_points=6, n_classes=40, batch=3),
+    'pts_seg_tiny_n64_b2': dict(task='seg', backbone='deit_tiny_patch16_224', n_points=64, d_points=22, n_classes=50, batch=2),
+    'pts_cls_tiny_n1024_b2': dict(task='cls', backbone='deit_tiny_patch16_224', n_points=1024, d_points=6, n_classes=40, batch=2),
+    'pts_seg_tiny_n2048_b1': dict(task='seg', backbone='deit_tiny_patch16_224', n_points=2048, d_points=22, n_classes=50, batch=1),
+}
+
+
+def build_reference(cfg):
+    stub = types.ModuleType('data')
+    stub.__path__ = ['/root/reference/data']
+    sys.modules['data'] = stub
+    mod = importlib.import_module('models.3DViT.model')
+    c = types.SimpleNamespace(num_point=cfg['n_points'], num_class=cfg['n_classes'], input_dim=cfg['d_points'],
+                              model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head='default',
+                                                          transformer_backbone=cfg['backbone'], pretrained=False, name='3DViT'))
+    return getattr(mod, 'PointTransformerCls' if cfg['task'] == 'cls' else 'PointTransformerSeg')(c)
+
+
+def run_case(name, cfg):
+    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9)
+    model = build_reference(cfg)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected                      # every generated key exists in the reference (name + shape contract)
+    assert all(k.startswith(('pos_embed', 'patch_embed.')) or 'last_pos_embed' in k for k in missing), missing
+    x, y, starts = po.synthetic_points(cfg['batch'], cfg['n_points'], cfg['d_points'], cfg['n_classes'], cfg['task'], seed=9)
+    queue = []
+    orig = torch.randint
+
+    def fake_randint(*a, **k):
+        return queue.pop(0).clone()
+
+    out = dict(cfg=np.array(json.dumps(cfg)), start0=starts[0].numpy(), start1=starts[1].numpy())
+    torch.randint = fake_randint
+    try:
+        model.train()
+        queue[:] = list(starts)
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits.reshape(-1, cfg['n_classes']), y.reshape(-1))
+        loss.backward()
+        model.eval()
+        queue[:] = list(starts)
+        with torch.no_grad():
+            out['logits_eval'] = model(x).numpy()
+    finally:
+        torch.randint = orig
+    out.update(logits=logits.detach().numpy(), loss=np.array(loss.item()), target=y.numpy(),
+               argmax=logits.detach().argmax(-1).numpy())
+    top2 = logits.detach().topk(2, dim=-1).values
+    out['top2_gap'] = (top2[..., 0] - top2[..., 1]).numpy()
+    for k, v in model.state_dict().items():
+        if 'running_' in k and 'last_pos' not in k:
+            out['stat/' + k] = v.numpy()
+    names = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().flatten()
+        names.append(k)
+        idx = sample_idx(g.numel())
+        out['gnorm/' + k] = np.array(float(g.double().norm())); out['gsum/' + k] = np.array(float(g.double().sum()))
+        out['gidx/' + k] = idx; out['gval/' + k] = g[idx].numpy()
+        if g.numel() <= 4096:
+            out['gfull/' + k] = p.grad.detach().numpy()
+    out['grad_names'] = np.array(json.dumps(names))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: loss {loss.item():.6f} logits {tuple(logits.shape)} gap_min {out["top2_gap"].min():.4f} {len(names)} grads')
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    for n, c in CASES.items():
+        if len(sys.argv) == 1 or n in sys.argv[1:]:
+            run_case(n, c)

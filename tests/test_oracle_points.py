@@ -1,0 +1,63 @@
+"""CPU: the point-cloud oracle (oracle/point_oracle.py) replayed against fixtures captured from the reference's own
+models/3DViT/model.py + data/pointnet_util.py (tests/golden/make_golden_points.py), train-mode BatchNorm."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import point_oracle as po
+from tests._util import check_grads_against_golden, GOLDEN
+
+POINT_CASES = ['pts_cls_tiny_n64_b3', 'pts_seg_tiny_n64_b2', 'pts_cls_tiny_n1024_b2', 'pts_seg_tiny_n2048_b1']
+
+
+def load_point_case(name):
+    z = np.load(f'{GOLDEN}/{name}.npz')
+    cfg = json.loads(str(z['cfg']))
+    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9)
+    x, y, starts = po.synthetic_points(cfg['batch'], cfg['n_points'], cfg['d_points'], cfg['n_classes'], cfg['task'], seed=9)
+    np.testing.assert_array_equal(starts[0].numpy(), z['start0'])
+    np.testing.assert_array_equal(y.numpy(), z['target'])
+    return z, cfg, sd, x, y, starts
+
+
+@pytest.mark.parametrize('name', POINT_CASES)
+def test_point_model_matches_reference(name):
+    z, cfg, sd, x, y, starts = load_point_case(name)
+    kw = dict(task=cfg['task'], backbone=cfg['backbone'], starts=starts)
+    logits, loss, grads, stats = po.loss_and_grads(sd, x, y, training=True, **kw)
+    np.testing.assert_allclose(logits.numpy(), z['logits'], rtol=0, atol=2e-5)
+    assert abs(float(loss) - float(z['loss'])) <= 1e-5
+    sure = z['top2_gap'] > 1e-3
+    np.testing.assert_array_equal(logits.argmax(-1).numpy()[sure], z['argmax'][sure])
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    # atol 2e-6: the gradients of a conv/linear bias that feeds a train-mode BatchNorm are exactly zero in theory and
+    # pure rounding noise (~2e-7) in both implementations
+    # rtol 1e-3: fp32 reduction-order noise over up to 32k grouped rows (conv2d in the reference vs a row GEMM here)
+    check_grads_against_golden(z, grads, rtol=1e-3, atol=2e-6)
+    for k, v in stats.items():                                   # BatchNorm running statistics after one train-mode forward
+        np.testing.assert_allclose(v.numpy(), z['stat/' + k], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():        # the golden eval pass ran after the train-mode pass had updated the running statistics
+        ev = po.forward({**sd, **stats}, x, training=False, **kw)
+    np.testing.assert_allclose(ev.numpy(), z['logits_eval'], rtol=0, atol=2e-5)
+
+
+def test_metrics_and_sgd():
+    logits = torch.tensor([[2.0, 1.0, 0.0], [0.0, 3.0, 1.0], [0.0, 0.0, 5.0], [4.0, 0.0, 1.0]])
+    tgt = torch.tensor([0, 1, 1, 0])
+    inst, cls = po.cls_accuracy(logits, tgt, 3)
+    assert abs(inst - 0.75) < 1e-9 and abs(cls - 0.75) < 1e-9
+    # part IoU with the argmax restricted to the shape's own parts
+    seg_classes = {'a': [0, 1], 'b': [2, 3]}
+    lg = torch.zeros(1, 4, 4); lg[0, :, 3] = 9.0; lg[0, :2, 0] = 1.0; lg[0, 2:, 1] = 1.0     # part 3 is NOT a part of category a
+    tg = torch.tensor([[0, 0, 1, 0]])
+    (cat, iou), = po.part_iou(lg, tg, seg_classes)
+    assert cat == 'a' and abs(iou - (2 / 3 + 1 / 2) / 2) < 1e-9
+    p = torch.randn(50); q = torch.nn.Parameter(p.clone()); opt = torch.optim.SGD([q], lr=0.01, momentum=0.9)
+    buf = torch.zeros(50); pp = p.clone()
+    for step in range(3):
+        g = torch.randn(50)
+        q.grad = g.clone(); opt.step()
+        po.sgd_momentum_step(pp, g, buf, first=(step == 0))
+        assert float((pp - q.detach()).abs().max()) < 1e-7
