@@ -144,6 +144,7 @@ typedef struct S3dCeArgs {
     float* loss;
     float* dlogits;
     float grad_scale;
+    int ld;             /* row pitch of logits / dlogits (0 = C); pad columns of dlogits are written as 0 */
 } S3dCeArgs;
 int s3d_cross_entropy(const S3dCeArgs* args, s3d_stream_t stream);
 
@@ -238,6 +239,52 @@ int s3d_encoder_layer_bwd(const S3dEncShape* shape, const S3dEncParams* params, 
 int s3d_assemble_tokens(const float* src, const float* cls, const float* pos, float* out, long B, int n, int D,
                         s3d_stream_t stream);
 int s3d_assemble_tokens_bwd(const float* dout, float* dsrc, long B, int n, int D, s3d_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ point clouds
+ * PointTransformerCls / PointTransformerSeg (models/3DViT/model.py:144-337, 341-535) geometry and normalisation operators.
+ *   s3d_fps                farthest_point_sample (data/pointnet_util.py:53-73); `start` = the torch.randint draw of :65
+ *   s3d_knn                square_distance + argsort()[:, :, :k] (:119-120) for k = 16, and the 3-NN + inverse-distance
+ *                          weights of PointNetFeaturePropagation (:401-408) for k = 3 (out_w non-NULL)
+ *   s3d_group_gather       index_points + [xyz - new_xyz | feats] concat (:126-134) -> split-bf16 GEMM operand rows (b,s,j)
+ *   s3d_group_scatter      its backward (scatter-add into d(feats))
+ *   s3d_batchnorm_fwd/bwd  train-mode nn.BatchNorm2d/1d + ReLU (:238-241, models/3DViT/model.py:52-64) over row matrices
+ *                          [rows][C]; with K > 0 also the max over the K neighbours (:242) fused in
+ *   s3d_interp3(_bwd)      3-NN interpolation + skip add of TransitionUp (models/3DViT/model.py:67-72)
+ *   s3d_mean_points        x.mean(1) (models/3DViT/model.py:325);  s3d_bcast_rows its backward
+ *   s3d_sgd_step           torch.optim.SGD(lr, momentum=0.9) (train_cls.py:91) over the flat arena */
+int s3d_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx, float* new_xyz,
+            s3d_stream_t stream);
+int s3d_knn(const float* query, const float* ref, int B, int S, int N, int K, int* out_idx, float* out_w, s3d_stream_t stream);
+int s3d_group_gather(const float* xyz, const float* new_xyz, const float* feats, const int* idx, int B, int N, int S, int K,
+                     int C, uint16_t* a_hi, uint16_t* a_lo, int lda, s3d_stream_t stream);
+int s3d_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats,
+                      s3d_stream_t stream);
+typedef struct S3dBnArgs {
+    const float* x; int ldx;              /* pre-normalisation activations [rows][ldx] */
+    long rows; int C; int K;              /* K > 0: rows = groups*K and the max over K is fused (y = [groups][C], arg) */
+    float eps; float momentum;
+    const float* gamma; const float* beta;
+    float* mean; float* rstd;             /* [C] batch statistics (written by fwd, read by bwd) */
+    float* run_mean; float* run_var;      /* running statistics, updated in place by fwd (may be NULL) */
+    double* sums;                         /* scratch [2*C] */
+    float* y; uint16_t* y_hi; uint16_t* y_lo; int ldo;     /* fwd outputs: fp32 and/or split planes */
+    unsigned char* arg;                   /* K > 0: argmax neighbour per (group, channel) */
+    const float* dy; int lddy;            /* bwd: gradient wrt the (ReLU / max) output */
+    uint16_t* dx; int lddx;               /* bwd: gradient wrt x as bf16 [rows][lddx] */
+    float* dgamma; float* dbeta;
+} S3dBnArgs;
+int s3d_batchnorm_fwd(const S3dBnArgs* args, s3d_stream_t stream);
+int s3d_batchnorm_bwd(const S3dBnArgs* args, s3d_stream_t stream);
+int s3d_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,
+                s3d_stream_t stream);
+int s3d_interp3_bwd(const float* dout, const int* idx, const float* w, int B, int S, int N, int C, float* df1,
+                    s3d_stream_t stream);
+int s3d_mean_points(const float* x, int B, int N, int C, float* out, s3d_stream_t stream);
+int s3d_bcast_rows(const float* x, int N, int C, long rows, float scale, float* y, s3d_stream_t stream);
+int s3d_pack_rows(const float* x, int C, int ldx, long rows, uint16_t* hi, uint16_t* lo, int ldo, s3d_stream_t stream);
+int s3d_add_inplace(float* a, const float* b, long n, s3d_stream_t stream);
+int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, float lr, float momentum,
+                 float grad_scale, int* step_counter, s3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -224,7 +224,7 @@ size_t s3d_sizeof(const char* n) {
 #define SZ(T) if (strcmp(n, #T) == 0) return sizeof(T)
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
-    SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs);
+    SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
 #undef SZ
     return 0;
 }
@@ -315,6 +315,46 @@ int s3d_assemble_tokens(const float* src, const float* cls, const float* pos, fl
 }
 int s3d_assemble_tokens_bwd(const float* dout, float* dsrc, long B, int n, int D, s3d_stream_t s) {
     return s3d_launch_assemble_bwd(dout, dsrc, B, n, D, st(s));
+}
+
+int s3d_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx, float* new_xyz, s3d_stream_t s) {
+    return s3d_launch_fps(xyz, xyz_ld, start, B, N, npoint, out_idx, new_xyz, st(s));
+}
+int s3d_knn(const float* q, const float* r, int B, int S, int N, int K, int* out_idx, float* out_w, s3d_stream_t s) {
+    return s3d_launch_knn(q, r, B, S, N, K, out_idx, out_w, st(s));
+}
+int s3d_group_gather(const float* xyz, const float* new_xyz, const float* feats, const int* idx, int B, int N, int S, int K, int C,
+                     uint16_t* a_hi, uint16_t* a_lo, int lda, s3d_stream_t s) {
+    return s3d_launch_group_gather(xyz, new_xyz, feats, idx, B, N, S, K, C, a_hi, a_lo, lda, st(s));
+}
+int s3d_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats, s3d_stream_t s) {
+    return s3d_launch_group_scatter(dA, ldd, idx, B, N, S, K, C, dfeats, st(s));
+}
+int s3d_batchnorm_fwd(const S3dBnArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_batchnorm_fwd: null args");
+    return s3d_launch_bn_fwd(*a, st(s));
+}
+int s3d_batchnorm_bwd(const S3dBnArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_batchnorm_bwd: null args");
+    return s3d_launch_bn_bwd(*a, st(s));
+}
+int s3d_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out, s3d_stream_t s) {
+    return s3d_launch_interp3(f1, S, f2, idx, w, B, N, C, out, st(s));
+}
+int s3d_interp3_bwd(const float* dout, const int* idx, const float* w, int B, int S, int N, int C, float* df1, s3d_stream_t s) {
+    return s3d_launch_interp3_bwd(dout, idx, w, B, S, N, C, df1, st(s));
+}
+int s3d_mean_points(const float* x, int B, int N, int C, float* out, s3d_stream_t s) { return s3d_launch_mean_points(x, B, N, C, out, st(s)); }
+int s3d_bcast_rows(const float* x, int N, int C, long rows, float scale, float* y, s3d_stream_t s) {
+    return s3d_launch_bcast_rows(x, N, C, rows, scale, y, st(s));
+}
+int s3d_pack_rows(const float* x, int C, int ldx, long rows, uint16_t* hi, uint16_t* lo, int ldo, s3d_stream_t s) {
+    return s3d_launch_pack_rows(x, C, ldx, rows, hi, lo, ldo, st(s));
+}
+int s3d_add_inplace(float* a, const float* b, long n, s3d_stream_t s) { return s3d_launch_add_inplace(a, b, n, st(s)); }
+int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, float lr, float momentum, float grad_scale,
+                 int* step_counter, s3d_stream_t s) {
+    return s3d_launch_sgd(p, g, buf, hi, lo, n, lr, momentum, grad_scale, step_counter, st(s));
 }
 
 }  // extern "C"

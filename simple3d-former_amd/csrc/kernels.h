@@ -37,3 +37,22 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s);
 typedef S3dAdamState AdamState;
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
                     int zero_grad, hipStream_t s);
+
+// ---- point-cloud operators (points.hip) ----
+int s3d_launch_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx,
+                   float* new_xyz, hipStream_t s);
+int s3d_launch_knn(const float* query, const float* ref, int B, int S, int N, int K, int* out_idx, float* out_w, hipStream_t s);
+int s3d_launch_group_gather(const float* xyz, const float* new_xyz, const float* feats, const int* idx, int B, int N, int S,
+                            int K, int C, bf16_t* a_hi, bf16_t* a_lo, int lda, hipStream_t s);
+int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats, hipStream_t s);
+int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s);
+int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s);
+int s3d_launch_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,
+                       hipStream_t s);
+int s3d_launch_interp3_bwd(const float* dout, const int* idx, const float* w, int B, int S, int N, int C, float* df1, hipStream_t s);
+int s3d_launch_mean_points(const float* x, int B, int N, int C, float* out, hipStream_t s);
+int s3d_launch_bcast_rows(const float* x, int N, int C, long rows, float scale, float* y, hipStream_t s);
+int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, bf16_t* lo, int ldo, hipStream_t s);
+int s3d_launch_add_inplace(float* a, const float* b, long n, hipStream_t s);
+int s3d_launch_sgd(float* p, float* g, float* buf, bf16_t* hi, bf16_t* lo, long n, float lr, float momentum, float grad_scale,
+                   int* step_counter, hipStream_t s);

@@ -241,8 +241,9 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
     const long nw = (long)gridDim.x * 4;
     const float den = p.loss[1];
     float acc = 0.f;
+    const int ld = p.ld > 0 ? p.ld : p.C;
     for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < p.rows; row += nw) {
-        const float* l = p.logits + row * p.C;
+        const float* l = p.logits + row * ld;
         float m = -INFINITY;
         for (int c = lane; c < p.C; c += 64) m = fmaxf(m, l[c]);
         m = wave_max(m);
@@ -254,8 +255,8 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
         const float lse = m + logf(s);
         acc += w * (lse - l[t]);
         if (p.dlogits)
-            for (int c = lane; c < p.C; c += 64)
-                p.dlogits[row * p.C + c] = p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den;
+            for (int c = lane; c < ld; c += 64)
+                p.dlogits[row * ld + c] = (c < p.C) ? p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den : 0.f;
     }
     if (lane == 0 && acc != 0.f) atomic_add_f32(p.loss, acc / den);
 }

@@ -1,0 +1,485 @@
+// Point-cloud kernels of the PointTransformerCls/Seg path for gfx950: farthest-point sampling, k-nearest-neighbour
+// selection, neighbourhood gather / scatter-add, train-mode BatchNorm (+ReLU, + max over the k neighbours) forward and
+// backward, 3-NN inverse-distance interpolation, mean pooling.  These are HBM/latency-bound integer + fp32 kernels (no
+// MFMA); the 1x1 convolutions / Linear layers between them run on the MFMA GEMM (gemm.hip).
+//
+// Distances are computed as ((dx*dx + dy*dy) + dz*dz) with explicitly NON-fused fp32 operations so that neighbour order
+// is bit-identical to the reference's torch.sum((src - dst) ** 2, -1) (data/pointnet_util.py:22-36) -- an FMA contraction
+// would flip near-ties at the 16th/17th neighbour.
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ------------------------------------------------------------------------------------------- FPS
+// One workgroup per cloud; the cloud lives in LDS, running min-distances in registers.  npoint sequential iterations of
+// {update min distance to the newest centroid, argmax}; ties resolve to the smallest index (torch.max's first maximum).
+constexpr int FPS_PPT = 8;   // points per thread -> N <= 2048
+
+__global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, long xyz_ld, const long long* __restrict__ start,
+                                                  int N, int npoint, int* __restrict__ out_idx, float* __restrict__ new_xyz) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sx = reinterpret_cast<float*>(smem);          // [N][3]
+    float* rv = sx + 3 * N;                              // [4] wave maxima
+    int* ri = reinterpret_cast<int*>(rv + 4);            // [4] wave argmax
+    int* sfar = ri + 4;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = xyz + (long)b * N * xyz_ld;
+    for (int i = tid; i < N; i += 256) {
+        sx[3 * i] = src[(long)i * xyz_ld]; sx[3 * i + 1] = src[(long)i * xyz_ld + 1]; sx[3 * i + 2] = src[(long)i * xyz_ld + 2];
+    }
+    float dist[FPS_PPT];
+#pragma unroll
+    for (int j = 0; j < FPS_PPT; ++j) dist[j] = 1e10f;
+    if (tid == 0) *sfar = (int)start[b];
+    __syncthreads();
+    for (int it = 0; it < npoint; ++it) {
+        const int far = *sfar;
+        const float cx = sx[3 * far], cy = sx[3 * far + 1], cz = sx[3 * far + 2];
+        if (tid == 0) {
+            out_idx[(long)b * npoint + it] = far;
+            float* o = new_xyz + ((long)b * npoint + it) * 3;
+            o[0] = cx; o[1] = cy; o[2] = cz;
+        }
+        float best = -1.f;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int j = 0; j < FPS_PPT; ++j) {
+            const int pidx = tid + j * 256;
+            if (pidx < N) {
+                const float d = sqdist(sx[3 * pidx], sx[3 * pidx + 1], sx[3 * pidx + 2], cx, cy, cz);
+                dist[j] = fminf(dist[j], d);
+                if (dist[j] > best) { best = dist[j]; bi = pidx; }       // strict >: first (smallest) index wins
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        __syncthreads();                                  // everyone has read *sfar
+        if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = rv[0]; int ix = ri[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) if (rv[w] > v || (rv[w] == v && ri[w] < ix)) { v = rv[w]; ix = ri[w]; }
+            *sfar = ix;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------- kNN
+// One wave per query point: distances to all N reference points in registers (<= 32 per lane), then K rounds of
+// {lane-local min over not-yet-taken, wave argmin}.  Ascending distance; ties -> smaller index.  K == 3 also emits the
+// normalised inverse-distance weights of PointNetFeaturePropagation (data/pointnet_util.py:401-408).
+constexpr int KNN_PPL = 32;  // N <= 2048
+
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ query, const float* __restrict__ ref, int S, int N,
+                                                  long total, int* __restrict__ out_idx, float* __restrict__ out_w) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= total) return;
+    const long b = item / S;
+    const float qx = query[item * 3], qy = query[item * 3 + 1], qz = query[item * 3 + 2];
+    const float* r = ref + b * N * 3;
+    float d[KNN_PPL];
+#pragma unroll
+    for (int j = 0; j < KNN_PPL; ++j) {
+        const int pidx = lane + j * 64;
+        d[j] = INFINITY;
+        if (pidx < N) d[j] = sqdist(qx, qy, qz, r[3 * pidx], r[3 * pidx + 1], r[3 * pidx + 2]);
+    }
+    unsigned taken = 0u;
+    float wsum = 0.f, wv[K];
+    int wi[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float best = INFINITY;
+        int bj = -1;
+#pragma unroll
+        for (int j = 0; j < KNN_PPL; ++j)
+            if (!((taken >> j) & 1u) && d[j] < best) { best = d[j]; bj = j; }
+        int bi = (bj < 0) ? 0x7fffffff : lane + bj * 64;
+        float v = best;
+        int ix = bi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (ix == bi && bj >= 0) taken |= (1u << bj);
+        wi[k] = ix;
+        wv[k] = 1.0f / (v + 1e-8f);
+        wsum += wv[k];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            out_idx[item * K + k] = wi[k];
+            if (out_w) out_w[item * K + k] = wv[k] / wsum;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- neighbourhood gather
+// rows r = (b, s, j): A[r] = [xyz[b, idx] - new_xyz[b, s] (3) | feats[b, idx] (C) | 0 pad] as split-bf16 planes
+// (sample_and_group(knn=True), data/pointnet_util.py:126-134)
+__global__ void group_gather_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                    const float* __restrict__ feats, const int* __restrict__ idx, int N, int S, int K, int C,
+                                    long rows, bf16_t* __restrict__ a_hi, bf16_t* __restrict__ a_lo, int lda) {
+    const long total = rows * lda;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / lda;
+        const int c = (int)(i % lda);
+        const long bs = r / K;
+        const long b = bs / S;
+        const int p = idx[r];
+        float v = 0.f;
+        if (c < 3) v = xyz[(b * N + p) * 3 + c] - new_xyz[bs * 3 + c];
+        else if (c < 3 + C) v = feats[(b * N + p) * (long)C + (c - 3)];
+        bf16_t h, l;
+        split_bf16(v, h, l);
+        a_hi[i] = h;
+        a_lo[i] = l;
+    }
+}
+// backward: dfeats[b, idx[r], c] += dA[r][3 + c]
+__global__ void group_scatter_kernel(const float* __restrict__ dA, int ldd, const int* __restrict__ idx, int N, int S, int K,
+                                     int C, long rows, float* __restrict__ dfeats) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        const long b = r / ((long)S * K);
+        atomic_add_f32(dfeats + (b * N + idx[r]) * (long)C + c, dA[r * ldd + 3 + c]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- BatchNorm (train mode)
+// statistics over rows per channel in double (fp64 atomics): sums[c] = sum x, sums[C + c] = sum x^2
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long rows, int C, int ld, double* __restrict__ sums) {
+    // thread t handles channel t % C of rows (t / C) + i * (256 / C * gridDim.x); C <= 256 and 256 % C need not hold
+    const int per = 256 / C;                       // rows handled per block iteration
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    if (sub >= per) return;
+    double s = 0.0, q = 0.0;
+    for (long r = (long)blockIdx.x * per + sub; r < rows; r += (long)gridDim.x * per) {
+        const double v = x[r * ld + c];
+        s += v; q += v * v;
+    }
+    atomicAdd(sums + c, s);
+    atomicAdd(sums + C + c, q);
+}
+// mean / rstd + running statistics (momentum m, unbiased running variance), nn.BatchNorm semantics
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, long rows, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = sums[c] / rows;
+    double var = sums[C + c] / rows - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
+    }
+}
+// y = relu((x - mean) * rstd * gamma + beta) -> fp32 and/or split planes (row pitch ldo)
+__global__ void bn_relu_kernel(const float* __restrict__ x, long rows, int C, int ld, const float* __restrict__ mean,
+                               const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               float* __restrict__ y, bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, int ldo) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        const float v = fmaxf((x[r * ld + c] - mean[c]) * rstd[c] * gamma[c] + beta[c], 0.f);
+        if (y) y[r * ldo + c] = v;
+        if (y_hi) {
+            bf16_t h, l;
+            split_bf16(v, h, l);
+            y_hi[r * ldo + c] = h;
+            if (y_lo) y_lo[r * ldo + c] = l;
+        }
+    }
+}
+// fused BN + ReLU + max over the K neighbours: out[s][c] = max_k relu(bn(x[(s,k)][c])), arg[s][c] = first argmax
+__global__ void bn_relu_max_kernel(const float* __restrict__ x, long groups, int K, int C, const float* __restrict__ mean,
+                                   const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ out, unsigned char* __restrict__ arg) {
+    const long total = groups * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long s = i / C;
+        const int c = (int)(i % C);
+        const float a = rstd[c] * gamma[c], b = beta[c] - mean[c] * a;
+        float best = -INFINITY;
+        int bk = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = fmaxf(x[(s * K + k) * C + c] * a + b, 0.f);
+            if (v > best) { best = v; bk = k; }
+        }
+        out[i] = best;
+        arg[i] = (unsigned char)bk;
+    }
+}
+// backward statistics.  mode 0: g = dy * (y > 0) per row.  mode 1 (max): g[(s,k)] = (k == arg[s]) ? dy[s] * (y > 0) : 0.
+// sums[c] = sum g, sums[C + c] = sum g * xhat
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
+                                                           const unsigned char* __restrict__ arg, int K, long rows, int C,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           double* __restrict__ sums) {
+    const int per = 256 / C;
+    const int c = threadIdx.x % C, sub = threadIdx.x / C;
+    if (sub >= per) return;
+    const float a = rstd[c] * gamma[c], b = beta[c] - mean[c] * a;
+    double s = 0.0, q = 0.0;
+    const long n = arg ? rows / K : rows;          // mode 1 iterates groups
+    for (long r = (long)blockIdx.x * per + sub; r < n; r += (long)gridDim.x * per) {
+        const long xr = arg ? r * K + arg[r * C + c] : r;
+        const float xv = x[xr * ld + c];
+        const float g = (xv * a + b > 0.f) ? dy[r * lddy + c] : 0.f;
+        s += g;
+        q += (double)g * (double)((xv - mean[c]) * rstd[c]);
+    }
+    atomicAdd(sums + c, s);
+    atomicAdd(sums + C + c, q);
+}
+// dx = gamma * rstd * (g - sum_g / R - xhat * sum_gxhat / R)  -> bf16 (operand of the following wgrad / dgrad GEMMs);
+// dgamma += sum_gxhat, dbeta += sum_g (block 0 only)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
+                                    const unsigned char* __restrict__ arg, int K, long rows, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const double* __restrict__ sums, bf16_t* __restrict__ dx, int lddx,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const long total = rows * C;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            atomic_add_f32(dgamma + c, (float)sums[C + c]);
+            atomic_add_f32(dbeta + c, (float)sums[c]);
+        }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        const float a = rstd[c] * gamma[c], b = beta[c] - mean[c] * a;
+        const float xv = x[r * ld + c];
+        float g = 0.f;
+        if (arg) {
+            const long s = r / K;
+            if ((int)(r % K) == (int)arg[s * C + c] && xv * a + b > 0.f) g = dy[s * lddy + c];
+        } else if (xv * a + b > 0.f) {
+            g = dy[r * lddy + c];
+        }
+        const float xh = (xv - mean[c]) * rstd[c];
+        const float v = a * (g - (float)(sums[c] / rows) - xh * (float)(sums[C + c] / rows));
+        dx[r * lddx + c] = f2bf(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- 3-NN interpolation
+// out[b, n] = sum_j w[b, n, j] * f1[b, idx[b, n, j]] + f2[b, n]     (TransitionUp, models/3DViT/model.py:67-72)
+__global__ void interp3_kernel(const float* __restrict__ f1, int S, const float* __restrict__ f2, const int* __restrict__ idx,
+                               const float* __restrict__ w, int N, int C, long rows, float* __restrict__ out) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        const long b = r / N;
+        float v = f2[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v += w[r * 3 + j] * f1[(b * S + idx[r * 3 + j]) * (long)C + c];
+        out[i] = v;
+    }
+}
+// backward: df1[b, idx] += w * dout (df2 = dout is the caller's alias)
+__global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ w, int S,
+                                   int N, int C, long rows, float* __restrict__ df1) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i % C);
+        const long b = r / N;
+        const float g = dout[i];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) atomic_add_f32(df1 + (b * S + idx[r * 3 + j]) * (long)C + c, w[r * 3 + j] * g);
+    }
+}
+
+// ------------------------------------------------------------------------------------------- misc row ops
+// mean over the N points of each cloud: out[b][c] = mean_n x[b, n, c]   (x.mean(1), models/3DViT/model.py:325)
+__global__ void mean_points_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ out) {
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += x[((long)b * N + n) * C + c];
+        out[(long)b * C + c] = s / N;
+    }
+}
+// y[r][c] = scale * x[r / N][c]   (backward of the mean: broadcast dfeat / N)
+__global__ void bcast_rows_kernel(const float* __restrict__ x, int N, int C, long rows, float scale, float* __restrict__ y) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        y[i] = scale * x[(i / C / N) * C + (i % C)];
+}
+// out[r][0..ld) bf16 planes <- concat / copy of fp32 rows with column padding: generic "pack rows" for GEMM operands
+__global__ void pack_rows_kernel(const float* __restrict__ x, int C, int ldx, long rows, bf16_t* __restrict__ hi,
+                                 bf16_t* __restrict__ lo, int ldo) {
+    const long total = rows * ldo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ldo;
+        const int c = (int)(i % ldo);
+        bf16_t h, l;
+        split_bf16(c < C ? x[r * ldx + c] : 0.f, h, l);
+        hi[i] = h;
+        if (lo) lo[i] = l;
+    }
+}
+// a += b (fp32)
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] += b[i];
+}
+// SGD with momentum over a flat arena (+ split-plane refresh, gradient zeroing): torch.optim.SGD(lr, momentum)
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, bf16_t* __restrict__ hi,
+                           bf16_t* __restrict__ lo, long n, float lr, float momentum, float grad_scale, const int* __restrict__ first) {
+    const bool is_first = (*first == 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * grad_scale;
+        const float bb = is_first ? gg : momentum * buf[i] + gg;
+        buf[i] = bb;
+        const float pp = p[i] - lr * bb;
+        p[i] = pp;
+        g[i] = 0.f;
+        bf16_t h, l;
+        split_bf16(pp, h, l);
+        if (hi) hi[i] = h;
+        if (lo) lo[i] = l;
+    }
+}
+__global__ void bump_kernel(int* c) { *c += 1; }
+
+inline unsigned grid_for(long n, int per = 256, long cap = 8192) {
+    long b = (n + per - 1) / per;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- launchers
+int s3d_launch_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx,
+                   float* new_xyz, hipStream_t s) {
+    S3D_REQUIRE(N <= 256 * FPS_PPT, "fps: N=%d exceeds %d points per cloud", N, 256 * FPS_PPT);
+    const int lds = 3 * N * 4 + 64;
+    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
+    S3D_CHECK_LAUNCH("fps");
+    return 0;
+}
+int s3d_launch_knn(const float* query, const float* ref, int B, int S, int N, int K, int* out_idx, float* out_w, hipStream_t s) {
+    S3D_REQUIRE(N <= 64 * KNN_PPL, "knn: N=%d exceeds %d reference points", N, 64 * KNN_PPL);
+    const long total = (long)B * S;
+    dim3 grid((unsigned)((total + 3) / 4));
+    if (K == 16) hipLaunchKernelGGL((knn_kernel<16>), grid, dim3(256), 0, s, query, ref, S, N, total, out_idx, out_w);
+    else if (K == 3) hipLaunchKernelGGL((knn_kernel<3>), grid, dim3(256), 0, s, query, ref, S, N, total, out_idx, out_w);
+    else { s3d_set_error("knn: K=%d not built (16, 3)", K); return 2; }
+    S3D_CHECK_LAUNCH("knn");
+    return 0;
+}
+int s3d_launch_group_gather(const float* xyz, const float* new_xyz, const float* feats, const int* idx, int B, int N, int S,
+                            int K, int C, bf16_t* a_hi, bf16_t* a_lo, int lda, hipStream_t s) {
+    const long rows = (long)B * S * K;
+    hipLaunchKernelGGL(group_gather_kernel, dim3(grid_for(rows * lda)), dim3(256), 0, s, xyz, new_xyz, feats, idx, N, S, K, C,
+                       rows, a_hi, a_lo, lda);
+    S3D_CHECK_LAUNCH("group_gather");
+    return 0;
+}
+int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats, hipStream_t s) {
+    const long rows = (long)B * S * K;
+    hipLaunchKernelGGL(group_scatter_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, dA, ldd, idx, N, S, K, C, rows, dfeats);
+    S3D_CHECK_LAUNCH("group_scatter");
+    return 0;
+}
+int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
+    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+    const int per = 256 / a.C;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
+                       a.run_mean, a.run_var);
+    if (a.K > 0) {
+        S3D_REQUIRE(a.rows % a.K == 0 && a.ldx == a.C, "batchnorm(max): rows must be groups*K and x compact");
+        const long groups = a.rows / a.K;
+        hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * a.C)), dim3(256), 0, s, a.x, groups, a.K, a.C, a.mean, a.rstd,
+                           a.gamma, a.beta, a.y, a.arg);
+    } else {
+        hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.mean, a.rstd,
+                           a.gamma, a.beta, a.y, a.y_hi, a.y_lo, a.ldo);
+    }
+    S3D_CHECK_LAUNCH("batchnorm_fwd");
+    return 0;
+}
+int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
+    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+    const int per = 256 / a.C;
+    const unsigned char* arg = a.K > 0 ? a.arg : nullptr;
+    const long n = a.K > 0 ? a.rows / a.K : a.rows;
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid_for(n, per, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
+                       a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
+                       a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta);
+    S3D_CHECK_LAUNCH("batchnorm_bwd");
+    return 0;
+}
+int s3d_launch_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,
+                       hipStream_t s) {
+    const long rows = (long)B * N;
+    hipLaunchKernelGGL(interp3_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, f1, S, f2, idx, w, N, C, rows, out);
+    S3D_CHECK_LAUNCH("interp3");
+    return 0;
+}
+int s3d_launch_interp3_bwd(const float* dout, const int* idx, const float* w, int B, int S, int N, int C, float* df1, hipStream_t s) {
+    const long rows = (long)B * N;
+    hipLaunchKernelGGL(interp3_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, dout, idx, w, S, N, C, rows, df1);
+    S3D_CHECK_LAUNCH("interp3_bwd");
+    return 0;
+}
+int s3d_launch_mean_points(const float* x, int B, int N, int C, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(mean_points_kernel, dim3(B), dim3(64), 0, s, x, N, C, out);
+    S3D_CHECK_LAUNCH("mean_points");
+    return 0;
+}
+int s3d_launch_bcast_rows(const float* x, int N, int C, long rows, float scale, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(bcast_rows_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, x, N, C, rows, scale, y);
+    S3D_CHECK_LAUNCH("bcast_rows");
+    return 0;
+}
+int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, bf16_t* lo, int ldo, hipStream_t s) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(rows * ldo)), dim3(256), 0, s, x, C, ldx, rows, hi, lo, ldo);
+    S3D_CHECK_LAUNCH("pack_rows");
+    return 0;
+}
+int s3d_launch_add_inplace(float* a, const float* b, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, n);
+    S3D_CHECK_LAUNCH("add_inplace");
+    return 0;
+}
+int s3d_launch_sgd(float* p, float* g, float* buf, bf16_t* hi, bf16_t* lo, long n, float lr, float momentum, float grad_scale,
+                   int* step_counter, hipStream_t s) {
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, buf, hi, lo, n, lr, momentum, grad_scale,
+                       step_counter);
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, step_counter);
+    S3D_CHECK_LAUNCH("sgd");
+    return 0;
+}

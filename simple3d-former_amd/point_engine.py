@@ -1,0 +1,492 @@
+"""PointEngine: PointTransformerCls / PointTransformerSeg (reference models/3DViT/model.py:144-337, 341-535) training step
+on one MI355X through the C ABI of libs3d_hip.so.
+
+Pipeline (deit_tiny: D = 192, C0 = D/4 = 48):
+  fc1(x) + fc_pos_embed(xyz)                       [B,N,C0]     two 2-layer MLPs              -> MFMA GEMMs
+  TransitionDown 0: FPS(N) -> kNN16 -> gather -> conv1x1+BN+ReLU x2 -> max_k      [B,N,2C0]   s3d_fps/knn/group_gather + GEMMs + batchnorm
+  TransitionDown 1: FPS(N/4) -> ...                                               [B,N/4,D]
+  cat cls -> 12 timm blocks -> LayerNorm -> drop cls                              s3d_blocks_fwd (shared with the voxel path)
+  TransitionUp 0/1: Linear+BN+ReLU on both inputs, 3-NN inverse-distance interpolation, add
+  cls: mean over points -> Linear head -> CE          seg: per-point Linear head -> CE over B*N rows
+Train-mode BatchNorm (batch statistics, running-stat update).  The FPS start indices (torch.randint in the reference,
+data/pointnet_util.py:65) are an explicit input so that runs are reproducible / comparable with the oracle."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import BACKBONES, LN_EPS, ParamArena, _BlockScratch, _BlockWorkspace, _round_up
+
+KNN = 16
+BN_EPS = 1e-5
+
+
+def point_param_shapes(backbone, n_classes, d_points):
+    cfg = BACKBONES[backbone]
+    D, depth = cfg['embed_dim'], cfg['depth']
+    C0 = D // 4
+    sh = {}
+    sh['fc1.0.weight'] = (C0, d_points); sh['fc1.0.bias'] = (C0,)
+    sh['fc1.2.weight'] = (C0, C0); sh['fc1.2.bias'] = (C0,)
+    sh['fc_pos_embed.0.weight'] = (C0, 3); sh['fc_pos_embed.0.bias'] = (C0,)
+    sh['fc_pos_embed.2.weight'] = (C0, C0); sh['fc_pos_embed.2.bias'] = (C0,)
+    for i in range(2):
+        ch = C0 * 2 ** (i + 1)
+        cin = ch // 2 + 3
+        p = f'transition_downs.{i}.sa.'
+        sh[p + 'mlp_convs.0.weight'] = (ch, cin, 1, 1); sh[p + 'mlp_convs.0.bias'] = (ch,)
+        sh[p + 'mlp_bns.0.weight'] = (ch,); sh[p + 'mlp_bns.0.bias'] = (ch,)
+        sh[p + 'mlp_convs.1.weight'] = (ch, ch, 1, 1); sh[p + 'mlp_convs.1.bias'] = (ch,)
+        sh[p + 'mlp_bns.1.weight'] = (ch,); sh[p + 'mlp_bns.1.bias'] = (ch,)
+    sh['cls_token'] = (1, 1, D)
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        sh[p + 'norm1.weight'] = (D,); sh[p + 'norm1.bias'] = (D,)
+        sh[p + 'attn.qkv.weight'] = (3 * D, D); sh[p + 'attn.qkv.bias'] = (3 * D,)
+        sh[p + 'attn.proj.weight'] = (D, D); sh[p + 'attn.proj.bias'] = (D,)
+        sh[p + 'norm2.weight'] = (D,); sh[p + 'norm2.bias'] = (D,)
+        sh[p + 'mlp.fc1.weight'] = (4 * D, D); sh[p + 'mlp.fc1.bias'] = (4 * D,)
+        sh[p + 'mlp.fc2.weight'] = (D, 4 * D); sh[p + 'mlp.fc2.bias'] = (D,)
+    sh['norm.weight'] = (D,); sh['norm.bias'] = (D,)
+    for j, i in enumerate(reversed(range(2))):
+        ch = C0 * 2 ** i
+        p = f'transition_ups.{j}.'
+        sh[p + 'fc1.0.weight'] = (ch, ch * 2); sh[p + 'fc1.0.bias'] = (ch,)
+        sh[p + 'fc1.2.weight'] = (ch,); sh[p + 'fc1.2.bias'] = (ch,)
+        sh[p + 'fc2.0.weight'] = (ch, ch); sh[p + 'fc2.0.bias'] = (ch,)
+        sh[p + 'fc2.2.weight'] = (ch,); sh[p + 'fc2.2.bias'] = (ch,)
+    sh['head.weight'] = (n_classes, C0); sh['head.bias'] = (n_classes,)
+    return sh
+
+
+def bn_buffer_names(backbone):
+    names = []
+    for i in range(2):
+        for j in range(2):
+            names.append(f'transition_downs.{i}.sa.mlp_bns.{j}')
+    for j in range(2):
+        names += [f'transition_ups.{j}.fc1.2', f'transition_ups.{j}.fc2.2']
+    return names
+
+
+class _Linear:
+    """y = x @ W^T + b with W [out][in] taken from the arena (padded bf16 planes when `in` or `out` need padding)."""
+
+    def __init__(self, eng, key, out_pad=None):
+        a = eng.arena
+        shp = a.shapes[key + '.weight']
+        self.key, self.out, self.inn = key, shp[0], int(np.prod(shp[1:]))
+        self.kpad = _round_up(self.inn, 8)
+        self.opad = out_pad or self.out
+        self.padded = (self.kpad != self.inn) or (self.opad != self.out)
+        dev = eng.device
+        if self.padded:
+            self.w = torch.zeros(2, self.opad, self.kpad, dtype=torch.bfloat16, device=dev)
+            self.gpad = torch.zeros(self.opad, self.kpad, dtype=torch.float32, device=dev)
+            self.bias = torch.zeros(self.opad, dtype=torch.float32, device=dev) if self.opad != self.out else a.param(key + '.bias')
+            self.gbias = torch.zeros(self.opad, dtype=torch.float32, device=dev) if self.opad != self.out else a.grad(key + '.bias')
+        else:
+            self.w = (a.hi_of(key + '.weight'), a.lo_of(key + '.weight'))
+            self.bias, self.gbias = a.param(key + '.bias'), a.grad(key + '.bias')
+        self.eng = eng
+
+    def refresh(self):
+        if self.padded:
+            a, lib = self.eng.arena, self.eng.lib
+            w = a.param(self.key + '.weight')
+            L.check(lib.s3d_split_bf16(L.ptr(w), L.ptr(self.w[0]), L.ptr(self.w[1]), ctypes.c_long(self.out),
+                                       ctypes.c_long(self.inn), ctypes.c_long(self.kpad), L.current_stream()), 'split')
+            if self.opad != self.out:
+                self.bias[:self.out].copy_(a.param(self.key + '.bias'))
+
+    def fwd(self, a_hi, a_lo, rows, epi, **kw):
+        """a planes [rows][kpad]; epi in F32 / RELU / RESID ...; kw: C, ldc, O_hi, O_lo, ldo, aux, ldaux, R, ldr"""
+        g = L.fill(L.S3dGemmArgs(), A_hi=a_hi, A_lo=a_lo, lda=self.kpad, B_hi=self.w[0], B_lo=self.w[1], ldb=self.kpad,
+                   M=rows, N=self.opad, K=self.kpad, bias=self.bias, alpha=1.0, **kw)
+        L.check(self.eng.lib.s3d_gemm(0, 0, 1 if self.eng.split else 0, epi, ctypes.byref(g), 1, L.current_stream()), self.key)
+
+    def bwd(self, dy_bf, x_hi, rows, dx=None, dx_epi=4, **kw):
+        """dy_bf [rows][opad] bf16, x_hi [rows][kpad]; accumulates dW/db; optional dx = dy @ W (epilogue dx_epi)."""
+        lib, s = self.eng.lib, L.current_stream()
+        a = self.eng.arena
+        gw = self.gpad if self.padded else a.grad(self.key + '.weight')
+        if self.padded:
+            self.gpad.zero_()
+            if self.opad != self.out:
+                self.gbias.zero_()
+        g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=x_hi, ldb=self.kpad, M=self.opad, N=self.kpad, K=rows,
+                   C=gw, ldc=self.kpad, alpha=1.0, bias_grad=self.gbias)
+        L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), self.key + ' wgrad')
+        if self.padded:
+            a.grad(self.key + '.weight').view(self.out, self.inn).add_(self.gpad[:self.out, :self.inn])
+            if self.opad != self.out:
+                a.grad(self.key + '.bias').add_(self.gbias[:self.out])
+        if dx is not None or kw:
+            g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kpad, K=self.opad,
+                       alpha=1.0, **({'C': dx, 'ldc': self.kpad} if dx is not None else {}), **kw)
+            L.check(lib.s3d_gemm(0, 1, 0, dx_epi, ctypes.byref(g), 1, s), self.key + ' dgrad')
+
+
+class _BatchNorm:
+    def __init__(self, eng, key, C):
+        dev = eng.device
+        self.eng, self.key, self.C = eng, key, C
+        self.mean = torch.zeros(C, device=dev); self.rstd = torch.zeros(C, device=dev)
+        self.run_mean = torch.zeros(C, device=dev); self.run_var = torch.ones(C, device=dev)
+        self.sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+
+    def _args(self, x, rows, K=0, **kw):
+        a = self.eng.arena
+        return L.fill(L.S3dBnArgs(), x=x, ldx=self.C, rows=rows, C=self.C, K=K, eps=BN_EPS, momentum=self.eng.bn_momentum,
+                      gamma=a.param(self.key + '.weight'), beta=a.param(self.key + '.bias'), mean=self.mean, rstd=self.rstd,
+                      run_mean=self.run_mean, run_var=self.run_var, sums=self.sums, **kw)
+
+    def fwd(self, x, rows, K=0, **kw):
+        L.check(self.eng.lib.s3d_batchnorm_fwd(ctypes.byref(self._args(x, rows, K, **kw)), L.current_stream()), self.key)
+
+    def bwd(self, x, rows, dy, dx, K=0, arg=None):
+        a = self.eng.arena
+        args = self._args(x, rows, K, dy=dy, lddy=self.C, dx=dx, lddx=self.C, arg=arg, dgamma=a.grad(self.key + '.weight'),
+                          dbeta=a.grad(self.key + '.bias'))
+        L.check(self.eng.lib.s3d_batchnorm_bwd(ctypes.byref(args), L.current_stream()), self.key + ' bwd')
+
+
+class PointEngine:
+    def __init__(self, *, backbone='deit_tiny_patch16_224', n_points, d_points, n_classes, task='cls', device='cuda', split=True,
+                 lr=0.01, momentum=0.9, bn_momentum=0.1):
+        if backbone not in BACKBONES:
+            raise ValueError("Unknown transformer backbone name!")
+        if task not in ('cls', 'seg'):
+            raise ValueError(f'unknown task {task!r}')
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise RuntimeError('PointEngine runs on an MI355X (cuda/HIP device) only; the CPU reference lives in oracle/')
+        cfg = BACKBONES[backbone]
+        self.D, self.depth, self.H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
+        self.C0 = self.D // 4
+        self.N, self.dp, self.ncls, self.task = n_points, d_points, n_classes, task
+        assert n_points % 4 == 0 and n_points <= 2048, 'num_point must be a multiple of 4 and <= 2048'
+        self.S = [n_points, n_points // 4]
+        self.ch = [2 * self.C0, 4 * self.C0]
+        self.cin = [self.C0 + 3, self.ch[0] + 3]
+        self.split, self.bn_momentum = bool(split), bn_momentum
+        self.lr, self.momentum = lr, momentum
+        self.shapes = point_param_shapes(backbone, n_classes, d_points)
+        self.arena = ParamArena(self.shapes, self.device)
+        self.buf = torch.zeros_like(self.arena.p)                   # SGD momentum buffer
+        self.sgd_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.world_size = 1
+        self.grad_scale = 1.0
+        a = self.arena
+        # layers
+        self.fc1 = [_Linear(self, 'fc1.0'), _Linear(self, 'fc1.2')]
+        self.fcp = [_Linear(self, 'fc_pos_embed.0'), _Linear(self, 'fc_pos_embed.2')]
+        self.td = []
+        for i in range(2):
+            p = f'transition_downs.{i}.sa.'
+            self.td.append(dict(c0=_Linear(self, p + 'mlp_convs.0'), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
+                                c1=_Linear(self, p + 'mlp_convs.1'), b1=_BatchNorm(self, p + 'mlp_bns.1', self.ch[i])))
+        self.tu = []
+        for j, i in enumerate(reversed(range(2))):
+            ch = self.C0 * 2 ** i
+            p = f'transition_ups.{j}.'
+            self.tu.append(dict(l1=_Linear(self, p + 'fc1.0'), b1=_BatchNorm(self, p + 'fc1.2', ch),
+                                l2=_Linear(self, p + 'fc2.0'), b2=_BatchNorm(self, p + 'fc2.2', ch), ch=ch))
+        self.head = _Linear(self, 'head', out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
+        self._linears = self.fc1 + self.fcp + [t[k] for t in self.td for k in ('c0', 'c1')] + \
+            [t[k] for t in self.tu for k in ('l1', 'l2')] + ([self.head] if self.head else [])
+        self.bns = {t[k].key: t[k] for t in self.td for k in ('b0', 'b1')}
+        self.bns.update({t[k].key: t[k] for t in self.tu for k in ('b1', 'b2')})
+        # transformer block tables
+        self.bparams = (L.S3dBlockParams * self.depth)()
+        self.bgrads = (L.S3dBlockGrads * self.depth)()
+        for i in range(self.depth):
+            p = f'blocks.{i}.'
+            L.fill(self.bparams[i], ln1_w=a.param(p + 'norm1.weight'), ln1_b=a.param(p + 'norm1.bias'),
+                   ln2_w=a.param(p + 'norm2.weight'), ln2_b=a.param(p + 'norm2.bias'), qkv_b=a.param(p + 'attn.qkv.bias'),
+                   proj_b=a.param(p + 'attn.proj.bias'), fc1_b=a.param(p + 'mlp.fc1.bias'), fc2_b=a.param(p + 'mlp.fc2.bias'),
+                   qkv_w_hi=a.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=a.lo_of(p + 'attn.qkv.weight'),
+                   proj_w_hi=a.hi_of(p + 'attn.proj.weight'), proj_w_lo=a.lo_of(p + 'attn.proj.weight'),
+                   fc1_w_hi=a.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=a.lo_of(p + 'mlp.fc1.weight'),
+                   fc2_w_hi=a.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=a.lo_of(p + 'mlp.fc2.weight'))
+            L.fill(self.bgrads[i], ln1_w=a.grad(p + 'norm1.weight'), ln1_b=a.grad(p + 'norm1.bias'), ln2_w=a.grad(p + 'norm2.weight'),
+                   ln2_b=a.grad(p + 'norm2.bias'), qkv_w=a.grad(p + 'attn.qkv.weight'), qkv_b=a.grad(p + 'attn.qkv.bias'),
+                   proj_w=a.grad(p + 'attn.proj.weight'), proj_b=a.grad(p + 'attn.proj.bias'), fc1_w=a.grad(p + 'mlp.fc1.weight'),
+                   fc1_b=a.grad(p + 'mlp.fc1.bias'), fc2_w=a.grad(p + 'mlp.fc2.weight'), fc2_b=a.grad(p + 'mlp.fc2.bias'))
+        self._ws = {}
+
+    # ------------------------------------------------------------------ parameters / buffers
+    def load_state_dict(self, sd):
+        self.arena.load(sd)
+        for k, bn in self.bns.items():
+            if k + '.running_mean' in sd:
+                bn.run_mean.copy_(sd[k + '.running_mean']); bn.run_var.copy_(sd[k + '.running_var'])
+        self.refresh_weight_planes()
+
+    def state_dict(self):
+        sd = self.arena.state_dict()
+        for k, bn in self.bns.items():
+            sd[k + '.running_mean'] = bn.run_mean.clone(); sd[k + '.running_var'] = bn.run_var.clone()
+        return sd
+
+    def refresh_weight_planes(self):
+        self.arena.refresh_planes()
+        for l in self._linears:
+            l.refresh()
+
+    def zero_grad(self):
+        self.arena.g.zero_()
+
+    # ------------------------------------------------------------------ workspace
+    def workspace(self, B):
+        ws = self._ws.get(B)
+        if ws is not None:
+            return ws
+        dev, D, C0, N = self.device, self.D, self.C0, self.N
+        f32 = dict(dtype=torch.float32, device=dev); b16 = dict(dtype=torch.bfloat16, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        ws = type('WS', (), {})()
+        ws.B = B
+        BN = B * N
+        dpp = _round_up(self.dp, 8)
+        ws.xp = torch.zeros(2, BN, dpp, **b16); ws.xyzp = torch.zeros(2, BN, 8, **b16)
+        ws.h1 = torch.empty(2, BN, C0, **b16); ws.h1pre = torch.empty(BN, C0, **b16)
+        ws.h2 = torch.empty(2, BN, C0, **b16); ws.h2pre = torch.empty(BN, C0, **b16)
+        ws.f = torch.empty(BN, C0, **f32); ws.fp = torch.empty(2, BN, C0, **b16)
+        ws.td = []
+        xyz_n = N
+        cprev = C0
+        for i in range(2):
+            S, ch, cinp = self.S[i], self.ch[i], _round_up(self.cin[i], 8)
+            R = B * S * KNN
+            t = type('TD', (), {})()
+            t.S, t.R, t.cinp, t.Nin, t.Cin = S, R, cinp, xyz_n, cprev
+            t.fps_idx = torch.empty(B, S, **i32); t.new_xyz = torch.empty(B, S, 3, **f32)
+            t.idx = torch.empty(B, S, KNN, **i32)
+            t.A = torch.empty(2, R, cinp, **b16)
+            t.x1 = torch.empty(R, ch, **f32); t.y1 = torch.empty(2, R, ch, **b16)
+            t.x2 = torch.empty(R, ch, **f32); t.out = torch.empty(B * S, ch, **f32)
+            t.arg = torch.empty(B * S, ch, dtype=torch.uint8, device=dev)
+            t.dx = torch.empty(R, ch, **b16)                  # bf16 gradient scratch (dx2 then dx1)
+            t.dy1 = torch.empty(R, ch, **f32)
+            t.dA = torch.empty(R, cinp, **f32)
+            t.dout = torch.empty(B * S, ch, **f32)            # gradient wrt this level's output features
+            ws.td.append(t)
+            xyz_n, cprev = S, ch
+        S1 = self.S[1]
+        ws.ntok = S1 + 1
+        M = B * ws.ntok
+        ws.zero_pos = torch.zeros(ws.ntok, D, **f32)
+        ws.blocks = _BlockWorkspace(self.depth, B, ws.ntok, D, self.H, 4 * D, dev, self.split)
+        ws.scratch = _BlockScratch(M, D, self.H, 4 * D, B * self.H * ws.ntok, dev)
+        ws.nstats = torch.empty(2, M, **f32)
+        ws.xn = torch.empty(M, D, **f32)                       # norm(x) incl. cls rows
+        ws.t = torch.empty(B * S1, D, **f32); ws.tp = torch.empty(2, B * S1, D, **b16)
+        ws.dxn = torch.empty(M, D, **f32); ws.dt = torch.empty(B * S1, D, **f32)
+        ws.zero_cls = torch.zeros(D, **f32)
+        ws.tu = []
+        lvl = [(S1, self.S[0], self.ch[0], ws.td[0]), (self.S[0], N, C0, None)]          # (coarse pts, fine pts, channels)
+        for j, (Sc, Sf, ch, _) in enumerate(lvl):
+            u = type('TU', (), {})()
+            u.Sc, u.Sf, u.ch = Sc, Sf, ch
+            u.u1 = torch.empty(B * Sc, ch, **f32); u.f1 = torch.empty(B * Sc, ch, **f32)
+            u.u2 = torch.empty(B * Sf, ch, **f32); u.f2 = torch.empty(B * Sf, ch, **f32)
+            u.idx = torch.empty(B, Sf, 3, **i32); u.w = torch.empty(B, Sf, 3, **f32)
+            u.out = torch.empty(B * Sf, ch, **f32)
+            u.inp2 = torch.empty(2, B * Sf, ch, **b16)         # planes of the fine-level input (p0 / f)
+            u.inp1 = torch.empty(2, B * Sc, 2 * ch, **b16) if j == 1 else None     # planes of the coarse input (tu1: v0)
+            u.df1 = torch.empty(B * Sc, ch, **f32)
+            u.dxb1 = torch.empty(B * Sc, ch, **b16); u.dxb2 = torch.empty(B * Sf, ch, **b16)
+            u.din1 = torch.empty(B * Sc, 2 * ch, **f32)        # gradient wrt the coarse input
+            ws.tu.append(u)
+        ws.dv1 = torch.empty(BN, C0, **f32)
+        ws.df = torch.empty(BN, C0, **f32); ws.dfb = torch.empty(BN, C0, **b16)
+        ws.dh = torch.empty(BN, C0, **b16)
+        ws.loss = torch.zeros(2, **f32)
+        if self.task == 'cls':
+            ws.feat = torch.empty(B, C0, **f32); ws.dfeat = torch.empty(B, C0, **f32)
+            ws.logits = torch.empty(B, self.ncls, **f32); ws.dlogits = torch.empty(B, self.ncls, **f32)
+        else:
+            cp = self.head.opad
+            ws.v1p = torch.empty(2, BN, C0, **b16)
+            ws.logits = torch.empty(BN, cp, **f32); ws.dlogits = torch.empty(BN, cp, **f32)
+            ws.dlb = torch.empty(BN, cp, **b16)
+        self._ws[B] = ws
+        return ws
+
+    # ------------------------------------------------------------------ small helpers
+    def _pack(self, x, C, ldx, rows, planes, lo=True):
+        L.check(self.lib.s3d_pack_rows(L.ptr(x), C, ldx, ctypes.c_long(rows), L.ptr(planes[0]), L.ptr(planes[1]) if lo else None,
+                                       planes.shape[-1], L.current_stream()), 'pack_rows')
+
+    def _pack_bf(self, x, C, rows, out):
+        L.check(self.lib.s3d_pack_rows(L.ptr(x), C, C, ctypes.c_long(rows), L.ptr(out), None, C, L.current_stream()), 'pack_rows')
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, starts):
+        """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = (start0, start1) int64 [B] each."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        B, N, dp = x.shape
+        assert N == self.N and dp == self.dp, f'input {tuple(x.shape)} does not match the model (N={self.N}, d={self.dp})'
+        ws = self.workspace(B)
+        lib, s, a, C0, D = self.lib, L.current_stream(), self.arena, self.C0, self.D
+        BN = B * N
+        ws.xyz = x[..., :3].contiguous()
+        # fc1(x) + fc_pos_embed(xyz)
+        self._pack(x, dp, dp, BN, ws.xp)
+        self._pack(x, 3, dp, BN, ws.xyzp)
+        self.fc1[0].fwd(ws.xp[0], ws.xp[1], BN, 7, O_hi=ws.h1[0], O_lo=ws.h1[1], ldo=C0, aux=ws.h1pre, ldaux=C0)
+        self.fc1[1].fwd(ws.h1[0], ws.h1[1], BN, 4, C=ws.f, ldc=C0)
+        self.fcp[0].fwd(ws.xyzp[0], ws.xyzp[1], BN, 7, O_hi=ws.h2[0], O_lo=ws.h2[1], ldo=C0, aux=ws.h2pre, ldaux=C0)
+        self.fcp[1].fwd(ws.h2[0], ws.h2[1], BN, 2, C=ws.f, ldc=C0, R=ws.f, ldr=C0)
+        # transition downs
+        xyz_in, feats, cin_feats = ws.xyz, ws.f, C0
+        for i in range(2):
+            t, lay = ws.td[i], self.td[i]
+            L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
+            L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
+            L.check(lib.s3d_group_gather(L.ptr(xyz_in), L.ptr(t.new_xyz), L.ptr(feats), L.ptr(t.idx), B, t.Nin, t.S, KNN, cin_feats,
+                                         L.ptr(t.A[0]), L.ptr(t.A[1]), t.cinp, s), 'group_gather')
+            ch = self.ch[i]
+            lay['c0'].fwd(t.A[0], t.A[1], t.R, 4, C=t.x1, ldc=ch)
+            lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch)
+            lay['c1'].fwd(t.y1[0], t.y1[1], t.R, 4, C=t.x2, ldc=ch)
+            lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
+            xyz_in, feats, cin_feats = t.new_xyz, t.out, ch
+        # tokens -> blocks -> norm -> drop cls
+        S1 = self.S[1]
+        L.check(lib.s3d_assemble_tokens(L.ptr(ws.td[1].out), L.ptr(a.param('cls_token')), L.ptr(ws.zero_pos), L.ptr(ws.blocks.x[0]),
+                                        ctypes.c_long(B), S1, D, s), 'assemble')
+        L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, s), 'blocks_fwd')
+        M = B * ws.ntok
+        ln = L.fill(L.S3dLnArgs(), x=ws.blocks.x[self.depth], ldx=D, rows=M, D=D, eps=LN_EPS, gamma=a.param('norm.weight'),
+                    beta=a.param('norm.bias'), out_f32=ws.xn, ldo=D, mean=ws.nstats[0], rstd=ws.nstats[1])
+        L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
+        L.check(lib.s3d_assemble_tokens_bwd(L.ptr(ws.xn), L.ptr(ws.t), ctypes.c_long(B), S1, D, s), 'drop cls')
+        self._pack(ws.t, D, D, B * S1, ws.tp)
+        # transition ups
+        coarse_planes = ws.tp
+        coarse_xyz = [ws.td[1].new_xyz, ws.td[0].new_xyz]
+        fine_xyz = [ws.td[0].new_xyz, ws.xyz]
+        fine_feats = [ws.td[0].out, ws.f]
+        for j in range(2):
+            u, lay = ws.tu[j], self.tu[j]
+            ch = u.ch
+            lay['l1'].fwd(coarse_planes[0], coarse_planes[1], B * u.Sc, 4, C=u.u1, ldc=ch)
+            lay['b1'].fwd(u.u1, B * u.Sc, y=u.f1, ldo=ch)
+            self._pack(fine_feats[j], ch, ch, B * u.Sf, u.inp2)
+            lay['l2'].fwd(u.inp2[0], u.inp2[1], B * u.Sf, 4, C=u.u2, ldc=ch)
+            lay['b2'].fwd(u.u2, B * u.Sf, y=u.f2, ldo=ch)
+            L.check(lib.s3d_knn(L.ptr(fine_xyz[j]), L.ptr(coarse_xyz[j]), B, u.Sf, u.Sc, 3, L.ptr(u.idx), L.ptr(u.w), s), 'knn3')
+            L.check(lib.s3d_interp3(L.ptr(u.f1), u.Sc, L.ptr(u.f2), L.ptr(u.idx), L.ptr(u.w), B, u.Sf, ch, L.ptr(u.out), s), 'interp3')
+            if j == 0:
+                self._pack(u.out, ch, ch, B * u.Sf, ws.tu[1].inp1)
+                coarse_planes = ws.tu[1].inp1
+        v1 = ws.tu[1].out
+        if self.task == 'cls':
+            L.check(lib.s3d_mean_points(L.ptr(v1), B, N, C0, L.ptr(ws.feat), s), 'mean')
+            L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
+            return ws.logits
+        self._pack(v1, C0, C0, BN, ws.v1p)
+        self.head.fwd(ws.v1p[0], ws.v1p[1], BN, 4, C=ws.logits, ldc=self.head.opad)
+        return ws.logits.view(B, N, self.head.opad)[..., :self.ncls]
+
+    def _head_args(self, ws):
+        a = self.arena
+        return L.fill(L.S3dHeadArgs(), feat=ws.feat, B=ws.B, D=self.C0, C=self.ncls, W=a.param('head.weight'), bias=a.param('head.bias'),
+                      logits=ws.logits, am_softmax=0, am_scale=1.0, dlogits=ws.dlogits, dfeat=ws.dfeat, dW=a.grad('head.weight'),
+                      dbias=a.grad('head.bias'))
+
+    # ------------------------------------------------------------------ loss
+    def cross_entropy(self, B, target):
+        ws = self.workspace(B)
+        rows = B if self.task == 'cls' else B * self.N
+        ld = 0 if self.task == 'cls' else self.head.opad
+        tgt = target.reshape(-1)
+        assert tgt.dtype == torch.int64 and tgt.is_cuda and tgt.is_contiguous()
+        ce = L.fill(L.S3dCeArgs(), logits=ws.logits, target=tgt, rows=rows, C=self.ncls, loss=ws.loss, dlogits=ws.dlogits,
+                    grad_scale=1.0, ld=ld)
+        L.check(self.lib.s3d_cross_entropy(ctypes.byref(ce), L.current_stream()), 'cross_entropy')
+        return ws.loss[0]
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, B):
+        ws = self.workspace(B)
+        lib, s, a, C0, D, N = self.lib, L.current_stream(), self.arena, self.C0, self.D, self.N
+        BN = B * N
+        # head
+        if self.task == 'cls':
+            L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
+            L.check(lib.s3d_bcast_rows(L.ptr(ws.dfeat), N, C0, ctypes.c_long(BN), 1.0 / N, L.ptr(ws.dv1), s), 'bcast')
+        else:
+            cp = self.head.opad
+            self._pack_bf(ws.dlogits, cp, BN, ws.dlb)
+            self.head.bwd(ws.dlb, ws.v1p[0], BN, dx=ws.dv1, dx_epi=4)
+        # transition ups (reverse)
+        dfine = ws.dv1                                           # gradient wrt tu1 output [BN, C0]
+        for j in (1, 0):
+            u, lay = ws.tu[j], self.tu[j]
+            ch = u.ch
+            u.df1.zero_()
+            L.check(lib.s3d_interp3_bwd(L.ptr(dfine), L.ptr(u.idx), L.ptr(u.w), B, u.Sc, u.Sf, ch, L.ptr(u.df1), s), 'interp3_bwd')
+            # fine branch: f2 = relu(bn(l2(inp2)));  d(f2) = dfine
+            lay['b2'].bwd(u.u2, B * u.Sf, dfine, u.dxb2)
+            dfine_in = ws.df if j == 1 else ws.td[0].dout        # gradient wrt the fine-level input features (f / p0)
+            lay['l2'].bwd(u.dxb2, u.inp2[0], B * u.Sf, dx=dfine_in, dx_epi=4)
+            # coarse branch
+            lay['b1'].bwd(u.u1, B * u.Sc, u.df1, u.dxb1)
+            coarse_x = ws.tu[1].inp1[0] if j == 1 else ws.tp[0]
+            dcoarse = u.din1 if j == 1 else ws.dt
+            lay['l1'].bwd(u.dxb1, coarse_x, B * u.Sc, dx=dcoarse, dx_epi=4)
+            dfine = dcoarse                                      # tu1's coarse input is tu0's output
+        # drop-cls backward -> final norm -> blocks
+        S1 = self.S[1]
+        M = B * ws.ntok
+        L.check(lib.s3d_assemble_tokens(L.ptr(ws.dt), L.ptr(ws.zero_cls), L.ptr(ws.zero_pos), L.ptr(ws.dxn), ctypes.c_long(B), S1, D, s), 'undrop')
+        sc = ws.scratch
+        lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dxn, lddy=D, x=ws.blocks.x[self.depth], ldx=D, mean=ws.nstats[0], rstd=ws.nstats[1],
+                    gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=D, dx_bf=sc.dx_a_bf, lddxbf=D, dgamma=a.grad('norm.weight'),
+                    dbeta=a.grad('norm.bias'), rows=M, D=D)
+        L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd')
+        L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts, ctypes.byref(sc.c),
+                                   self.depth - 1, 0, s), 'blocks_bwd')
+        pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=B, ntok=ws.ntok, D=D, dcls=a.grad('cls_token'))
+        L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'cls grad')
+        L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.td[1].dout), ctypes.c_long(B), S1, D, s), 'tokens bwd')
+        # transition downs (reverse): dout of level 1 is complete; level 0's dout already holds tu0's contribution
+        for i in (1, 0):
+            t, lay = ws.td[i], self.td[i]
+            ch = self.ch[i]
+            lay['b1'].bwd(t.x2, t.R, t.dout, t.dx, K=KNN, arg=t.arg)
+            lay['c1'].bwd(t.dx, t.y1[0], t.R, dx=t.dy1, dx_epi=4)
+            lay['b0'].bwd(t.x1, t.R, t.dy1, t.dx)
+            lay['c0'].bwd(t.dx, t.A[0], t.R, dx=t.dA, dx_epi=4)
+            dprev = ws.td[0].dout if i == 1 else ws.df
+            L.check(lib.s3d_group_scatter(L.ptr(t.dA), t.cinp, L.ptr(t.idx), B, t.Nin, t.S, KNN, t.Cin, L.ptr(dprev), s), 'group_scatter')
+        # the two input MLPs: f = fc1(x) + fc_pos_embed(xyz)
+        self._pack_bf(ws.df, C0, BN, ws.dfb)
+        self.fc1[1].bwd(ws.dfb, ws.h1[0], BN, dx_epi=8, O_hi=ws.dh, ldo=C0, aux=ws.h1pre, ldaux=C0)
+        self.fc1[0].bwd(ws.dh, ws.xp[0], BN)
+        self.fcp[1].bwd(ws.dfb, ws.h2[0], BN, dx_epi=8, O_hi=ws.dh, ldo=C0, aux=ws.h2pre, ldaux=C0)
+        self.fcp[0].bwd(ws.dh, ws.xyzp[0], BN)
+
+    # ------------------------------------------------------------------ optimizer
+    def sgd_step(self):
+        """torch.optim.SGD(lr=0.01, momentum=0.9) (train_cls.py:91) + weight-plane refresh + gradient zeroing."""
+        a = self.arena
+        L.check(self.lib.s3d_sgd_step(L.ptr(a.p), L.ptr(a.g), L.ptr(self.buf), L.ptr(a.hi), L.ptr(a.lo), ctypes.c_long(a.numel),
+                                      ctypes.c_float(self.lr), ctypes.c_float(self.momentum), ctypes.c_float(self.grad_scale),
+                                      L.ptr(self.sgd_steps), L.current_stream()), 'sgd')
+        for l in self._linears:
+            l.refresh()
+
+    def train_step(self, x, target, starts):
+        B = x.shape[0]
+        self.forward(x, starts)
+        loss = self.cross_entropy(B, target)
+        self.backward(B)
+        self.sgd_step()
+        return loss
