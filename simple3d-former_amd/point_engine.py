@@ -420,7 +420,7 @@ class PointEngine:
         # head
         if self.task == 'cls':
             L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
-            L.check(lib.s3d_bcast_rows(L.ptr(ws.dfeat), N, C0, ctypes.c_long(BN), 1.0 / N, L.ptr(ws.dv1), s), 'bcast')
+            L.check(lib.s3d_bcast_rows(L.ptr(ws.dfeat), N, C0, ctypes.c_long(BN), ctypes.c_float(1.0 / N), L.ptr(ws.dv1), s), 'bcast')
         else:
             cp = self.head.opad
             self._pack_bf(ws.dlogits, cp, BN, ws.dlb)

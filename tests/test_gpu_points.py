@@ -35,8 +35,8 @@ def test_fps_indices_bit_exact(B, N, npoint):
     start = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(1))
     ref = po.farthest_point_sample(xyz, npoint, start)
     idx = torch.empty(B, npoint, dtype=torch.int32, device=DEV); nx = torch.empty(B, npoint, 3, device=DEV)
-    xd = xyz.to(DEV)
-    L.check(L.lib().s3d_fps(L.ptr(xd), ctypes.c_long(3), L.ptr(start.to(DEV)), B, N, npoint, L.ptr(idx), L.ptr(nx), L.current_stream()), 'fps')
+    xd, sd_ = xyz.to(DEV), start.to(DEV)            # keep device tensors alive: L.ptr() only takes the address
+    L.check(L.lib().s3d_fps(L.ptr(xd), ctypes.c_long(3), L.ptr(sd_), B, N, npoint, L.ptr(idx), L.ptr(nx), L.current_stream()), 'fps')
     assert torch.equal(idx.cpu().long(), ref)
     assert torch.equal(nx.cpu(), po.index_points(xyz, ref))
 
@@ -48,7 +48,8 @@ def test_knn16_and_3nn_indices_bit_exact(B, S, N):
     q = ref[:, torch.randperm(N, generator=g)[:S]].contiguous() if S <= N else torch.rand(B, S, 3, generator=g)
     want = po.knn_indices(q, ref, 16)
     idx = torch.empty(B, S, 16, dtype=torch.int32, device=DEV)
-    L.check(L.lib().s3d_knn(L.ptr(q.to(DEV)), L.ptr(ref.to(DEV)), B, S, N, 16, L.ptr(idx), None, L.current_stream()), 'knn')
+    qd, rd = q.to(DEV), ref.to(DEV)
+    L.check(L.lib().s3d_knn(L.ptr(qd), L.ptr(rd), B, S, N, 16, L.ptr(idx), None, L.current_stream()), 'knn')
     d = po.square_distance(q, ref)
     got = idx.cpu().long()
     # indices equal except inside exact distance ties, where any order is a valid argsort
@@ -57,7 +58,7 @@ def test_knn16_and_3nn_indices_bit_exact(B, S, N):
     assert bool((same | tied).all()) and float(same.float().mean()) > 0.999
     widx, w = po.three_nn_weights(q, ref)
     i3 = torch.empty(B, S, 3, dtype=torch.int32, device=DEV); w3 = torch.empty(B, S, 3, device=DEV)
-    L.check(L.lib().s3d_knn(L.ptr(q.to(DEV)), L.ptr(ref.to(DEV)), B, S, N, 3, L.ptr(i3), L.ptr(w3), L.current_stream()), 'knn3')
+    L.check(L.lib().s3d_knn(L.ptr(qd), L.ptr(rd), B, S, N, 3, L.ptr(i3), L.ptr(w3), L.current_stream()), 'knn3')
     assert float((i3.cpu().long() == widx).float().mean()) > 0.999
     assert rel_err(w3, w) < 1e-5
 
@@ -103,13 +104,15 @@ def test_gather_scatter_interp():
     lda = 16
     A = torch.zeros(2, B * S * K, lda, dtype=torch.bfloat16, device=DEV)
     idxd = idx.to(torch.int32).to(DEV)
-    L.check(L.lib().s3d_group_gather(L.ptr(xyz.to(DEV)), L.ptr(new_xyz.to(DEV)), L.ptr(feats.to(DEV)), L.ptr(idxd), B, N, S, K, C,
+    xyzd, nxd, fd = xyz.to(DEV), new_xyz.to(DEV), feats.to(DEV)
+    L.check(L.lib().s3d_group_gather(L.ptr(xyzd), L.ptr(nxd), L.ptr(fd), L.ptr(idxd), B, N, S, K, C,
                                      L.ptr(A[0]), L.ptr(A[1]), lda, L.current_stream()), 'gather')
     got = (A[0].float() + A[1].float()).cpu()
     assert rel_err(got[:, :3 + C], ref) < 1e-4 and float(got[:, 3 + C:].abs().max()) == 0.0
     dA = torch.randn(B * S * K, lda, generator=g)
     dfe = torch.zeros(B * N, C, device=DEV)
-    L.check(L.lib().s3d_group_scatter(L.ptr(dA.to(DEV)), lda, L.ptr(idxd), B, N, S, K, C, L.ptr(dfe), L.current_stream()), 'scatter')
+    dAd = dA.to(DEV)
+    L.check(L.lib().s3d_group_scatter(L.ptr(dAd), lda, L.ptr(idxd), B, N, S, K, C, L.ptr(dfe), L.current_stream()), 'scatter')
     want = torch.zeros(B, N, C).scatter_add_(1, idx.reshape(B, -1, 1).expand(-1, -1, C), dA[:, 3:3 + C].reshape(B, S * K, C))
     assert rel_err(dfe.view(B, N, C), want) < 1e-5
     # interpolation
@@ -118,7 +121,8 @@ def test_gather_scatter_interp():
     ref_out = (po.index_points(f1, i3) * w3[..., None]).sum(2) + f2
     out = torch.empty(B * N, C, device=DEV)
     i3d, w3d = i3.to(torch.int32).to(DEV), w3.to(DEV)
-    L.check(L.lib().s3d_interp3(L.ptr(f1.to(DEV)), S, L.ptr(f2.to(DEV)), L.ptr(i3d), L.ptr(w3d), B, N, C, L.ptr(out), L.current_stream()), 'interp')
+    f1d, f2d = f1.to(DEV), f2.to(DEV)
+    L.check(L.lib().s3d_interp3(L.ptr(f1d), S, L.ptr(f2d), L.ptr(i3d), L.ptr(w3d), B, N, C, L.ptr(out), L.current_stream()), 'interp')
     assert rel_err(out.view(B, N, C), ref_out) < 1e-5
 
 
@@ -143,7 +147,11 @@ def test_point_engine_matches_reference_golden(name):
     eng.backward(cfg['batch'])
     grads = {k: eng.arena.grad(k) for k in eng.shapes}
     assert set(grads) == set(json.loads(str(z['grad_names'])))
-    worst = check_grads_against_golden(z, grads, rtol=3e-3, atol=3e-6)
+    # biases that feed a train-mode BatchNorm (and the final LayerNorm bias, which only reaches the loss through one) have a
+    # theoretically ZERO gradient; both implementations return rounding noise there, so they are excluded from the comparison
+    zero_theory = ('mlp_convs.0.bias', 'mlp_convs.1.bias', 'fc1.0.bias', 'fc2.0.bias', 'norm.bias')
+    zero_theory = tuple(k for k in grads if k.endswith(zero_theory) and (k.startswith('transition_') or k == 'norm.bias'))
+    worst = check_grads_against_golden(z, grads, rtol=3e-3, atol=3e-6, skip=zero_theory)
     print(f'{name}: logits err {err:.2e}, worst sampled grad err / rms {worst:.3f}')
 
 
