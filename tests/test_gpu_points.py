@@ -151,6 +151,7 @@ def test_point_engine_matches_reference_golden(name):
     # theoretically ZERO gradient; both implementations return rounding noise there, so they are excluded from the comparison
     zero_theory = ('mlp_convs.0.bias', 'mlp_convs.1.bias', 'fc1.0.bias', 'fc2.0.bias', 'norm.bias')
     zero_theory = tuple(k for k in grads if k.endswith(zero_theory) and (k.startswith('transition_') or k == 'norm.bias'))
+    zero_theory += ('fc1.2.bias', 'fc_pos_embed.2.bias')       # constant shifts of f: cancelled by the BatchNorms downstream
     worst = check_grads_against_golden(z, grads, rtol=3e-3, atol=3e-6, skip=zero_theory)
     print(f'{name}: logits err {err:.2e}, worst sampled grad err / rms {worst:.3f}')
 
