@@ -272,6 +272,7 @@ typedef struct S3dBnArgs {
     const float* dy; int lddy;            /* bwd: gradient wrt the (ReLU / max) output */
     uint16_t* dx; int lddx;               /* bwd: gradient wrt x as bf16 [rows][lddx] */
     float* dgamma; float* dbeta;
+    int eval_mode;                        /* fwd: normalise with the running statistics (model.eval()), no update */
 } S3dBnArgs;
 int s3d_batchnorm_fwd(const S3dBnArgs* args, s3d_stream_t stream);
 int s3d_batchnorm_bwd(const S3dBnArgs* args, s3d_stream_t stream);

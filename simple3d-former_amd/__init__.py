@@ -5,8 +5,10 @@ the timm==0.3.2 VisionTransformer it subclasses); everything computes through li
 from . import _lib
 from .engine import BACKBONES, VoxelEngine, voxel_param_shapes
 from .tokenizers import VoxelEmbed, VoxelEmbed_no_average, VoxelNaiveProjection
+from .point_engine import PointEngine, point_param_shapes
+from .point_model import PointTransformerCls, PointTransformerSeg
 from .voxel_model import AMSoftmaxLayer, Attention, Block, Feature3D_ViT2D_V2, Mlp, PatchEmbed, VisionTransformer
 
 __all__ = ['VoxelEmbed', 'VoxelEmbed_no_average', 'VoxelNaiveProjection', 'VisionTransformer', 'Block', 'Attention',
            'Mlp', 'PatchEmbed', 'AMSoftmaxLayer', 'Feature3D_ViT2D_V2', 'VoxelEngine', 'BACKBONES',
-           'voxel_param_shapes']
+           'voxel_param_shapes', 'PointEngine', 'point_param_shapes', 'PointTransformerCls', 'PointTransformerSeg']

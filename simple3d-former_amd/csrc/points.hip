@@ -195,6 +195,11 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, long rows, i
         run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(var * ((double)rows / (double)(rows > 1 ? rows - 1 : 1)));
     }
 }
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float eps,
+                                       float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { mean[c] = run_mean[c]; rstd[c] = 1.0f / sqrtf(run_var[c] + eps); }
+}
 // y = relu((x - mean) * rstd * gamma + beta) -> fp32 and/or split planes (row pitch ldo)
 __global__ void bn_relu_kernel(const float* __restrict__ x, long rows, int C, int ld, const float* __restrict__ mean,
                                const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -412,11 +417,16 @@ int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, in
 }
 int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
-    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
-    const int per = 256 / a.C;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
-                       a.run_mean, a.run_var);
+    if (a.eval_mode) {
+        S3D_REQUIRE(a.run_mean && a.run_var, "batchnorm(eval): running statistics required");
+        hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, a.run_mean, a.run_var, a.C, a.eps, a.mean, a.rstd);
+    } else {
+        (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+        const int per = 256 / a.C;
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
+                           a.run_mean, a.run_var);
+    }
     if (a.K > 0) {
         S3D_REQUIRE(a.rows % a.K == 0 && a.ldx == a.C, "batchnorm(max): rows must be groups*K and x compact");
         const long groups = a.rows / a.K;

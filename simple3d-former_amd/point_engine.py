@@ -141,7 +141,7 @@ class _BatchNorm:
         a = self.eng.arena
         return L.fill(L.S3dBnArgs(), x=x, ldx=self.C, rows=rows, C=self.C, K=K, eps=BN_EPS, momentum=self.eng.bn_momentum,
                       gamma=a.param(self.key + '.weight'), beta=a.param(self.key + '.bias'), mean=self.mean, rstd=self.rstd,
-                      run_mean=self.run_mean, run_var=self.run_var, sums=self.sums, **kw)
+                      run_mean=self.run_mean, run_var=self.run_var, sums=self.sums, eval_mode=0 if self.eng.training else 1, **kw)
 
     def fwd(self, x, rows, K=0, **kw):
         L.check(self.eng.lib.s3d_batchnorm_fwd(ctypes.byref(self._args(x, rows, K, **kw)), L.current_stream()), self.key)
@@ -174,6 +174,7 @@ class PointEngine:
         self.cin = [self.C0 + 3, self.ch[0] + 3]
         self.split, self.bn_momentum = bool(split), bn_momentum
         self.lr, self.momentum = lr, momentum
+        self.training = True                # BatchNorm mode: batch statistics (model.train()) vs running statistics
         self.shapes = point_param_shapes(backbone, n_classes, d_points)
         self.arena = ParamArena(self.shapes, self.device)
         self.buf = torch.zeros_like(self.arena.p)                   # SGD momentum buffer
@@ -326,8 +327,10 @@ class PointEngine:
         L.check(self.lib.s3d_pack_rows(L.ptr(x), C, C, ctypes.c_long(rows), L.ptr(out), None, C, L.current_stream()), 'pack_rows')
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, starts):
-        """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = (start0, start1) int64 [B] each."""
+    def forward(self, x, starts, training=True):
+        """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = (start0, start1) int64 [B] each.
+        training=False normalises with the BatchNorm running statistics (model.eval()); backward needs training=True."""
+        self.training = bool(training)
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         B, N, dp = x.shape
         assert N == self.N and dp == self.dp, f'input {tuple(x.shape)} does not match the model (N={self.N}, d={self.dp})'

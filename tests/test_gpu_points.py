@@ -167,3 +167,45 @@ def test_point_engine_sgd_training_reduces_loss():
     for _ in range(15):
         l1 = float(eng.train_step(x.to(DEV), y.to(DEV), sts))
     assert l1 < l0, f'{l0} -> {l1}'
+
+
+@pytest.mark.parametrize('name', ['pts_cls_tiny_n64_b3', 'pts_seg_tiny_n64_b2'])
+def test_drop_in_point_module_matches_reference(name):
+    """classifier = PointTransformerCls(cfg).cuda(); pred = classifier(points); loss.backward(); SGD.step()
+    (train_cls.py:69,117-123 / train_partseg.py:74,143-152) on the drop-in module, train- and eval-mode."""
+    import types
+    import simple3d_former_amd as s3d
+    z, cfg, sd, x, y, starts = load_point_case(name)
+    c = types.SimpleNamespace(num_point=cfg['n_points'], num_class=cfg['n_classes'], input_dim=cfg['d_points'],
+                              model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head='default',
+                                                          transformer_backbone=cfg['backbone'], pretrained=False, name='3DViT'))
+    model = (s3d.PointTransformerCls if cfg['task'] == 'cls' else s3d.PointTransformerSeg)(c)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected
+    model = model.to(DEV).train()
+    model.s3d_fps_starts = starts
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    opt.zero_grad()
+    pred = model(x.to(DEV))
+    assert tuple(pred.shape) == tuple(z['logits'].shape)
+    assert float(np.abs(pred.detach().cpu().numpy() - z['logits']).max()) <= 1e-3
+    loss = F.cross_entropy(pred.reshape(-1, cfg['n_classes']), y.to(DEV).reshape(-1))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-3
+    loss.backward()
+    g = model.transition_ups[0].fc1[0].weight.grad
+    assert g is not None and abs(float(g.double().norm()) - float(z['gnorm/transition_ups.0.fc1.0.weight'])) <= 0.03 * float(z['gnorm/transition_ups.0.fc1.0.weight'])
+    assert model.pos_embed.grad is None and model.patch_embed.conv1.weight.grad is None      # unused, as in the reference
+    opt.step()
+    # BatchNorm buffers were updated in place by the train-mode forward (module buffers alias the engine's)
+    np.testing.assert_allclose(model.transition_downs[0].sa.mlp_bns[0].running_mean.cpu().numpy(),
+                               z['stat/transition_downs.0.sa.mlp_bns.0.running_mean'], rtol=1e-4, atol=1e-5)
+    assert int(model.transition_downs[0].sa.mlp_bns[0].num_batches_tracked) == 1
+    # eval mode: running statistics; the golden eval pass ran after exactly one train-mode pass, before any optimizer step
+    model2 = (s3d.PointTransformerCls if cfg['task'] == 'cls' else s3d.PointTransformerSeg)(c)
+    model2.load_state_dict(sd, strict=False)
+    model2 = model2.to(DEV).train()
+    model2.s3d_fps_starts = starts
+    with torch.no_grad():
+        model2(x.to(DEV))
+        ev = model2.eval()(x.to(DEV))
+    assert float(np.abs(ev.cpu().numpy() - z['logits_eval']).max()) <= 1e-3

@@ -121,3 +121,35 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), f
                 assert 'timm_shim' not in src, f
+
+
+def _point_cfg(task):
+    import types
+    n, d, c = (1024, 6, 40) if task == 'cls' else (2048, 22, 50)
+    return types.SimpleNamespace(num_point=n, num_class=c, input_dim=d,
+                                 model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head='default',
+                                                             transformer_backbone='deit_tiny_patch16_224', pretrained=False, name='3DViT'))
+
+
+@pytest.mark.parametrize('task', ['cls', 'seg'])
+def test_point_module_state_dict_contract(task):
+    """Key names + shapes equal the reference's PointTransformerCls/Seg state_dict (fixture captured from the reference by
+    tests/golden/make_golden_points.py tooling), incl. the parameters the reference creates but never uses."""
+    import json
+    from tests._util import GOLDEN
+    from oracle import point_oracle as po
+    ref = json.load(open(f'{GOLDEN}/point_state_dict_keys.json'))[task]
+    cfg = _point_cfg(task)
+    model = (s3d.PointTransformerCls if task == 'cls' else s3d.PointTransformerSeg)(cfg)
+    assert cfg.embed_dim == 192                                        # written back like models/3DViT/model.py:221
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == ref
+    # the engine's parameter set is exactly the set the oracle's forward touches
+    sd = po.init_state_dict(backbone='deit_tiny_patch16_224', n_classes=cfg.num_class, d_points=cfg.input_dim)
+    shapes = s3d.point_param_shapes('deit_tiny_patch16_224', cfg.num_class, cfg.input_dim)
+    assert set(shapes) == set(po.used_param_names(sd))
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(1, cfg.num_point, cfg.input_dim))
+    cfg.model.transformer_backbone = 'resnet50'
+    with pytest.raises(ValueError, match='Unknown transformer backbone name!'):
+        s3d.PointTransformerCls(cfg)
