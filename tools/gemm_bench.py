@@ -38,9 +38,12 @@ def planes(r, c):
 
 
 def main():
+    only = os.environ.get('ONLY', '')
     res = []
     # forward NT split: (name, N, K, epi)
     for name, N, K, epi in [('qkv', 3 * D, D, 'BF16_BIAS'), ('proj', D, D, 'RESID'), ('fc1', 4 * D, D, 'GELU'), ('fc2', D, 4 * D, 'RESID')]:
+        if only and only != 'fwd_' + name:
+            continue
         ah, al = planes(M, K); bh, bl = planes(N, K)
         bias = torch.randn(N, device=DEV)
         R = torch.randn(M, N, device=DEV); C = torch.empty(M, N, device=DEV)
@@ -53,6 +56,8 @@ def main():
             res.append((f'fwd {name} split={split}', M, N, K, us))
     # dgrad NN
     for name, N, K, epi in [('fc2', 4 * D, D, 'DGELU'), ('fc1', D, 4 * D, 'F32'), ('proj', D, D, 'BF16_BIAS'), ('qkv', D, 3 * D, 'F32')]:
+        if only and only != 'dgrad_' + name:
+            continue
         ah, _ = planes(M, K); bh, _ = planes(K, N)
         C = torch.empty(M, N, device=DEV); oh = torch.empty(M, N, dtype=torch.bfloat16, device=DEV); aux = torch.randn(M, N, device=DEV).to(torch.bfloat16)
         def f():
@@ -60,6 +65,8 @@ def main():
         res.append((f'dgrad {name}', M, N, K, timeit(f)))
     # wgrad TN: dW[O][I] = dy[M][O]^T x[M][I]
     for name, O, I in [('fc2', D, 4 * D), ('fc1', 4 * D, D), ('proj', D, D), ('qkv', 3 * D, D)]:
+        if only and only != 'wgrad_' + name:
+            continue
         dy, _ = planes(M, O); x, _ = planes(M, I)
         dW = torch.zeros(O, I, device=DEV); db = torch.zeros(O, device=DEV)
         def f():
