@@ -48,9 +48,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, one exp + 5 FMAs): ~3x fewer VALU instructions than erff in
+// the GELU epilogues, with an error far below the bf16/1e-3 budgets of this path.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = 1.0f / (1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
     const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
     return cdf + x * pdf;
 }

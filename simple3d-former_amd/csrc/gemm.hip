@@ -59,6 +59,7 @@ struct Stager {
     // hipcc branch around every load and wait for each one separately, which serialises the HBM/L2 latencies.
     // Rows beyond R only feed out-of-range outputs (never stored), so they are clamped, not zeroed; k beyond kend
     // must read as zero.
+    template <bool KFULL>
     __device__ static __forceinline__ void load(u32x4 (&v)[NV], const bf16_t* __restrict__ base, long ld, int r0,
                                                 int k0, int R, int kend, int tid) {
         const u32x4 zero = {0u, 0u, 0u, 0u};
@@ -67,9 +68,13 @@ struct Stager {
             for (int i = 0; i < NT; ++i) {
                 const int r = (tid >> 3) + i * 32, kc = tid & 7;
                 const int gr = min(r0 + r, R - 1), gk = k0 + kc * 8;
-                const bool ok = gk < kend;
-                const u32x4 t = *reinterpret_cast<const u32x4*>(base + (long)gr * ld + (ok ? gk : 0));
-                v[i] = ok ? t : zero;
+                if constexpr (KFULL) {
+                    v[i] = *reinterpret_cast<const u32x4*>(base + (long)gr * ld + gk);
+                } else {
+                    const bool ok = gk < kend;
+                    const u32x4 t = *reinterpret_cast<const u32x4*>(base + (long)gr * ld + (ok ? gk : 0));
+                    v[i] = ok ? t : zero;
+                }
             }
         } else {
 #pragma unroll
@@ -78,6 +83,11 @@ struct Stager {
                 const int rc = q % CH, kp = q / CH;
                 const int gk = k0 + 2 * kp, gr = min(r0 + rc * 8, R - 8);
                 if (NT * 256 == CH * 32 || q < CH * 32) {      // wave-uniform (only BR = 32 leaves waves idle)
+                    if constexpr (KFULL) {
+                        v[2 * j] = *reinterpret_cast<const u32x4*>(base + (long)gk * ld + gr);
+                        v[2 * j + 1] = *reinterpret_cast<const u32x4*>(base + (long)(gk + 1) * ld + gr);
+                        continue;
+                    }
                     const bool ok0 = gk < kend, ok1 = gk + 1 < kend;
                     const u32x4 t0 = *reinterpret_cast<const u32x4*>(base + (long)(ok0 ? gk : 0) * ld + gr);
                     const u32x4 t1 = *reinterpret_cast<const u32x4*>(base + (long)(ok1 ? gk + 1 : 0) * ld + gr);
@@ -175,15 +185,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < 8; ++i) bsum[j][i] = 0.f;
     }
 
-#define GLOAD(SET, T)                                                                     \
+    // every k-tile full (kend - kbeg a multiple of 64): loads need no k-bound select (block-uniform fast path)
+    const bool kfull = ((kend - kbeg) & 63) == 0;
+#define GLOAD_(KF, SET, T)                                                                \
     do {                                                                                  \
         const int k0__ = kbeg + (T) * 64;                                                 \
-        SA::load(va_hi[SET], p.A_hi, p.lda, m0, k0__, p.M, kend, tid);                    \
-        SB::load(vb_hi[SET], p.B_hi, p.ldb, n0, k0__, p.N, kend, tid);                    \
+        SA::template load<KF>(va_hi[SET], p.A_hi, p.lda, m0, k0__, p.M, kend, tid);       \
+        SB::template load<KF>(vb_hi[SET], p.B_hi, p.ldb, n0, k0__, p.N, kend, tid);       \
         if constexpr (SPLIT) {                                                            \
-            SA::load(va_lo[SET], p.A_lo, p.lda, m0, k0__, p.M, kend, tid);                \
-            SB::load(vb_lo[SET], p.B_lo, p.ldb, n0, k0__, p.N, kend, tid);                \
+            SA::template load<KF>(va_lo[SET], p.A_lo, p.lda, m0, k0__, p.M, kend, tid);   \
+            SB::template load<KF>(vb_lo[SET], p.B_lo, p.ldb, n0, k0__, p.N, kend, tid);   \
         }                                                                                 \
+    } while (0)
+#define GLOAD(SET, T)                                                                     \
+    do {                                                                                  \
+        if (kfull) GLOAD_(true, SET, T); else GLOAD_(false, SET, T);                      \
     } while (0)
 #define LSTORE(SET, BUF)                                                                  \
     do {                                                                                  \
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
 #undef GLOAD
+#undef GLOAD_
 #undef LSTORE
 
     // ---------------------------------------------------------------- epilogue
