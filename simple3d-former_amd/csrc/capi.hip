@@ -81,12 +81,15 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     return 0;
 }
 
-// wgrad helper: dW[out][in] += dy^T x  (dy [M][out] bf16, x [M][in] bf16), db[out] += colsum(dy)
-int wgrad(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db, hipStream_t s) {
+// wgrad: dW[out][in] += dy^T x  (dy [M][out] bf16, x [M][in] bf16), db[out] += colsum(dy)
+GemmArgs wgrad_args(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db) {
     GemmArgs g = gemm_zero();
     g.A_hi = dy; g.lda = out; g.B_hi = x; g.ldb = in; g.M = out; g.N = in; g.K = (int)M; g.C = dW; g.ldc = in;
     g.bias_grad = db;
-    return s3d_launch_gemm(true, true, false, EPI_ATOMIC, g, 0, s);
+    return g;
+}
+int wgrad(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db, hipStream_t s) {
+    return s3d_launch_gemm(true, true, false, EPI_ATOMIC, wgrad_args(dy, out, x, in, M, dW, db), 0, s);
 }
 
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
@@ -94,15 +97,14 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     // ---- MLP branch: d(x_out) is in dx_a / dx_a_bf
-    S3D_TRY(wgrad(w.dx_a_bf, D, a.hact_hi, Hd, M, gr.fc2_w, gr.fc2_b, s));
-    GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)
+    // every dgrad is launched together with the wgrad that consumes the same dy (one grid, two problems)
+    GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)          || dW2 += dx_out^T hact
     g.A_hi = w.dx_a_bf; g.lda = D; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M; g.N = Hd; g.K = D;
     g.aux = a.hpre; g.ldaux = Hd; g.O_hi = w.dh; g.ldo = Hd;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DGELU, g, 1, s));
-    S3D_TRY(wgrad(w.dh, Hd, a.xn2_hi, D, M, gr.fc1_w, gr.fc1_b, s));
-    g = gemm_zero();            // dxn2 = dh @ W1
+    S3D_TRY(s3d_launch_gemm_pair(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M, gr.fc2_w, gr.fc2_b), s));
+    g = gemm_zero();            // dxn2 = dh @ W1                             || dW1 += dh^T xn2
     g.A_hi = w.dh; g.lda = Hd; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M, gr.fc1_w, gr.fc1_b), s));
     LnBwdArgs lb;
     memset(&lb, 0, sizeof(lb));
     lb.dy = w.dxn; lb.lddy = D; lb.x = a.x_mid; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
@@ -110,10 +112,9 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M; lb.D = D;
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
-    S3D_TRY(wgrad(w.dx_b_bf, D, a.att_hi, D, M, gr.proj_w, gr.proj_b, s));
-    g = gemm_zero();            // datt = dx_mid @ Wproj
+    g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
     g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_BF16_BIAS, g, 1, s));
+    S3D_TRY(s3d_launch_gemm_pair(EPI_BF16_BIAS, g, wgrad_args(w.dx_b_bf, D, a.att_hi, D, M, gr.proj_w, gr.proj_b), s));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
@@ -121,10 +122,9 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
     S3D_TRY(s3d_launch_attention_bwd(at, s));
-    S3D_TRY(wgrad(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b, s));
-    g = gemm_zero();            // dxn1 = dqkv @ Wqkv
+    g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s));
     lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = w.dx_b; lb.dx = w.dx_a;
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
     S3D_TRY(s3d_launch_ln_bwd(lb, s));

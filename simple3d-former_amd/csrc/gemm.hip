@@ -140,8 +140,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int r, int
 // rows at cfg-2) and latency-bound: bytes in flight per CU / memory latency sets the rate, so the loads of tile
 // t+PD are issued before tile t is consumed.
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
+                                          const int bz) {
     constexpr int PD = (BM * BN >= 128 * 128) ? 2 : 3;
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
@@ -155,14 +155,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // XCD-aware tile mapping: the dispatcher places consecutive workgroups on consecutive XCDs (private L2 each).
     // Give every XCD a contiguous run of row-major tile ids so workgroups that share an A row-panel (and the B
     // panel walk) hit the same L2 instead of fetching the panel once per XCD.  Pure speed; any placement is correct.
-    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     {
-        const int ntile = gridDim.x * gridDim.y;
+        const int ntile = ntx * nty;
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any ntile
     }
-    const int m0 = (tile_id / gridDim.x) * BM, n0 = (tile_id % gridDim.x) * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    const int kbeg = bz * p.kchunk;
     const int kend = min(p.K, kbeg + p.kchunk);
     const int ntiles = (kend - kbeg + 63) >> 6;
 
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // bias-gradient partials (TN only): row sums of the A operand over k, taken from the staged registers
     float bsum[TA ? SA::NT : 1][8];
-    const bool want_bsum = TA && (EPI == EPI_ATOMIC) && p.bias_grad != nullptr && (tile_id % gridDim.x) == 0;
+    const bool want_bsum = TA && (EPI == EPI_ATOMIC) && p.bias_grad != nullptr && (tile_id % ntx) == 0;
     if constexpr (TA) {
 #pragma unroll
         for (int j = 0; j < SA::NT; ++j)
@@ -385,6 +384,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_body<BM, BN, TA, TB, SPLIT, EPI>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+}
+
+// Two independent GEMM problems in ONE launch: a dgrad (NN) and the wgrad (TN, split-K atomics) that consume the same dy.
+// Each alone under-fills the chip at these sizes (latency-bound); sharing a grid halves the backward GEMM launch count
+// and overlaps their latencies without streams.  Workgroups [0, nA) run problem A, the rest problem B.
+template <int BMA, int EPIA, int BMB>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs pa, const GemmArgs pb, int nA, int ntxA, int ntyA,
+                                                        int ntxB, int ntyB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < nA) {
+        gemm_body<BMA, 64, false, true, false, EPIA>(pa, smem, bid, ntxA, ntyA, 0);
+    } else {
+        const int b = bid - nA, tiles = ntxB * ntyB;
+        gemm_body<BMB, 64, true, true, false, EPI_ATOMIC>(pb, smem, b % tiles, ntxB, ntyB, b / tiles);
+    }
+}
+
+template <int BMA, int EPIA, int BMB>
+int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream) {
+    constexpr int LDS = 2 * ((BMA > BMB ? BMA : BMB) + 64) * 128;
+    static bool attr_set = false;
+    auto kern = gemm_pair_kernel<BMA, EPIA, BMB>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int ntxA = (a.N + 63) / 64, ntyA = (a.M + BMA - 1) / BMA, ntxB = (b.N + 63) / 64, ntyB = (b.M + BMB - 1) / BMB;
+    const int nA = ntxA * ntyA, nB = ntxB * ntyB * splitk;
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = 9000000 + BMA * 10000 + BMB * 100 + EPIA;
+        sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+    }
+    S3D_CHECK_LAUNCH("gemm_pair");
+    return 0;
+}
+
+template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
     constexpr int LDS = 2 * NPL * (BM + BN) * 128;
@@ -451,6 +499,53 @@ int s3d_gemm_pick_tile(int M, int N, int splitk) {
     return 0;
 }
 
+static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk) {
+    static const int forced_sk = env_int("S3D_GEMM_SPLITK");
+    if (forced_sk > 0) splitk = forced_sk;
+    if (splitk <= 0) {
+        const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+        splitk = (int)((512 + tiles64 - 1) / tiles64);
+        const int maxk = (a.K + 127) / 128;
+        if (splitk > maxk) splitk = maxk;
+        if (splitk < 1) splitk = 1;
+    }
+    kchunk = ((a.K + splitk - 1) / splitk + 63) / 64 * 64;
+    splitk = (a.K + kchunk - 1) / kchunk;
+}
+
+template <int EPIA>
+static int launch_pair_tiles(int ta_, int tb_, const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t s) {
+    if (ta_ == 0 && tb_ == 0) return launch_pair_one<32, EPIA, 32>(a, b, splitk, s);
+    if (ta_ == 0 && tb_ == 1) return launch_pair_one<32, EPIA, 64>(a, b, splitk, s);
+    if (ta_ == 1 && tb_ == 0) return launch_pair_one<64, EPIA, 32>(a, b, splitk, s);
+    return launch_pair_one<64, EPIA, 64>(a, b, splitk, s);
+}
+
+// dgrad (NN, epilogue epi_a) + wgrad (TN atomic) in one launch; falls back to two launches for shapes that want 128x128 tiles
+int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
+    static const int no_pair = env_int("S3D_GEMM_NOPAIR");
+    GemmArgs a = a_in, b = b_in;
+    int splitk = 0, kchunk = 0;
+    wgrad_split(b, splitk, kchunk);
+    const int tile_a = s3d_gemm_pick_tile(a.M, a.N, 1), tile_b = s3d_gemm_pick_tile(b.M, b.N, splitk);
+    const bool ok = (a.K % 8 == 0) && (a.N % 8 == 0) && (b.M % 8 == 0) && (b.N % 8 == 0) && (a.lda % 8 == 0) && (a.ldb % 8 == 0) &&
+                    (b.lda % 8 == 0) && (b.ldb % 8 == 0);
+    if (no_pair > 0 || tile_a == 2 || tile_b == 2 || !ok) {
+        if (int rc = s3d_launch_gemm(true, true, false, EPI_ATOMIC, b_in, 0, stream)) return rc;
+        return s3d_launch_gemm(false, true, false, epi_a, a_in, 1, stream);
+    }
+    a.kchunk = (a.K + 63) / 64 * 64;
+    b.kchunk = kchunk;
+    switch (epi_a) {
+        case EPI_F32: return launch_pair_tiles<EPI_F32>(tile_a, tile_b, a, b, splitk, stream);
+        case EPI_DGELU: return launch_pair_tiles<EPI_DGELU>(tile_a, tile_b, a, b, splitk, stream);
+        case EPI_DRELU: return launch_pair_tiles<EPI_DRELU>(tile_a, tile_b, a, b, splitk, stream);
+        case EPI_RESID: return launch_pair_tiles<EPI_RESID>(tile_a, tile_b, a, b, splitk, stream);
+        case EPI_BF16_BIAS: return launch_pair_tiles<EPI_BF16_BIAS>(tile_a, tile_b, a, b, splitk, stream);
+        default: s3d_set_error("gemm_pair: epilogue %d not available", epi_a); return 2;
+    }
+}
+
 int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in, int splitk, hipStream_t stream) {
     GemmArgs a = a_in;
     S3D_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -464,17 +559,8 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
 
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
         S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");
-        static const int forced_sk = env_int("S3D_GEMM_SPLITK");
-        if (forced_sk > 0) splitk = forced_sk;
-        if (splitk <= 0) {
-            const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-            splitk = (int)((512 + tiles64 - 1) / tiles64);
-            const int maxk = (a.K + 127) / 128;
-            if (splitk > maxk) splitk = maxk;
-            if (splitk < 1) splitk = 1;
-        }
-        int kchunk = ((a.K + splitk - 1) / splitk + 63) / 64 * 64;
-        splitk = (a.K + kchunk - 1) / kchunk;
+        int kchunk = 0;
+        wgrad_split(a, splitk, kchunk);
         a.kchunk = kchunk;
         const int tile = s3d_gemm_pick_tile(a.M, a.N, splitk);
         return launch_tiles<true, true, false, EPI_ATOMIC>(tile, a, splitk, stream);
