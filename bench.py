@@ -47,6 +47,9 @@ EPI_NAMES = {0: 'bf16_bias', 1: 'gelu', 2: 'resid', 3: 'token', 4: 'f32', 5: 'dg
 
 def kernel_name(key):
     key = int(key)
+    if key >= 9000000:       # fused dgrad + wgrad launch: 9000000 + BM_dgrad*10000 + BM_wgrad*100 + dgrad epilogue
+        k = key - 9000000
+        return f'gemm_pair_kernel<dgrad {k // 10000}x64 NN {EPI_NAMES.get(k % 100, k % 100)} || wgrad {(k // 100) % 100}x64 TN atomic>'
     bm, ta, tb, sp, epi = key // 100000, (key // 10000) % 10, (key // 1000) % 10, (key // 100) % 10, key % 100
     bn = 128 if bm == 128 else 64
     return f'gemm_kernel<{bm},{bn},{"T" if ta else "N"}{"T" if not tb else "N"},{"split3" if sp else "bf16"},{EPI_NAMES.get(epi, epi)}>'
