@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
     }
 }
 
+// Backward: each wave owns RPW consecutive-by-stride rows and issues ALL their loads before any reduction, so it pays one
+// memory latency instead of RPW (the kernel is latency-bound at M ~ 1.7k rows); dgamma/dbeta partials are reduced across the
+// block's waves in LDS and added with one atomic per column per block (same-address atomics serialise at ~12 ns each, so the
+// block count is kept at rows/16).
+constexpr int RPW = 4;
+
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);          // [2][4 waves][D]
@@ -65,42 +71,67 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
     float4 dg[MAXC], db[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nchunk = (p.D + 255) / 256;                 // float4 chunks per lane actually used (<= MAXC)
 
-    for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += nw) {
-        const float mean = p.mean[row], rstd = p.rstd[row];
-        float4 xh[MAXC], g[MAXC];
-        float s1 = 0.f, s2 = 0.f;
+    for (long row0 = (long)blockIdx.x * 4 + wave; row0 < p.rows; row0 += nw * RPW) {
+        float4 X[RPW][MAXC], DY[RPW][MAXC], R[RPW][MAXC];
+        float mean[RPW], rstd[RPW];
+        // phase 1: every load of every row of this batch
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < p.D) {
-                const float4 x = *reinterpret_cast<const float4*>(p.x + row * p.ldx + col);
-                const float4 dy = *reinterpret_cast<const float4*>(p.dy + row * p.lddy + col);
-                const float4 w = *reinterpret_cast<const float4*>(p.gamma + col);
-                xh[c] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
-                g[c] = make_float4(dy.x * w.x, dy.y * w.y, dy.z * w.z, dy.w * w.w);
-                s1 += g[c].x + g[c].y + g[c].z + g[c].w;
-                s2 += g[c].x * xh[c].x + g[c].y * xh[c].y + g[c].z * xh[c].z + g[c].w * xh[c].w;
-                dg[c].x += dy.x * xh[c].x; dg[c].y += dy.y * xh[c].y; dg[c].z += dy.z * xh[c].z; dg[c].w += dy.w * xh[c].w;
-                db[c].x += dy.x; db[c].y += dy.y; db[c].z += dy.z; db[c].w += dy.w;
+        for (int i = 0; i < RPW; ++i) {
+            const long row = min(row0 + (long)i * nw, p.rows - 1);      // clamped duplicate rows are not stored
+            mean[i] = p.mean[row];
+            rstd[i] = p.rstd[row];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int col = min(c * 256 + lane * 4, p.D - 4);
+                if (c < nchunk) {
+                    X[i][c] = *reinterpret_cast<const float4*>(p.x + row * p.ldx + col);
+                    DY[i][c] = *reinterpret_cast<const float4*>(p.dy + row * p.lddy + col);
+                    R[i][c] = p.dres ? *reinterpret_cast<const float4*>(p.dres + row * p.lddres + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
         }
-        s1 = wave_sum(s1) / p.D;
-        s2 = wave_sum(s2) / p.D;
+        // phase 2: per-row reductions and stores
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int col = c * 256 + lane * 4;
-            if (col < p.D) {
-                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.dres) r = *reinterpret_cast<const float4*>(p.dres + row * p.lddres + col);
-                float d[4] = {rstd * (g[c].x - s1 - xh[c].x * s2) + r.x, rstd * (g[c].y - s1 - xh[c].y * s2) + r.y,
-                              rstd * (g[c].z - s1 - xh[c].z * s2) + r.z, rstd * (g[c].w - s1 - xh[c].w * s2) + r.w};
-                if (p.dx) *reinterpret_cast<float4*>(p.dx + row * p.lddx + col) = make_float4(d[0], d[1], d[2], d[3]);
-                if (p.dx_bf) {
-                    union { uint2 u; bf16_t h[4]; } o;
+        for (int i = 0; i < RPW; ++i) {
+            const long row = row0 + (long)i * nw;
+            const bool live = row < p.rows;
+            float4 xh[MAXC], g[MAXC];
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o.h[i] = f2bf(d[i]);
-                    *reinterpret_cast<uint2*>(p.dx_bf + row * p.lddxbf + col) = o.u;
+            for (int c = 0; c < MAXC; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (c < nchunk && col < p.D) {
+                    const float4 w = *reinterpret_cast<const float4*>(p.gamma + col);
+                    const float4 x = X[i][c], dy = DY[i][c];
+                    xh[c] = make_float4((x.x - mean[i]) * rstd[i], (x.y - mean[i]) * rstd[i], (x.z - mean[i]) * rstd[i], (x.w - mean[i]) * rstd[i]);
+                    g[c] = make_float4(dy.x * w.x, dy.y * w.y, dy.z * w.z, dy.w * w.w);
+                    s1 += g[c].x + g[c].y + g[c].z + g[c].w;
+                    s2 += g[c].x * xh[c].x + g[c].y * xh[c].y + g[c].z * xh[c].z + g[c].w * xh[c].w;
+                    if (live) {
+                        dg[c].x += dy.x * xh[c].x; dg[c].y += dy.y * xh[c].y; dg[c].z += dy.z * xh[c].z; dg[c].w += dy.w * xh[c].w;
+                        db[c].x += dy.x; db[c].y += dy.y; db[c].z += dy.z; db[c].w += dy.w;
+                    }
+                }
+            }
+            s1 = wave_sum(s1) / p.D;
+            s2 = wave_sum(s2) / p.D;
+            if (!live) continue;                          // wave-uniform
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) {
+                const int col = c * 256 + lane * 4;
+                if (c < nchunk && col < p.D) {
+                    const float4 r = R[i][c];
+                    float d[4] = {rstd[i] * (g[c].x - s1 - xh[c].x * s2) + r.x, rstd[i] * (g[c].y - s1 - xh[c].y * s2) + r.y,
+                                  rstd[i] * (g[c].z - s1 - xh[c].z * s2) + r.z, rstd[i] * (g[c].w - s1 - xh[c].w * s2) + r.w};
+                    if (p.dx) *reinterpret_cast<float4*>(p.dx + row * p.lddx + col) = make_float4(d[0], d[1], d[2], d[3]);
+                    if (p.dx_bf) {
+                        union { uint2 u; bf16_t h[4]; } o;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) o.h[k] = f2bf(d[k]);
+                        *reinterpret_cast<uint2*>(p.dx_bf + row * p.lddxbf + col) = o.u;
+                    }
                 }
             }
         }
@@ -136,8 +167,8 @@ int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
 int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
     if (a.rows <= 0) return 0;
-    long blocks = (a.rows + 15) / 16;
-    if (blocks > 2048) blocks = 2048;
+    long blocks = (a.rows + 4 * RPW - 1) / (4 * RPW);
+    if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 2 * 4 * a.D * sizeof(float), s, a);
     S3D_CHECK_LAUNCH("ln_bwd");

@@ -312,7 +312,7 @@ int s3d_launch_fold(const FoldArgs& a, hipStream_t s) {
 }
 
 int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
-    long gs = (a.groups + 63) / 64;        // group slices per token
+    long gs = (a.groups + 3) / 4;          // group slices per token: a thread sums <= 4 rows serially (latency-bound otherwise)
     if (gs > 64) gs = 64;
     if (gs < 1) gs = 1;
     const long gchunk = (a.groups + gs - 1) / gs;
