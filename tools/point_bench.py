@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Throughput of the point-cloud training step (forward + CE + backward + SGD) on one MI355X.
+   python tools/point_bench.py cfg4|cfg5 [steps]     cfg4: cls 1024 pts x 6, B=128; cfg5: seg 2048 pts x 22, B=32"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simple3d_former_amd.point_engine import PointEngine  # noqa: E402
+from oracle import point_oracle as po  # noqa: E402  (synthetic-input recipe only)
+
+CFG = {'cfg4': dict(task='cls', n_points=1024, d_points=6, n_classes=40, batch=128),
+       'cfg5': dict(task='seg', n_points=2048, d_points=22, n_classes=50, batch=32)}
+
+
+def main():
+    name = sys.argv[1] if len(sys.argv) > 1 else 'cfg4'
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    c = CFG[name]
+    B = int(os.environ.get('BATCH', c['batch']))
+    eng = PointEngine(backbone='deit_tiny_patch16_224', n_points=c['n_points'], d_points=c['d_points'], n_classes=c['n_classes'],
+                      task=c['task'], device='cuda')
+    eng.load_state_dict(po.init_state_dict(backbone='deit_tiny_patch16_224', n_classes=c['n_classes'], d_points=c['d_points'], seed=9))
+    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9)
+    x, y, starts = x.cuda(), y.cuda(), tuple(s.cuda() for s in starts)
+    for _ in range(3):
+        loss = eng.train_step(x, y, starts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = eng.train_step(x, y, starts)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = dict(config=name, batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
+               points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='eager')
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()
