@@ -52,6 +52,10 @@ typedef struct S3dGemmArgs {
     float alpha;
     const float* cls; const float* pos; int ntok;
     float* bias_grad;
+    /* optional dropout on the epilogue value (RESID: on acc+bias before the residual add; RELU: on the activation; DRELU: on
+     * the gradient): keep(m*N + n) = hash(*drop_seed, drop_site, index) >= drop_thr, kept values scaled by drop_scale.
+     * drop_thr = 0 disables it.  The seed lives in device memory so that HIP-graph replays see a fresh value. */
+    const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
 } S3dGemmArgs;
 /* ta / tb: operand stored k-major.  (0,0) forward "x @ W^T"; (0,1) dgrad "dy @ W"; (1,1) wgrad "dy^T @ x" (split-K,
  * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
@@ -82,6 +86,8 @@ typedef struct S3dLnBwdArgs {
     uint16_t* dx_bf; long lddxbf;
     float* dgamma; float* dbeta;
     long rows; int D;
+    /* optional dropout mask applied to the bf16 copy only (the branch gradient of a post-norm residual), see S3dGemmArgs */
+    const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
 } S3dLnBwdArgs;
 int s3d_layernorm_fwd(const S3dLnArgs* args, s3d_stream_t stream);
 int s3d_layernorm_bwd(const S3dLnBwdArgs* args, s3d_stream_t stream);
@@ -99,6 +105,8 @@ typedef struct S3dAttnArgs {
     const uint16_t* dout; long lddo;
     uint16_t* dqkv; long lddq;
     float* delta;
+    /* optional dropout on the attention weights, index ((b*H + h)*N + q)*N + key, see S3dGemmArgs */
+    const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
 } S3dAttnArgs;
 int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
 int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);
@@ -209,11 +217,15 @@ int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, con
  * (models/vit_3d_2d_pretrain.py:381, :479): default batch_first=False and post-norm, so for the (G, Nb, D) input
  * (G = B*P*P groups, Nb = P+1 tokens per group) self-attention runs over the G axis for each of the Nb positions, i.e.
  * ACROSS the samples of the batch; ReLU feed-forward D -> Dff -> D; LayerNorm eps 1e-5.  Rows are r = g*Nb + t.
- * Dropout (p = 0.1, four sites) is the identity here: eval-mode semantics. */
+ * Dropout (p = 0.1, four sites: attention weights, after out_proj, after the ReLU, after linear2) uses a counter-based
+ * hash mask keep = splitmix64(index, seed, site) >= p*2^32 (torch's RNG stream cannot be reproduced); dropout_p = 0 gives
+ * the eval-mode layer. */
 typedef struct S3dEncShape {
     int G, Nb, D, H, Dff;
     float eps;
     int split;
+    float dropout_p;                       /* 0 = eval mode; 0.1 = the reference's training mode */
+    const unsigned long long* seed;        /* device-resident seed (bump it once per step), required when dropout_p > 0 */
 } S3dEncShape;
 typedef struct S3dEncParams {
     const float *in_b, *out_b, *l1_b, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;

@@ -124,7 +124,25 @@ def run_blocks(x, sd, depth, num_heads, bf16=False):
 
 
 # ----------------------------------------------------------------------------- group_embed
-def group_encoder_layer(x, sd, dropout_p=0.0, training=False, generator=None):
+def hash_keep_mask(shape, seed, site, p):
+    """Counter-based dropout mask shared with the HIP kernels (common.h: drop_key / drop_keep): element i (row-major
+    linear index) is kept iff splitmix64(i, key(seed, site)) >> 32 >= floor(p * 2^32)."""
+    import numpy as np
+    n = 1
+    for d in shape:
+        n *= int(d)
+    thr = int(p * 4294967296.0)
+    with np.errstate(over='ignore'):
+        key = np.uint64((seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & _MASK64)
+        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + key
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    keep = (z >> np.uint64(32)) >= np.uint64(thr)
+    return torch.from_numpy(keep.reshape(tuple(shape)))
+
+
+def group_encoder_layer(x, sd, dropout_p=0.0, training=False, generator=None, hash_seed=None):
     """Seq-first post-norm encoder layer: x is (L, Nb, D); self-attention runs over axis 0.
     In the reference L = B*P*P and Nb = P+1 (vit_3d_2d_pretrain.py:474-479), i.e. attention
     mixes tokens ACROSS the samples of the batch.  dropout_p>0 with training=True applies the
@@ -133,9 +151,14 @@ def group_encoder_layer(x, sd, dropout_p=0.0, training=False, generator=None):
     L, Nb, D = x.shape
     H, hd = GROUP_HEADS, D // GROUP_HEADS
 
-    def drop(t):
+    def drop(t, site):
+        """site: 0 attention weights (Nb,H,L,L), 1 after out_proj, 2 after the ReLU, 3 after linear2 (all (L,Nb,*));
+        hash_seed selects the counter-based mask shared with the HIP path, otherwise torch's generator is used."""
         if training and dropout_p > 0:
-            keep = torch.rand(t.shape, generator=generator) >= dropout_p
+            if hash_seed is not None:
+                keep = hash_keep_mask(t.shape, hash_seed, site, dropout_p)
+            else:
+                keep = torch.rand(t.shape, generator=generator) >= dropout_p
             return t * keep / (1 - dropout_p)
         return t
 
@@ -145,13 +168,13 @@ def group_encoder_layer(x, sd, dropout_p=0.0, training=False, generator=None):
     q = q.reshape(L, Nb, H, hd).permute(1, 2, 0, 3) * hd ** -0.5
     k = k.reshape(L, Nb, H, hd).permute(1, 2, 0, 3)
     v = v.reshape(L, Nb, H, hd).permute(1, 2, 0, 3)
-    p = drop((q @ k.transpose(-2, -1)).softmax(dim=-1))
+    p = drop((q @ k.transpose(-2, -1)).softmax(dim=-1).contiguous(), 0)
     a = (p @ v).permute(2, 0, 1, 3).reshape(L, Nb, D)
     a = a @ sd[g + 'self_attn.out_proj.weight'].t() + sd[g + 'self_attn.out_proj.bias']
-    x = F.layer_norm(x + drop(a), (D,), sd[g + 'norm1.weight'], sd[g + 'norm1.bias'], GROUP_LN_EPS)
-    f = drop(F.relu(x @ sd[g + 'linear1.weight'].t() + sd[g + 'linear1.bias']))
+    x = F.layer_norm(x + drop(a, 1), (D,), sd[g + 'norm1.weight'], sd[g + 'norm1.bias'], GROUP_LN_EPS)
+    f = drop(F.relu(x @ sd[g + 'linear1.weight'].t() + sd[g + 'linear1.bias']), 2)
     f = f @ sd[g + 'linear2.weight'].t() + sd[g + 'linear2.bias']
-    return F.layer_norm(x + drop(f), (D,), sd[g + 'norm2.weight'], sd[g + 'norm2.bias'], GROUP_LN_EPS)
+    return F.layer_norm(x + drop(f, 3), (D,), sd[g + 'norm2.weight'], sd[g + 'norm2.bias'], GROUP_LN_EPS)
 
 
 # ----------------------------------------------------------------------------- heads
@@ -169,7 +192,7 @@ def voxel_head(feat, sd):
 
 # ----------------------------------------------------------------------------- model
 def forward_features(sd, x, *, backbone, embed_layer, cell, patch, pos_embedding='default',
-                     bf16=False, training=False, dropout_p=0.1, generator=None):
+                     bf16=False, training=False, dropout_p=0.1, generator=None, hash_seed=None):
     cfg = BACKBONES[backbone]
     D, depth, H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
     w, b = sd['voxel_embed.proj.conv3d_1.weight'] if embed_layer != 'VoxelNaiveProjection' else \
@@ -197,7 +220,7 @@ def forward_features(sd, x, *, backbone, embed_layer, cell, patch, pos_embedding
         t = t.permute(0, 2, 3, 4, 1).reshape(Bsz * P * P, P, D)            # '(b px py) pz c'
         t = torch.cat((sd['group_cls_token'].expand(t.shape[0], -1, -1), t), dim=1)
         t = t + sd['group_pos_embed']
-        t = group_encoder_layer(t, sd, dropout_p, training, generator)
+        t = group_encoder_layer(t, sd, dropout_p, training, generator, hash_seed)
         t = run_blocks(t, sd, depth, H, bf16)[:, 0]                        # pass 1
         t = t.reshape(Bsz, P * P, D)
         t = torch.cat((sd['cls_token'].expand(Bsz, -1, -1), t), dim=1) + sd['voxel_pos_embed']

@@ -135,6 +135,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         lsum += __shfl_xor(lsum, 32, 64);
         l_i = l_i * alpha + lsum;
         m_i = mnew;
+        if (p.drop_thr) {                                         // dropout on the attention weights (normaliser undropped)
+            const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
+            const unsigned long long rowbase = ((unsigned long long)bh * p.N + min(qrow, p.N - 1)) * p.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sv[r] = drop_keep(key, rowbase + (k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
+        }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -262,7 +269,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 const int r = 8 * s2 + j;
                 const bool ok = (k0 + acc_row(r, h2)) < p.N;
                 const float pr = ok ? expf(sacc[r] * p.scale - lse_q) : 0.f;
-                dsf[s2].h[j] = f2bf(pr * (dpacc[r] - delta) * p.scale);
+                float dpn = dpacc[r];
+                if (p.drop_thr)
+                    dpn = drop_keep(drop_key(p.drop_seed, p.drop_site),
+                                    ((unsigned long long)bh * p.N + qrow_c) * p.N + (k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
             }
         __syncthreads();
 #pragma unroll
@@ -359,8 +370,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 const float lse_r = p.lse[(long)bh * p.N + qc];
                 const float del_r = p.delta[(long)bh * p.N + qc];
                 const float pr = ok ? expf(sacc[r] * p.scale - lse_r) : 0.f;
-                pf[s2].h[j] = f2bf(pr);
-                dsf[s2].h[j] = f2bf(pr * (dpacc[r] - del_r) * p.scale);
+                float dm = 1.f;
+                if (p.drop_thr)
+                    dm = drop_keep(drop_key(p.drop_seed, p.drop_site), ((unsigned long long)bh * p.N + qc) * p.N + krow_c, p.drop_thr)
+                             ? p.drop_scale : 0.f;
+                pf[s2].h[j] = f2bf(pr * dm);
+                dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - del_r) * p.scale);
             }
         __syncthreads();
 #pragma unroll

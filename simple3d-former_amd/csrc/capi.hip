@@ -132,10 +132,24 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
 }
 
 // ---- seq-first post-norm encoder layer (group_embed) ----
+// dropout sites of nn.TransformerEncoderLayer: 0 attention weights, 1 after out_proj, 2 after the ReLU, 3 after linear2
+struct DropCfg { const unsigned long long* seed; unsigned thr; float scale; };
+DropCfg drop_cfg(const S3dEncShape& sh) {
+    DropCfg d{sh.seed, 0u, 1.f};
+    if (sh.dropout_p > 0.f) {
+        d.thr = (unsigned)((double)sh.dropout_p * 4294967296.0);
+        d.scale = 1.0f / (1.0f - sh.dropout_p);
+    }
+    return d;
+}
+#define SET_DROP(obj, site) do { (obj).drop_seed = dc.seed; (obj).drop_site = (site); (obj).drop_thr = dc.thr; (obj).drop_scale = dc.scale; } while (0)
+
 int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, hipStream_t s) {
     const long M = (long)sh.G * sh.Nb;
     const int D = sh.D, F = sh.Dff;
     const bool split = sh.split != 0;
+    const DropCfg dc = drop_cfg(sh);
+    S3D_REQUIRE(dc.thr == 0 || dc.seed != nullptr, "encoder layer: dropout needs a device-resident seed");
     S3D_REQUIRE(M < (1L << 31), "encoder layer: too many rows");
     S3D_TRY(s3d_launch_split(a.x_in, a.xin_hi, split ? a.xin_lo : nullptr, M, D, D, s));
     GemmArgs g = gemm_zero();                       // qkv = x @ Win^T + b
@@ -147,10 +161,12 @@ int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, h
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = split ? a.att_lo : nullptr;
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    SET_DROP(at, 0);
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
-    g = gemm_zero();                                // s1 = x + att @ Wo^T + bo
+    g = gemm_zero();                                // s1 = x + drop(att @ Wo^T + bo)
     g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.out_w_hi; g.B_lo = p.out_w_lo; g.ldb = D;
     g.M = (int)M; g.N = D; g.K = D; g.bias = p.out_b; g.R = a.x_in; g.ldr = D; g.C = a.s1; g.ldc = D;
+    SET_DROP(g, 1);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
     LnArgs ln;                                      // x1 = LN1(s1)
     memset(&ln, 0, sizeof(ln));
@@ -160,10 +176,12 @@ int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, h
     g = gemm_zero();                                // f = relu(x1 @ W1^T + b1)
     g.A_hi = a.x1_hi; g.A_lo = a.x1_lo; g.lda = D; g.B_hi = p.l1_w_hi; g.B_lo = p.l1_w_lo; g.ldb = D;
     g.M = (int)M; g.N = F; g.K = D; g.bias = p.l1_b; g.aux = a.fpre; g.ldaux = F; g.O_hi = a.f_hi; g.O_lo = split ? a.f_lo : nullptr; g.ldo = F;
+    SET_DROP(g, 2);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RELU, g, 1, s));
-    g = gemm_zero();                                // s2 = x1 + f @ W2^T + b2
+    g = gemm_zero();                                // s2 = x1 + drop(f @ W2^T + b2)
     g.A_hi = a.f_hi; g.A_lo = a.f_lo; g.lda = F; g.B_hi = p.l2_w_hi; g.B_lo = p.l2_w_lo; g.ldb = F;
     g.M = (int)M; g.N = D; g.K = F; g.bias = p.l2_b; g.R = a.x1; g.ldr = D; g.C = a.s2; g.ldc = D;
+    SET_DROP(g, 3);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
     ln.x = a.s2; ln.gamma = p.n2_w; ln.beta = p.n2_b; ln.out_hi = nullptr; ln.out_lo = nullptr; ln.out_f32 = a.x_out;
     ln.mean = a.mean2; ln.rstd = a.rstd2;           // x_out = LN2(s2)
@@ -175,8 +193,10 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
             const S3dBlockScratch& w, hipStream_t s) {
     const long M = (long)sh.G * sh.Nb;
     const int D = sh.D, F = sh.Dff;
-    LnBwdArgs lb;                                   // ds2 = LN2'(dx_out)            -> dx_b (+bf16)
+    const DropCfg dc = drop_cfg(sh);
+    LnBwdArgs lb;                                   // ds2 = LN2'(dx_out)            -> dx_b (+bf16, masked by site 3)
     memset(&lb, 0, sizeof(lb));
+    SET_DROP(lb, 3);
     lb.dy = w.dx_a; lb.lddy = D; lb.x = a.s2; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.n2_w;
     lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D; lb.dgamma = gr.n2_w; lb.dbeta = gr.n2_b; lb.rows = M; lb.D = D;
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
@@ -184,6 +204,7 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
     GemmArgs g = gemm_zero();                       // df = (ds2 @ W2) * relu'(fpre)   -> dh
     g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.l2_w_hi; g.ldb = F; g.M = (int)M; g.N = F; g.K = D;
     g.aux = a.fpre; g.ldaux = F; g.O_hi = w.dh; g.ldo = F;
+    SET_DROP(g, 2);
     S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DRELU, g, 1, s));
     S3D_TRY(wgrad(w.dh, F, a.x1_hi, D, M, gr.l1_w, gr.l1_b, s));
     g = gemm_zero();                                // g1 = df @ W1 + ds2              -> dxn
@@ -191,7 +212,8 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
     g.C = w.dxn; g.ldc = D;
     S3D_TRY(s3d_launch_gemm(false, true, false, EPI_RESID, g, 1, s));
     lb.dy = w.dxn; lb.x = a.s1; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.n1_w; lb.dx = w.dx_a; lb.dx_bf = w.dx_a_bf;
-    lb.dgamma = gr.n1_w; lb.dbeta = gr.n1_b;        // ds1 = LN1'(g1)                  -> dx_a (+bf16)
+    lb.dgamma = gr.n1_w; lb.dbeta = gr.n1_b;        // ds1 = LN1'(g1)                  -> dx_a (+bf16, masked by site 1)
+    SET_DROP(lb, 1);
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
     S3D_TRY(wgrad(w.dx_a_bf, D, a.att_hi, D, M, gr.out_w, gr.out_b, s));
     g = gemm_zero();                                // datt = ds1 @ Wo
@@ -203,6 +225,7 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+    SET_DROP(at, 0);
     S3D_TRY(s3d_launch_attention_bwd(at, s));
     S3D_TRY(wgrad(w.dqkv, 3 * D, a.xin_hi, D, M, gr.in_w, gr.in_b, s));
     g = gemm_zero();                                // dx = dqkv @ Win + ds1           -> dx_b (+bf16 copy)

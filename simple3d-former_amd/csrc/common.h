@@ -64,6 +64,18 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// counter-based dropout mask (splitmix64 of the element index; the oracle evaluates the same function)
+__device__ __forceinline__ unsigned long long drop_key(const unsigned long long* seed, int site) {
+    return (*seed) * 0x9E3779B97F4A7C15ull + (unsigned long long)site * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
+}
+__device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long long idx, unsigned thr) {
+    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + key;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (unsigned)(z >> 32) >= thr;
+}
+
 // fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 

@@ -314,6 +314,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                 }
             }
             union { u32x2 u; bf16_t h[4]; } hi, lo, ax;
+            float dm[4] = {1.f, 1.f, 1.f, 1.f};                 // dropout multipliers (RESID / RELU / DRELU only)
+            if constexpr (EPI == EPI_RESID || EPI == EPI_RELU || EPI == EPI_DRELU) {
+                if (p.drop_thr) {
+                    const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        dm[r] = drop_keep(key, (unsigned long long)m * p.N + n + r, p.drop_thr) ? p.drop_scale : 0.f;
+                }
+            }
             if constexpr (EPI == EPI_BF16_BIAS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) split_bf16(v[r] * p.alpha + bq[r], hi.h[r], lo.h[r]);
@@ -324,14 +333,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                 for (int r = 0; r < 4; ++r) {
                     const float pre = v[r] + bq[r];
                     ax.h[r] = f2bf(pre);
-                    split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f), hi.h[r], lo.h[r]);
+                    split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f) * dm[r], hi.h[r], lo.h[r]);
                 }
                 if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (long)m * p.ldaux + n) = ax.u;
                 *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
                 if (p.O_lo) *reinterpret_cast<u32x2*>(p.O_lo + (long)m * p.ldo + n) = lo.u;
             } else if constexpr (EPI == EPI_RESID) {
                 const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + n);
-                f32x4 o = {v[0] + bq[0] + rr[0], v[1] + bq[1] + rr[1], v[2] + bq[2] + rr[2], v[3] + bq[3] + rr[3]};
+                f32x4 o = {(v[0] + bq[0]) * dm[0] + rr[0], (v[1] + bq[1]) * dm[1] + rr[1], (v[2] + bq[2]) * dm[2] + rr[2],
+                           (v[3] + bq[3]) * dm[3] + rr[3]};
                 *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
                 if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
 #pragma unroll
@@ -354,7 +364,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float pre = bf2f(ax.h[r]);
-                    hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] : 0.f));
+                    hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
                 }
                 *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
             }

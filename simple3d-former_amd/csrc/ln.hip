@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
                     if (p.dx) *reinterpret_cast<float4*>(p.dx + row * p.lddx + col) = make_float4(d[0], d[1], d[2], d[3]);
                     if (p.dx_bf) {
                         union { uint2 u; bf16_t h[4]; } o;
+                        if (p.drop_thr) {                  // masked branch gradient of a post-norm residual
+                            const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                d[k] = drop_keep(key, (unsigned long long)row * p.D + col + k, p.drop_thr) ? d[k] * p.drop_scale : 0.f;
+                        }
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o.h[k] = f2bf(d[k]);
                         *reinterpret_cast<uint2*>(p.dx_bf + row * p.lddxbf + col) = o.u;

@@ -220,6 +220,9 @@ class VoxelEngine:
         self._ws = {}
         self._graphs = {}
         self.world_size = 1
+        # group_embed encoder-layer dropout: 0 = eval mode; set_dropout(0.1) = the reference's training mode (hash-based masks)
+        self.dropout_p = 0.0
+        self.dropout_seed = torch.zeros(1, dtype=torch.int64, device=self.device)
 
     # ------------------------------------------------------------------ parameters
     def _build_param_tables(self):
@@ -284,6 +287,16 @@ class VoxelEngine:
         st[7] = cur_step
         self.adam_state.copy_(torch.from_numpy(st))
 
+    def set_dropout(self, p, seed=None):
+        """Dropout of nn.TransformerEncoderLayer inside group_embed (vit_3d_2d_pretrain.py:381; p = 0.1 when model.train()).
+        The seed lives on the device and is advanced once per train_step."""
+        self.dropout_p = float(p)
+        if seed is not None:
+            self.dropout_seed.fill_(int(seed))
+        for ws in self._ws.values():
+            if self.group:
+                ws.enc.shape.dropout_p = self.dropout_p
+
     def set_lr(self, lr):
         self.adam_state[0:1].copy_(torch.tensor([lr], dtype=torch.float32).view(torch.int32))
 
@@ -317,7 +330,8 @@ class VoxelEngine:
                             rstd1=e.stats[1], mean2=e.stats[2], rstd2=e.stats[3], lse=e.lse, xin_hi=e.xin[0], xin_lo=e.xin[1],
                             qkv_hi=e.qkv[0], qkv_lo=e.qkv[1], att_hi=e.att[0], att_lo=e.att[1], x1_hi=e.x1p[0], x1_lo=e.x1p[1],
                             fpre=e.fpre, f_hi=e.f[0], f_lo=e.f[1])
-            e.shape = L.S3dEncShape(G=G, Nb=self.ntok, D=D, H=self.enc_heads, Dff=D, eps=1e-5, split=1 if self.split else 0)
+            e.shape = L.S3dEncShape(G=G, Nb=self.ntok, D=D, H=self.enc_heads, Dff=D, eps=1e-5, split=1 if self.split else 0,
+                                    dropout_p=self.dropout_p, seed=self.dropout_seed.data_ptr())
             ws.enc = e
             ws.gstats = torch.empty(2, G, **f32)              # final-norm statistics of the pass-1 cls rows
             ws.gfeat = torch.empty(G, D, **f32)               # norm(x)[:, 0] of pass 1  -> tokens of pass 2
@@ -521,6 +535,8 @@ class VoxelEngine:
         """zero_grad -> model(voxel) -> F.cross_entropy -> backward -> Adam  (train_cls_voxel.py:277-288), all on the
         HIP path.  Gradients are zeroed by the previous step's Adam kernel.  Returns the loss as a device scalar."""
         B = x.shape[0]
+        if self.group and self.dropout_p > 0:
+            self.dropout_seed.add_(1)                     # fresh masks every step (device-side, graph-replay safe)
         self.forward(x)
         loss = self.cross_entropy(B, target, weight)
         self.backward(B)

@@ -198,3 +198,36 @@ def test_dp_trainer_segmented_graphs_and_rccl_path():
         assert float(d) <= 6.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
         dist.destroy_process_group()
+
+
+def test_group_embed_training_mode_dropout_matches_oracle():
+    """model.train() semantics of group_embed: dropout(0.1) at the four sites of nn.TransformerEncoderLayer, with the
+    counter-based mask shared by the HIP kernels and the oracle (torch's RNG stream itself cannot be reproduced)."""
+    cfg = dict(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=12, cell=4, patch=3, n_classes=10,
+               pos_embedding='group_embed', head='default', batch=3)
+    sd = vo.init_state_dict(seed=5, exercise_all=True, portable=True, **{k: cfg[k] for k in MODEL_KEYS})
+    x, y = vo.synthetic_batch(3, 12, 10, seed=6, portable=True)
+    eng = make_engine(cfg, sd)
+    eng.set_dropout(0.1, seed=1234)
+    logits = eng.forward(x.to(DEV)).cpu()
+    kw = dict(fwd_kwargs(cfg), training=True, dropout_p=0.1, hash_seed=1234)
+    logits_ref, loss_ref, grads_ref = vo.loss_and_grads(sd, x, y, **kw)
+    with torch.no_grad():
+        logits_eval = vo.forward(sd, x, **fwd_kwargs(cfg))
+    assert float((logits_ref - logits_eval).abs().max()) > 1e-2           # the masks really change the output
+    assert float((logits - logits_ref).abs().max()) <= LOGIT_TOL
+    loss = float(eng.cross_entropy(3, y.to(DEV)))
+    assert abs(loss - float(loss_ref)) <= LOGIT_TOL
+    eng.zero_grad(); eng.backward(3)
+    for k, g in grads_ref.items():
+        got = eng.arena.grad(k).cpu().double()
+        ref = g.double()
+        rms = float(ref.pow(2).mean().sqrt())
+        err = float((got - ref).pow(2).mean().sqrt())
+        assert err <= 3e-2 * rms + 1e-7, f'{k}: grad rms err {err:.3e} vs rms {rms:.3e}'
+    # a different seed gives different masks; seed advance per fused step
+    eng.set_dropout(0.1, seed=99)
+    assert float((eng.forward(x.to(DEV)).cpu() - logits).abs().max()) > 1e-3
+    s0 = int(eng.dropout_seed)
+    eng.train_step(x.to(DEV), y.to(DEV))
+    assert int(eng.dropout_seed) == s0 + 1
