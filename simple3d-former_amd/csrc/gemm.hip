@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include <array>
+#include <type_traits>
 #include <map>
 #include <vector>
 
@@ -186,7 +187,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
 
     // every k-tile full (kend - kbeg a multiple of 64): loads need no k-bound select (block-uniform fast path)
     const bool kfull = ((kend - kbeg) & 63) == 0;
-#define GLOAD_(KF, SET, T)                                                                \
+#define GLOAD(KF, SET, T)                                                                 \
     do {                                                                                  \
         const int k0__ = kbeg + (T) * 64;                                                 \
         SA::template load<KF>(va_hi[SET], p.A_hi, p.lda, m0, k0__, p.M, kend, tid);       \
@@ -195,10 +196,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
             SA::template load<KF>(va_lo[SET], p.A_lo, p.lda, m0, k0__, p.M, kend, tid);   \
             SB::template load<KF>(vb_lo[SET], p.B_lo, p.ldb, n0, k0__, p.N, kend, tid);   \
         }                                                                                 \
-    } while (0)
-#define GLOAD(SET, T)                                                                     \
-    do {                                                                                  \
-        if (kfull) GLOAD_(true, SET, T); else GLOAD_(false, SET, T);                      \
     } while (0)
 #define LSTORE(SET, BUF)                                                                  \
     do {                                                                                  \
@@ -219,63 +216,79 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
             }                                                                             \
         }                                                                                 \
     } while (0)
+#define COMPUTE(T)                                                                                                   \
+    do {                                                                                                             \
+        const unsigned char* s = smem + ((T) & 1) * STAGE;                                                           \
+        const unsigned char* sA = s;                                                                                 \
+        const unsigned char* sB = s + NPL * A_BYTES;                                                                 \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
+            const int kc = ks * 4 + (lane >> 4);                                                                     \
+            bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];                                   \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                                         \
+                const int r = wm * (BM / 2) + i * 16 + (lane & 15);                                                  \
+                a_hi[i] = read_frag(sA, r, kc);                                                                      \
+                if constexpr (SPLIT) a_lo[i] = read_frag(sA + A_BYTES, r, kc);                                       \
+            }                                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                         \
+                const int r = wn * (BN / 2) + j * 16 + (lane & 15);                                                  \
+                b_hi[j] = read_frag(sB, r, kc);                                                                      \
+                if constexpr (SPLIT) b_lo[j] = read_frag(sB + B_BYTES, r, kc);                                       \
+            }                                                                                                        \
+            _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                           \
+                _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                     \
+                    if constexpr (EPI == EPI_ATOMIC) { /* natural order: lanes 0-15 = consecutive n */               \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);   \
+                    } else { /* swapped order: 4 consecutive n per lane */                                           \
+                        if constexpr (SPLIT) {                                                                       \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0); \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0); \
+                        }                                                                                            \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);   \
+                    }                                                                                                \
+                }                                                                                                    \
+        }                                                                                                            \
+    } while (0)
 
-    // prologue: tiles 0 .. PD-1 in flight, tile 0 staged into LDS buffer 0
+    // The mainloop is instantiated for KF = true / false OUTSIDE the loop and its steady state is branch-free: hipcc's
+    // s_waitcnt insertion only keeps the younger prefetches in flight (vmcnt(N > 0) at the LDS-store point) when it can
+    // count loads on straight-line code; with the prefetch guards inside the loop it drained to vmcnt(0) every iteration,
+    // i.e. it exposed a full memory latency per k-tile.
+    auto mainloop = [&](auto kf_tag) {
+        constexpr bool KF = decltype(kf_tag)::value;
+        // prologue: tiles 0 .. PD-1 in flight, tile 0 staged into LDS buffer 0
 #pragma unroll
-    for (int u = 0; u < PD; ++u)
-        if (u < ntiles) GLOAD(u, u);
-    if (ntiles > 0) LSTORE(0, 0);
-    __syncthreads();
-
-    for (int t0 = 0; t0 < ntiles; t0 += PD) {
+        for (int u = 0; u < PD; ++u)
+            if (u < ntiles) GLOAD(KF, u, u);
+        if (ntiles > 0) LSTORE(0, 0);
+        __syncthreads();
+        int t = 0;
+        // steady state: tiles t .. t+PD-1, all of which have a tile t+u+PD to prefetch and a tile t+u+1 to stage
+        for (; t + 2 * PD - 1 < ntiles; t += PD) {
 #pragma unroll
-        for (int u = 0; u < PD; ++u) {
-            const int t = t0 + u;
-            if (t < ntiles) {                                  // block-uniform
-                // register set u held tile t (already staged) -> refill it with tile t+PD
-                if (t + PD < ntiles) GLOAD(u, t + PD);
-                const unsigned char* s = smem + (t & 1) * STAGE;
-                const unsigned char* sA = s;
-                const unsigned char* sB = s + NPL * A_BYTES;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int kc = ks * 4 + (lane >> 4);
-                    bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
-#pragma unroll
-                    for (int i = 0; i < FM; ++i) {
-                        const int r = wm * (BM / 2) + i * 16 + (lane & 15);
-                        a_hi[i] = read_frag(sA, r, kc);
-                        if constexpr (SPLIT) a_lo[i] = read_frag(sA + A_BYTES, r, kc);
-                    }
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        const int r = wn * (BN / 2) + j * 16 + (lane & 15);
-                        b_hi[j] = read_frag(sB, r, kc);
-                        if constexpr (SPLIT) b_lo[j] = read_frag(sB + B_BYTES, r, kc);
-                    }
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int j = 0; j < FN; ++j) {
-                            if constexpr (EPI == EPI_ATOMIC) {     // natural order: lanes 0-15 = consecutive n
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-                            } else {                               // swapped order: 4 consecutive n per lane
-                                if constexpr (SPLIT) {
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0);
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0);
-                                }
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
-                            }
-                        }
-                }
-                // stage tile t+1 (register set (u+1)%PD) into the other LDS buffer
-                if (t + 1 < ntiles) LSTORE((u + 1) % PD, (t + 1) & 1);
+            for (int u = 0; u < PD; ++u) {
+                GLOAD(KF, u, t + u + PD);            // register set u held tile t+u (already staged) -> refill
+                COMPUTE(t + u);
+                LSTORE((u + 1) % PD, (t + u + 1) & 1);
                 __syncthreads();
             }
         }
-    }
+        // drain: the last (< 2*PD) tiles
+        for (; t < ntiles; t += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int tt = t + u;
+                if (tt < ntiles) {                   // block-uniform
+                    if (tt + PD < ntiles) GLOAD(KF, u, tt + PD);
+                    COMPUTE(tt);
+                    if (tt + 1 < ntiles) LSTORE((u + 1) % PD, (tt + 1) & 1);
+                    __syncthreads();
+                }
+            }
+        }
+    };
+    if (kfull) mainloop(std::true_type{}); else mainloop(std::false_type{});
+#undef COMPUTE
 #undef GLOAD
-#undef GLOAD_
 #undef LSTORE
 
     // ---------------------------------------------------------------- epilogue
