@@ -488,6 +488,7 @@ int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
     switch (tile) {
         case 0: return launch_one<32, 64, TA, TB, SPLIT, EPI>(a, splitk, stream);
         case 1: return launch_one<64, 64, TA, TB, SPLIT, EPI>(a, splitk, stream);
+        case 3: return launch_one<32, 32, TA, TB, SPLIT, EPI>(a, splitk, stream);
         default: return launch_one<128, 128, TA, TB, SPLIT, EPI>(a, splitk, stream);
     }
 }
@@ -555,7 +556,7 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     const int tile_a = s3d_gemm_pick_tile(a.M, a.N, 1, false), tile_b = s3d_gemm_pick_tile(b.M, b.N, splitk, false);
     const bool ok = (a.K % 8 == 0) && (a.N % 8 == 0) && (b.M % 8 == 0) && (b.N % 8 == 0) && (a.lda % 8 == 0) && (a.ldb % 8 == 0) &&
                     (b.lda % 8 == 0) && (b.ldb % 8 == 0);
-    if (no_pair > 0 || tile_a == 2 || tile_b == 2 || !ok) {
+    if (no_pair > 0 || tile_a >= 2 || tile_b >= 2 || !ok) {
         if (int rc = s3d_launch_gemm(true, true, false, EPI_ATOMIC, b_in, 0, stream)) return rc;
         return s3d_launch_gemm(false, true, false, epi_a, a_in, 1, stream);
     }
