@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--plain-bf16', action='store_true', help='one-MFMA forward (fails the 1e-3 logit bar; for comparison only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--buckets', type=int, default=3)
+    ap.add_argument('--buckets', type=int, default=4)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
     args = ap.parse_args()
@@ -165,8 +165,11 @@ def main():
         'metric': conf['metric'], 'value': round(value, 1),
         'unit': 'voxels/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if args.plain_bf16 else 'bf16 (split-bf16 x3 MFMA forward, bf16 backward, fp32 accumulate/residual/Adam)',
-        'data': 'synthetic (seeded 10%-occupancy 32^3 grids, random-init weights of the reference architecture)',
+        'dtype': 'bf16',
+        'precision_note': ('plain bf16 forward (fails the 1e-3 logit bar; comparison only)' if args.plain_bf16 else
+                           'bf16 MFMA operands: split-bf16 (hi+lo, 3 MFMAs per product) forward, plain bf16 backward; fp32 '
+                           'accumulation, residual stream, LayerNorm/softmax/GELU, loss and Adam'),
+        'data': f'synthetic (seeded 10%-occupancy {CFG["voxel_size"]}^3 grids, random-init weights of the reference architecture)',
         'config': {'workload': conf['workload'], 'batch_per_gpu': BATCH_PER_GPU,
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
@@ -211,8 +214,9 @@ def main():
         out['cpu_baseline'] = cpu_baseline(x_cpu, y_cpu)
 
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        barrier()                     # rank 0 ran the instrumented pass; leave together
         dist.destroy_process_group()
 
 
