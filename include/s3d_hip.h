@@ -299,6 +299,21 @@ int s3d_add_inplace(float* a, const float* b, long n, s3d_stream_t stream);
 int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, float lr, float momentum,
                  float grad_scale, int* step_counter, s3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ evaluation + input format
+ *   s3d_cls_eval       pred = logits.max(1)[1]; counts[0] += correct, counts[1+c] += correct of class c, counts[1+C+c] += seen of
+ *                      class c (the accuracy / mean-class-accuracy bookkeeping of train_cls_voxel.py:315-329, train_cls.py:22-41)
+ *   s3d_partseg_eval   train_partseg.py:181-206: argmax restricted to the parts [first, first+count) of the shape's own category
+ *                      (category of target[b][0]; part_range[2*l] = first, part_range[2*l+1] = count for every part label l),
+ *                      per-shape mean part IoU (1.0 for a part that is neither present nor predicted), per-part seen / correct
+ *                      counts in counts[1+l] / counts[1+P+l], counts[0] = total correct points
+ *   s3d_unpack_voxels  1 bit per voxel (z fastest, LSB first, 32 voxels per word) -> fp32 grid: the device half of the
+ *                      .binvox reader (utils/binvox_rw.py:117-151 does the RLE decode on the host) */
+int s3d_cls_eval(const float* logits, int ld, const long long* target, long rows, int C, int* pred, long long* counts,
+                 s3d_stream_t stream);
+int s3d_partseg_eval(const float* logits, int ld, const long long* target, int B, int N, int num_part, const int* part_range,
+                     int* pred, double* shape_iou, int* shape_first, long long* counts, s3d_stream_t stream);
+int s3d_unpack_voxels(const unsigned int* bits, float* out, long nwords, s3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,4 +380,16 @@ int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, lon
     return s3d_launch_sgd(p, g, buf, hi, lo, n, lr, momentum, grad_scale, step_counter, st(s));
 }
 
+int s3d_cls_eval(const float* logits, int ld, const long long* target, long rows, int C, int* pred, long long* counts, s3d_stream_t s) {
+    return s3d_launch_cls_eval(logits, ld, target, rows, C, pred, counts, st(s));
+}
+int s3d_partseg_eval(const float* logits, int ld, const long long* target, int B, int N, int num_part, const int* part_range, int* pred,
+                     double* shape_iou, int* shape_first, long long* counts, s3d_stream_t s) {
+    S3D_REQUIRE(num_part > 0 && part_range != nullptr, "s3d_partseg_eval: part table required");
+    return s3d_launch_partseg_eval(logits, ld, target, B, N, num_part, part_range, pred, shape_iou, shape_first, counts, st(s));
+}
+int s3d_unpack_voxels(const unsigned int* bits, float* out, long nwords, s3d_stream_t s) {
+    return s3d_launch_unpack_bits(bits, out, nwords, st(s));
+}
+
 }  // extern "C"

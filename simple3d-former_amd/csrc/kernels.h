@@ -56,3 +56,9 @@ int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, 
 int s3d_launch_add_inplace(float* a, const float* b, long n, hipStream_t s);
 int s3d_launch_sgd(float* p, float* g, float* buf, bf16_t* hi, bf16_t* lo, long n, float lr, float momentum, float grad_scale,
                    int* step_counter, hipStream_t s);
+
+// ---- evaluation metrics + bit-packed voxel input (metrics.hip) ----
+int s3d_launch_cls_eval(const float* logits, int ld, const long long* target, long rows, int C, int* pred, long long* counts, hipStream_t s);
+int s3d_launch_partseg_eval(const float* logits, int ld, const long long* target, int B, int N, int num_part, const int* part_range,
+                            int* pred, double* shape_iou, int* shape_first, long long* counts, hipStream_t s);
+int s3d_launch_unpack_bits(const unsigned int* bits, float* out, long nwords, hipStream_t s);
