@@ -50,6 +50,14 @@ int s3d_gemm_prof_collect(double* rows, int cap) {
 
 namespace {
 
+// LDS stages per workgroup.  Split-bf16 tiles carry two planes per operand; with two stages a 32x64 tile needs 48 KB and
+// only three workgroups fit a CU.  -DS3D_SPLIT_SINGLE_BUF=1 trades the second stage for twice the resident workgroups
+// (measured: no change, 18.6 us either way for fc1 fwd -- the k-loop is LDS-throughput-bound, not occupancy-bound).
+#ifndef S3D_SPLIT_SINGLE_BUF
+#define S3D_SPLIT_SINGLE_BUF 0
+#endif
+constexpr int gemm_nbuf(int BM, int BN, bool split) { return (split && S3D_SPLIT_SINGLE_BUF && BM * BN <= 64 * 64) ? 1 : 2; }
+
 template <int BR, bool T>
 struct Stager {
     static constexpr int CH = BR / 8;                                   // 16-byte chunks along the row axis (T only)
@@ -145,6 +153,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                                           const int bz) {
     constexpr int PD = (BM * BN >= 128 * 128) ? 2 : 3;
     constexpr int NPL = SPLIT ? 2 : 1;
+    constexpr int NBUF = gemm_nbuf(BM, BN, SPLIT);
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
     constexpr int STAGE = NPL * (A_BYTES + B_BYTES);
     constexpr int FM = BM / 32, FN = BN / 32;
@@ -199,7 +208,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
     } while (0)
 #define LSTORE(SET, BUF)                                                                  \
     do {                                                                                  \
-        unsigned char* s__ = smem + (BUF) * STAGE;                                        \
+        unsigned char* s__ = smem + ((BUF) & (NBUF - 1)) * STAGE;                         \
         SA::store(va_hi[SET], s__, tid);                                                  \
         if constexpr (SPLIT) SA::store(va_lo[SET], s__ + A_BYTES, tid);                   \
         SB::store(vb_hi[SET], s__ + NPL * A_BYTES, tid);                                  \
@@ -218,7 +227,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
     } while (0)
 #define COMPUTE(T)                                                                                                   \
     do {                                                                                                             \
-        const unsigned char* s = smem + ((T) & 1) * STAGE;                                                           \
+        const unsigned char* s = smem + ((T) & (NBUF - 1)) * STAGE;                                                  \
         const unsigned char* sA = s;                                                                                 \
         const unsigned char* sB = s + NPL * A_BYTES;                                                                 \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                           \
@@ -268,6 +277,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
             for (int u = 0; u < PD; ++u) {
                 GLOAD(KF, u, t + u + PD);            // register set u held tile t+u (already staged) -> refill
                 COMPUTE(t + u);
+                if constexpr (NBUF == 1) __syncthreads();
                 LSTORE((u + 1) % PD, (t + u + 1) & 1);
                 __syncthreads();
             }
@@ -280,6 +290,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                 if (tt < ntiles) {                   // block-uniform
                     if (tt + PD < ntiles) GLOAD(KF, u, tt + PD);
                     COMPUTE(tt);
+                    if constexpr (NBUF == 1) __syncthreads();
                     if (tt + 1 < ntiles) LSTORE((u + 1) % PD, (tt + 1) & 1);
                     __syncthreads();
                 }
@@ -458,7 +469,7 @@ int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
-    constexpr int LDS = 2 * NPL * (BM + BN) * 128;
+    constexpr int LDS = gemm_nbuf(BM, BN, SPLIT) * NPL * (BM + BN) * 128;
     static bool attr_set = false;
     auto kern = gemm_kernel<BM, BN, TA, TB, SPLIT, EPI>;
     if (!attr_set) {
