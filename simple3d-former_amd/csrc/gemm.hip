@@ -56,6 +56,7 @@ namespace {
 #ifndef S3D_SPLIT_SINGLE_BUF
 #define S3D_SPLIT_SINGLE_BUF 0
 #endif
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int gemm_nbuf(int BM, int BN, bool split) { return (split && S3D_SPLIT_SINGLE_BUF && BM * BN <= 64 * 64) ? 1 : 2; }
 
 template <int BR, bool T>
@@ -143,6 +144,97 @@ struct Stager {
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int r, int kc) {
     const int sw = (r ^ (r >> 3)) & 7;
     return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((kc ^ sw) << 4));
+}
+
+// Vector load / store helpers for W = 4 or 8 consecutive elements (16-byte transactions wherever the width allows).
+template <int W> __device__ __forceinline__ void ld_f32(float (&d)[W], const float* src) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+        d[4 * q] = t[0]; d[4 * q + 1] = t[1]; d[4 * q + 2] = t[2]; d[4 * q + 3] = t[3];
+    }
+}
+template <int W> __device__ __forceinline__ void st_f32(float* dst, const float (&v)[W]) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+}
+template <int W> struct BfVec;
+template <> struct BfVec<4> { union { u32x2 u; bf16_t h[4]; }; };
+template <> struct BfVec<8> { union { u32x4 u; bf16_t h[8]; }; };
+template <int W> __device__ __forceinline__ void st_bf(bf16_t* dst, const BfVec<W>& v) { *reinterpret_cast<decltype(v.u)*>(dst) = v.u; }
+template <int W> __device__ __forceinline__ void ld_bf(BfVec<W>& v, const bf16_t* src) { v.u = *reinterpret_cast<const decltype(v.u)*>(src); }
+
+// One lane's share of a vector epilogue: row m, W consecutive columns n .. n+W-1 (accumulators v).  N % W == 0, so the
+// group is all-in or all-out.
+template <int EPI, int W>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, const int n, const float (&v)[W]) {
+    if (m >= p.M || n >= p.N) return;
+    float bq[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) bq[r] = 0.f;
+    if constexpr (EPI != EPI_ATOMIC && EPI != EPI_DGELU && EPI != EPI_DRELU) {
+        if (p.bias) ld_f32<W>(bq, p.bias + n);
+    }
+    BfVec<W> hi, lo, ax;
+    float dm[W];                                        // dropout multipliers (RESID / RELU / DRELU only)
+#pragma unroll
+    for (int r = 0; r < W; ++r) dm[r] = 1.f;
+    if constexpr (EPI == EPI_RESID || EPI == EPI_RELU || EPI == EPI_DRELU) {
+        if (p.drop_thr) {
+            const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
+#pragma unroll
+            for (int r = 0; r < W; ++r)
+                dm[r] = drop_keep(key, (unsigned long long)m * p.N + n + r, p.drop_thr) ? p.drop_scale : 0.f;
+        }
+    }
+    if constexpr (EPI == EPI_BF16_BIAS) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) split_bf16(v[r] * p.alpha + bq[r], hi.h[r], lo.h[r]);
+        st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
+        if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
+    } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+            const float pre = v[r] + bq[r];
+            ax.h[r] = f2bf(pre);
+            split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f) * dm[r], hi.h[r], lo.h[r]);
+        }
+        if (p.aux) st_bf<W>(p.aux + (long)m * p.ldaux + n, ax);
+        st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
+        if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
+    } else if constexpr (EPI == EPI_RESID) {
+        float rr[W], o[W];
+        ld_f32<W>(rr, p.R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int r = 0; r < W; ++r) o[r] = (v[r] + bq[r]) * dm[r] + rr[r];
+        st_f32<W>(p.C + (long)m * p.ldc + n, o);
+        if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
+#pragma unroll
+            for (int r = 0; r < W; ++r) hi.h[r] = f2bf(o[r]);
+            st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
+        }
+    } else if constexpr (EPI == EPI_TOKEN) {
+        const int t = m % p.ntok;
+        float ps[W], cl[W], o[W];
+        ld_f32<W>(ps, p.pos + (long)t * p.N + n);
+        ld_f32<W>(cl, p.cls + n);
+#pragma unroll
+        for (int r = 0; r < W; ++r) o[r] = v[r] * p.alpha + (t == 0 ? cl[r] : bq[r]) + ps[r];
+        st_f32<W>(p.C + (long)m * p.ldc + n, o);
+    } else if constexpr (EPI == EPI_F32) {
+        float o[W];
+#pragma unroll
+        for (int r = 0; r < W; ++r) o[r] = v[r] * p.alpha + bq[r];
+        st_f32<W>(p.C + (long)m * p.ldc + n, o);
+    } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+        ld_bf<W>(ax, p.aux + (long)m * p.ldaux + n);
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+            const float pre = bf2f(ax.h[r]);
+            hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
+        }
+        st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
+    }
 }
 
 // PD = register prefetch distance (tiles of global loads in flight per thread).  These GEMMs are small (M = 1664
@@ -321,78 +413,36 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                     if (m < p.M && n < p.N) atomic_add_f32(&p.C[(long)m * p.ldc + n], acc[i][j][r] * p.alpha);
                 }
             }
+    } else if ((p.N & 7) == 0) {                       // block-uniform
+        // Staged epilogue.  Straight from the MFMA layout a store instruction writes 16 rows x 32 bytes (8 bytes per lane):
+        // the epilogue is store-ISSUE-bound (~7 B/clk/CU) and cost 3-6 us of the 10-18 us these GEMMs take.  The tile goes
+        // through LDS (fp32, rows padded by 16 bytes) instead, and every thread finishes 8 consecutive columns of one row:
+        // 16-byte stores, 8 lanes per 128-byte line of a bf16 output.
+        constexpr int LDC = BN + 4, CPR = BN / 8;
+        float* ct = reinterpret_cast<float*>(smem);
+        __syncthreads();                                // every wave is done reading the operand stages
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) =
+                    acc[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int c = tid; c < BM * CPR; c += 256) {
+            const int row = c / CPR, col = (c % CPR) * 8;
+            float v[8];
+            ld_f32<8>(v, ct + row * LDC + col);
+            epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
+        }
     } else {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + (lane & 15);
-            const int n = n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4;
-            if (m >= p.M || n >= p.N) continue;                 // N % 4 == 0: the quad is all-in or all-out
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            float bq[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI != EPI_ATOMIC && EPI != EPI_DGELU && EPI != EPI_DRELU) {
-                if (p.bias) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    bq[0] = t[0]; bq[1] = t[1]; bq[2] = t[2]; bq[3] = t[3];
-                }
+            for (int j = 0; j < FN; ++j) {
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epilogue_vec<EPI, 4>(p, m0 + wm * (BM / 2) + i * 16 + (lane & 15), n0 + wn * (BN / 2) + j * 16 + (lane >> 4) * 4, v);
             }
-            union { u32x2 u; bf16_t h[4]; } hi, lo, ax;
-            float dm[4] = {1.f, 1.f, 1.f, 1.f};                 // dropout multipliers (RESID / RELU / DRELU only)
-            if constexpr (EPI == EPI_RESID || EPI == EPI_RELU || EPI == EPI_DRELU) {
-                if (p.drop_thr) {
-                    const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        dm[r] = drop_keep(key, (unsigned long long)m * p.N + n + r, p.drop_thr) ? p.drop_scale : 0.f;
-                }
-            }
-            if constexpr (EPI == EPI_BF16_BIAS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) split_bf16(v[r] * p.alpha + bq[r], hi.h[r], lo.h[r]);
-                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
-                if (p.O_lo) *reinterpret_cast<u32x2*>(p.O_lo + (long)m * p.ldo + n) = lo.u;
-            } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = v[r] + bq[r];
-                    ax.h[r] = f2bf(pre);
-                    split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f) * dm[r], hi.h[r], lo.h[r]);
-                }
-                if (p.aux) *reinterpret_cast<u32x2*>(p.aux + (long)m * p.ldaux + n) = ax.u;
-                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
-                if (p.O_lo) *reinterpret_cast<u32x2*>(p.O_lo + (long)m * p.ldo + n) = lo.u;
-            } else if constexpr (EPI == EPI_RESID) {
-                const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (long)m * p.ldr + n);
-                f32x4 o = {(v[0] + bq[0]) * dm[0] + rr[0], (v[1] + bq[1]) * dm[1] + rr[1], (v[2] + bq[2]) * dm[2] + rr[2],
-                           (v[3] + bq[3]) * dm[3] + rr[3]};
-                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
-                if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hi.h[r] = f2bf(o[r]);
-                    *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
-                }
-            } else if constexpr (EPI == EPI_TOKEN) {
-                const int t = m % p.ntok;
-                const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (long)t * p.N + n);
-                const f32x4 cl = *reinterpret_cast<const f32x4*>(p.cls + n);
-                f32x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha + (t == 0 ? cl[r] : bq[r]) + ps[r];
-                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
-            } else if constexpr (EPI == EPI_F32) {
-                f32x4 o = {v[0] * p.alpha + bq[0], v[1] * p.alpha + bq[1], v[2] * p.alpha + bq[2], v[3] * p.alpha + bq[3]};
-                *reinterpret_cast<f32x4*>(p.C + (long)m * p.ldc + n) = o;
-            } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
-                ax.u = *reinterpret_cast<const u32x2*>(p.aux + (long)m * p.ldaux + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = bf2f(ax.h[r]);
-                    hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
-                }
-                *reinterpret_cast<u32x2*>(p.O_hi + (long)m * p.ldo + n) = hi.u;
-            }
-        }
     }
 
     if constexpr (TA && EPI == EPI_ATOMIC) {
@@ -441,7 +491,7 @@ __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs pa, const
 
 template <int BMA, int EPIA, int BMB>
 int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream) {
-    constexpr int LDS = 2 * ((BMA > BMB ? BMA : BMB) + 64) * 128;
+    constexpr int LDS = cmax(2 * ((BMA > BMB ? BMA : BMB) + 64) * 128, BMA * (64 + 4) * 4);
     static bool attr_set = false;
     auto kern = gemm_pair_kernel<BMA, EPIA, BMB>;
     if (!attr_set) {
@@ -469,7 +519,7 @@ int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     constexpr int NPL = SPLIT ? 2 : 1;
-    constexpr int LDS = gemm_nbuf(BM, BN, SPLIT) * NPL * (BM + BN) * 128;
+    constexpr int LDS = cmax(gemm_nbuf(BM, BN, SPLIT) * NPL * (BM + BN) * 128, BM * (BN + 4) * 4);
     static bool attr_set = false;
     auto kern = gemm_kernel<BM, BN, TA, TB, SPLIT, EPI>;
     if (!attr_set) {
@@ -504,15 +554,20 @@ int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
     }
 }
 
+template <bool SPLIT, int EPI>
+int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
+    return launch_tiles<false, false, SPLIT, EPI>(tile, a, 1, s);
+}
+
 template <bool SPLIT>
 int launch_nt(int epi, int tile, const GemmArgs& a, hipStream_t s) {
     switch (epi) {
-        case EPI_BF16_BIAS: return launch_tiles<false, false, SPLIT, EPI_BF16_BIAS>(tile, a, 1, s);
-        case EPI_GELU: return launch_tiles<false, false, SPLIT, EPI_GELU>(tile, a, 1, s);
-        case EPI_RELU: return launch_tiles<false, false, SPLIT, EPI_RELU>(tile, a, 1, s);
-        case EPI_RESID: return launch_tiles<false, false, SPLIT, EPI_RESID>(tile, a, 1, s);
-        case EPI_TOKEN: return launch_tiles<false, false, SPLIT, EPI_TOKEN>(tile, a, 1, s);
-        case EPI_F32: return launch_tiles<false, false, SPLIT, EPI_F32>(tile, a, 1, s);
+        case EPI_BF16_BIAS: return launch_nt_epi<SPLIT, EPI_BF16_BIAS>(tile, a, s);
+        case EPI_GELU: return launch_nt_epi<SPLIT, EPI_GELU>(tile, a, s);
+        case EPI_RELU: return launch_nt_epi<SPLIT, EPI_RELU>(tile, a, s);
+        case EPI_RESID: return launch_nt_epi<SPLIT, EPI_RESID>(tile, a, s);
+        case EPI_TOKEN: return launch_nt_epi<SPLIT, EPI_TOKEN>(tile, a, s);
+        case EPI_F32: return launch_nt_epi<SPLIT, EPI_F32>(tile, a, s);
         default: s3d_set_error("gemm: epilogue %d not available for NT", epi); return 2;
     }
 }
@@ -604,7 +659,11 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     }
     a.kchunk = (a.K + 63) / 64 * 64;
     const int tile = s3d_gemm_pick_tile(a.M, a.N, 1, split);
-    if (!ta && !tb) return split ? launch_nt<true>(epi, tile, a, stream) : launch_nt<false>(epi, tile, a, stream);
+    if (!ta && !tb) {
+        static const int forced_nt = env_int("S3D_GEMM_NT_TILE");
+        const int t = forced_nt >= 0 ? forced_nt : tile;
+        return split ? launch_nt<true>(epi, t, a, stream) : launch_nt<false>(epi, t, a, stream);
+    }
     if (!ta && tb) {
         S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
         switch (epi) {
