@@ -13,6 +13,8 @@
 // reference; backward runs in plain bf16 on the hi planes.
 #include "attention.h"
 
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ int slot_key(int s2, int h2, int j) {   // key (or query) index of k-slot (s2, lane-half, j)
@@ -405,6 +407,169 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward, N <= 32: one launch
+// With a single 32-token tile per (batch, head) -- cfg-1/2: N = 26 -- the two backward kernels above are each a few
+// microseconds of launch ramp and memory latency around a handful of MFMAs.  Here one wave does both for its (batch, head):
+// phase A = the dQ kernel's body (lane = query; also yields delta), phase B = the dK/dV kernel's body (lane = key), with
+// delta / lse handed over through LDS instead of a global round trip.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
+    constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;                    // K | Q | dO tiles (bf16) + delta / lse (fp32)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    bf16_t* ldsK = reinterpret_cast<bf16_t*>(smem + wave * WAVE_LDS);
+    bf16_t* ldsQ = ldsK + 32 * HD;
+    bf16_t* ldsDO = ldsQ + 32 * HD;
+    float* ldsR = reinterpret_cast<float*>(ldsDO + 32 * HD);           // [0..31] delta, [32..63] lse
+
+    const long W = (long)p.Bb * p.H;
+    long item = (long)blockIdx.x * 4 + wave;
+    const bool active = item < W;
+    if (!active) item = W - 1;
+    const int bh = (int)item;
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const long dobase = (long)b * p.sb * p.lddo + h * HD;
+    const long st_lddo = p.st * p.lddo;
+    const bool tok_ok = l31 < p.N;                                     // this lane's token (query in A, key in B)
+    const int tok = min(l31, p.N - 1);
+    const long tokrow = (long)b * p.sb + (long)tok * p.st;
+    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;   // the seed lives on the device
+
+    stage_tile<HD>(ldsK, p.qkv_hi, p.ld, base + p.D, st_ld, 0, p.N, lane);
+    stage_tile<HD>(ldsQ, p.qkv_hi, p.ld, base, st_ld, 0, p.N, lane);
+    stage_tile<HD>(ldsDO, p.dout, p.lddo, dobase, st_lddo, 0, p.N, lane);
+
+    // row-fragments of this lane's token: Q, dO (phase A operands), K, V (phase B operands)
+    bf16x8 qf[NS], dof[NS], kf[NS], vf[NS];
+    float delta = 0.f;
+    {
+        const long off = base + (long)tok * st_ld + h2 * 8;
+        const long doff = tokrow * p.lddo + h * HD + h2 * 8;
+        const long ooff = tokrow * p.ldo + h * HD + h2 * 8;
+        const float lo_on = p.out_lo ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qf[s] = ld_frag(p.qkv_hi + off + 16 * s);
+            kf[s] = ld_frag(p.qkv_hi + off + p.D + 16 * s);
+            vf[s] = ld_frag(p.qkv_hi + off + 2 * p.D + 16 * s);
+            dof[s] = ld_frag(p.dout + doff + 16 * s);
+            U128 a, ol, d;
+            a.v = ld_frag(p.out_hi + ooff + 16 * s);
+            ol.v = ld_frag((p.out_lo ? p.out_lo : p.out_hi) + ooff + 16 * s);
+            d.v = dof[s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
+        }
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    const float lse_q = p.lse[(long)bh * p.N + tok];
+    if (h2 == 0) { ldsR[l31] = delta; ldsR[32 + l31] = lse_q; }
+    if (active && tok_ok && h2 == 0 && p.delta) p.delta[(long)bh * p.N + l31] = delta;
+    __syncthreads();                                                   // tiles + delta / lse are staged
+
+    // ---- phase A: lane = query.  S^T = K . Q^T, dP^T = V . dO^T, dQ^T = K^T . dS^T
+    {
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sacc = MFMA32(kf[s], qf[s], sacc);
+            dpacc = MFMA32(vf[s], dof[s], dpacc);
+        }
+        U128 dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j, key = acc_row(r, h2);
+                const float pr = key < p.N ? expf(sacc[r] * p.scale - lse_q) : 0.f;
+                float dpn = dpacc[r];
+                if (p.drop_thr)
+                    dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
+            }
+        f32x16 dq[NDB];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dq[d] = MFMA32(gather_frag<HD>(ldsK, s2, h2, d * 32 + l31), dsf[s2].v, dq[d]);
+        }
+        if (active && tok_ok) {
+            const long orow = tokrow * p.lddq + h * HD;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    union { uint2 u; bf16_t h[4]; } v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
+                    const int dcol = d * 32 + 8 * c + 4 * h2;
+                    if (HD % 32 != 0 && dcol >= HD) continue;
+                    *reinterpret_cast<uint2*>(p.dqkv + orow + dcol) = v.u;
+                }
+        }
+    }
+    // ---- phase B: lane = key.  S = Q . K^T, dP = dO . V^T, dV^T = dO^T . P, dK^T = Q^T . dS
+    {
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            sacc = MFMA32(qf[s], kf[s], sacc);
+            dpacc = MFMA32(dof[s], vf[s], dpacc);
+        }
+        U128 pf[2], dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j, q = acc_row(r, h2);
+                const bool ok = tok_ok && (q < p.N);
+                const int qc = min(q, p.N - 1);
+                const float pr = ok ? expf(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
+                float dm = 1.f;
+                if (p.drop_thr) dm = drop_keep(dkey, ((unsigned long long)bh * p.N + qc) * p.N + tok, p.drop_thr) ? p.drop_scale : 0.f;
+                pf[s2].h[j] = f2bf(pr * dm);
+                dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[qc]) * p.scale);
+            }
+        f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dv[d] = MFMA32(gather_frag<HD>(ldsDO, s2, h2, d * 32 + l31), pf[s2].v, dv[d]);
+                dk[d] = MFMA32(gather_frag<HD>(ldsQ, s2, h2, d * 32 + l31), dsf[s2].v, dk[d]);
+            }
+        }
+        if (active && tok_ok) {
+            const long orow = tokrow * p.lddq + h * HD;
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    union { uint2 u; bf16_t h[4]; } a, v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
+                    const int dcol = d * 32 + 8 * c + 4 * h2;
+                    if (HD % 32 != 0 && dcol >= HD) continue;
+                    const long off = orow + dcol;
+                    *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
+                    *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
+                }
+        }
+    }
+}
+
 template <typename K>
 void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -431,6 +596,16 @@ template <int HD, int DSPLIT>
 int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     dim3 grid((unsigned)((W + 3) / 4));
+    if constexpr (HD <= 96) {
+        static const bool no_small = getenv("S3D_ATTN_NO_SMALL") != nullptr;
+        if (a.N <= 32 && !no_small) {
+            const int lds = 4 * (3 * 32 * HD * 2 + 256);
+            set_lds(attn_bwd_small_kernel<HD>, lds);
+            hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(256), lds, s, a);
+            S3D_CHECK_LAUNCH("attention_bwd_small");
+            return 0;
+        }
+    }
     {
         const int lds = 4 * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, lds);

@@ -167,7 +167,8 @@ def _attn_ref(q, k, v):
 
 
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(4, 6, 26, 64, False), (3, 3, 15, 256, False), (2, 3, 197, 256, False),
-                                                (5, 4, 100, 192, True), (2, 3, 257, 64, False), (64, 6, 26, 64, False)])
+                                                (5, 4, 100, 192, True), (2, 3, 257, 64, False), (64, 6, 26, 64, False),
+                                                (3, 4, 20, 96, True), (5, 4, 32, 48, False), (3, 2, 7, 64, False), (2, 2, 2, 64, False)])
 def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     g = torch.Generator().manual_seed(6)
     D = H * hd
