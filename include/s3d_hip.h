@@ -86,11 +86,20 @@ typedef struct S3dLnBwdArgs {
     uint16_t* dx_bf; long lddxbf;
     float* dgamma; float* dbeta;
     long rows; int D;
+    /* partial != NULL: instead of atomically adding its column sums to dgamma / dbeta, workgroup b of the partial_blocks
+     * launched STORES them at partial[b][0][0..D) (gamma) and partial[b][1][0..D) (beta); s3d_layernorm_grad_reduce adds the
+     * partial_blocks rows to dgamma / dbeta afterwards (same-address fp32 atomics from ~100 workgroups cost a third of the
+     * kernel at cfg-2; without them the grid can also be finer) */
+    float* partial; int partial_blocks;
     /* optional dropout mask applied to the bf16 copy only (the branch gradient of a post-norm residual), see S3dGemmArgs */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
 } S3dLnBwdArgs;
 int s3d_layernorm_fwd(const S3dLnArgs* args, s3d_stream_t stream);
 int s3d_layernorm_bwd(const S3dLnBwdArgs* args, s3d_stream_t stream);
+/* dgamma[c] += sum_b partial[b][0][c], dbeta[c] += sum_b partial[b][1][c] for n_ln independent LayerNorms in one launch
+ * (n_ln <= 64; partial[i] is [nblk][2][D]) */
+int s3d_layernorm_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
+                              s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ attention
  * softmax(q k^T * hd^-0.5) v of timm Attention.forward (math restated at visualize_attention_map_voxel.py:125-138)
@@ -199,6 +208,10 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
     uint16_t* dqkv;                               /* [M][3D] */
     uint16_t* datt;                               /* [M][D] */
     float* delta;                                 /* [Bb*H*N] */
+    /* optional: LayerNorm column-sum partials, [n_layers_in_one_s3d_blocks_bwd_call][2][ln_partial_blocks][2][D]; when set,
+     * s3d_blocks_bwd / s3d_block_bwd run the LayerNorm backward kernels in partial mode and finish with one
+     * s3d_layernorm_grad_reduce over all their LayerNorms (NULL: atomics) */
+    float* ln_partial; int ln_partial_blocks;
 } S3dBlockScratch;
 int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
                   s3d_stream_t stream);

@@ -92,8 +92,25 @@ int wgrad(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW,
     return s3d_launch_gemm(true, true, false, EPI_ATOMIC, wgrad_args(dy, out, x, in, M, dW, db), 0, s);
 }
 
+// LayerNorm column-sum partials of one s3d_blocks_bwd call (see S3dBlockScratch::ln_partial): slot k of the call's LayerNorms
+struct LnPartials {
+    const float* part[64]; float* dg[64]; float* db[64];
+    int n = 0;
+    float* slot(const S3dBlockScratch& w, int D, float* dgamma, float* dbeta) {
+        float* ptr = w.ln_partial + (long)n * w.ln_partial_blocks * 2 * D;
+        part[n] = ptr; dg[n] = dgamma; db[n] = dbeta;
+        ++n;
+        return ptr;
+    }
+    int flush(const S3dBlockScratch& w, int D, hipStream_t s) {
+        const int rc = n ? s3d_launch_ln_grad_reduce(part, dg, db, n, w.ln_partial_blocks, D, s) : 0;
+        n = 0;
+        return rc;
+    }
+};
+
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
-              const S3dBlockScratch& w, hipStream_t s) {
+              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr) {
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     // ---- MLP branch: d(x_out) is in dx_a / dx_a_bf
@@ -110,6 +127,7 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     lb.dy = w.dxn; lb.lddy = D; lb.x = a.x_mid; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
     lb.dres = w.dx_a; lb.lddres = D; lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D;
     lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M; lb.D = D;
+    if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
     g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
@@ -127,6 +145,7 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s));
     lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = w.dx_b; lb.dx = w.dx_a;
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
+    if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
     return 0;
 }
@@ -263,6 +282,11 @@ int s3d_layernorm_fwd(const S3dLnArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_layernorm_fwd: null args");
     return s3d_launch_ln_fwd(*a, st(s));
 }
+int s3d_layernorm_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
+                              s3d_stream_t s) {
+    S3D_REQUIRE(partial && dgamma && dbeta, "s3d_layernorm_grad_reduce: null args");
+    return s3d_launch_ln_grad_reduce(partial, dgamma, dbeta, n_ln, nblk, D, st(s));
+}
 int s3d_layernorm_bwd(const S3dLnBwdArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_layernorm_bwd: null args");
     return s3d_launch_ln_bwd(*a, st(s));
@@ -310,7 +334,10 @@ int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlo
 int s3d_block_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockGrads* g, const S3dBlockActs* a,
                   const S3dBlockScratch* w, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && g && a && w, "s3d_block_bwd: null args");
-    return block_bwd(*sh, *p, *g, *a, *w, st(s));
+    LnPartials lp;
+    const bool partial = w->ln_partial != nullptr && w->ln_partial_blocks > 0;
+    S3D_TRY(block_bwd(*sh, *p, *g, *a, *w, st(s), partial ? &lp : nullptr));
+    return lp.flush(*w, sh->D, st(s));
 }
 int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, int depth, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_blocks_fwd: null args");
@@ -320,8 +347,13 @@ int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
 int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockGrads* g, const S3dBlockActs* a,
                    const S3dBlockScratch* w, int first, int last, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && g && a && w, "s3d_blocks_bwd: null args");
-    for (int i = first; i >= last; --i) S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s)));
-    return 0;
+    LnPartials lp;
+    const bool partial = w->ln_partial != nullptr && w->ln_partial_blocks > 0;
+    for (int i = first; i >= last; --i) {
+        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr));
+        if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
+    }
+    return lp.flush(*w, sh->D, st(s));
 }
 
 int s3d_encoder_layer_fwd(const S3dEncShape* sh, const S3dEncParams* p, const S3dEncActs* a, s3d_stream_t s) {

@@ -6,6 +6,8 @@
 typedef S3dLnArgs LnArgs;
 typedef S3dLnBwdArgs LnBwdArgs;
 int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s);
+int s3d_launch_ln_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
+                              hipStream_t s);
 int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
 
 // ---- tokenizer patch gather ("fold"): voxel grid -> GEMM A operand (split-bf16 planes) ----

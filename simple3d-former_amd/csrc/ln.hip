@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
 // memory latency instead of RPW (the kernel is latency-bound at M ~ 1.7k rows); dgamma/dbeta partials are reduced across the
 // block's waves in LDS and added with one atomic per column per block (same-address atomics serialise at ~12 ns each, so the
 // block count is kept at rows/16).
-constexpr int RPW = 4;
+constexpr int MAX_RPW = 4;
 
+template <int RPW>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);          // [2][4 waves][D]
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
             }
         }
     }
-    if (p.dgamma == nullptr) return;   // uniform
+    if (p.dgamma == nullptr && p.partial == nullptr) return;   // uniform
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const int col = c * 256 + lane * 4;
@@ -156,7 +157,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
         const int which = i / p.D, col = i % p.D;
         const float s = red[(which * 4 + 0) * p.D + col] + red[(which * 4 + 1) * p.D + col] +
                         red[(which * 4 + 2) * p.D + col] + red[(which * 4 + 3) * p.D + col];
-        atomic_add_f32((which ? p.dbeta : p.dgamma) + col, s);
+        if (p.partial) p.partial[((long)blockIdx.x * 2 + which) * p.D + col] = s;      // every block stores (zeros if it had no row)
+        else atomic_add_f32((which ? p.dbeta : p.dgamma) + col, s);
+    }
+}
+
+// dgamma / dbeta += column sums of the [nblk][2][D] partials of up to 64 LayerNorms.  One workgroup per (LayerNorm, 64
+// columns of the 2*D): thread (c, rg) sums rows rg, rg+4, .. with 13 independent loads in flight, LDS folds the four groups.
+struct LnReduceArgs { const float* part[64]; float* dg[64]; float* db[64]; int nblk, D; };
+__global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const LnReduceArgs a) {
+    __shared__ float red[4][64];
+    const int ln = blockIdx.y, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + c;                   // 0 .. 2D-1: [gamma | beta]
+    const float* src = a.part[ln];
+    float s = 0.f;
+    if (col < 2 * a.D) {
+        const int which = col / a.D, cc = col % a.D;
+        for (int b = rg; b < a.nblk; b += 4) s += src[((long)b * 2 + which) * a.D + cc];
+    }
+    red[rg][c] = s;
+    __syncthreads();
+    if (rg == 0 && col < 2 * a.D) {
+        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+        float* dst = (col < a.D) ? a.dg[ln] + col : a.db[ln] + (col - a.D);
+        *dst += t;
     }
 }
 
@@ -173,10 +197,31 @@ int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
 int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
     if (a.rows <= 0) return 0;
-    long blocks = (a.rows + 4 * RPW - 1) / (4 * RPW);
+    long blocks = (a.rows + 4 * MAX_RPW - 1) / (4 * MAX_RPW);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)blocks), dim3(256), 2 * 4 * a.D * sizeof(float), s, a);
+    if (a.partial) {
+        S3D_REQUIRE(a.partial_blocks > 0, "layernorm bwd: partial mode needs partial_blocks > 0");
+        blocks = a.partial_blocks;                       // the caller sized the buffer; the kernel grid-strides over rows
+    }
+    // rows each wave handles per trip: as many as the grid leaves it (clamped duplicate rows would only add loads)
+    const long per_wave = (a.rows + blocks * 4 - 1) / (blocks * 4);
+    const size_t lds = 2 * 4 * a.D * sizeof(float);
+    if (per_wave >= 3) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else if (per_wave == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, a);
     S3D_CHECK_LAUNCH("ln_bwd");
+    return 0;
+}
+
+int s3d_launch_ln_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
+                              hipStream_t s) {
+    S3D_REQUIRE(n_ln >= 0 && n_ln <= 64 && nblk > 0 && D > 0, "layernorm_grad_reduce: n_ln=%d (<= 64), nblk=%d, D=%d", n_ln, nblk, D);
+    if (n_ln == 0) return 0;
+    LnReduceArgs a;
+    for (int i = 0; i < n_ln; ++i) { a.part[i] = partial[i]; a.dg[i] = dgamma[i]; a.db[i] = dbeta[i]; }
+    a.nblk = nblk; a.D = D;
+    hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3((2 * D + 63) / 64, n_ln), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("ln_grad_reduce");
     return 0;
 }

@@ -9,6 +9,7 @@ Reference call sites this replaces: Feature3D_ViT2D_V2.forward_features/forward
 (models/vit_3d_2d_pretrain.py:453-526), F.cross_entropy + loss.backward() + optimizer.step()
 (train_cls_voxel.py:277-288)."""
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -152,8 +153,11 @@ class _BlockWorkspace:
         self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0)
 
 
+LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '208'))    # 0: LayerNorm backward uses atomics
+
+
 class _BlockScratch:
-    def __init__(self, M, D, H, hidden, BHN, device):
+    def __init__(self, M, D, H, hidden, BHN, device, depth=0):
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
         self.dxn = torch.empty(M, D, **f32)
@@ -168,6 +172,10 @@ class _BlockScratch:
         self.c = L.S3dBlockScratch()
         L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
                dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
+        if depth > 0 and LN_PARTIAL_BLOCKS > 0:
+            # column-sum partials of the 2*depth LayerNorms of one s3d_blocks_bwd call (S3dBlockScratch::ln_partial)
+            self.ln_partial = torch.empty(2 * depth, LN_PARTIAL_BLOCKS, 2, D, **f32)
+            L.fill(self.c, ln_partial=self.ln_partial, ln_partial_blocks=LN_PARTIAL_BLOCKS)
 
 
 class VoxelEngine:
@@ -314,7 +322,7 @@ class VoxelEngine:
         ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
-        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev)
+        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth)
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)

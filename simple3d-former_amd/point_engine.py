@@ -282,7 +282,7 @@ class PointEngine:
         M = B * ws.ntok
         ws.zero_pos = torch.zeros(ws.ntok, D, **f32)
         ws.blocks = _BlockWorkspace(self.depth, B, ws.ntok, D, self.H, 4 * D, dev, self.split)
-        ws.scratch = _BlockScratch(M, D, self.H, 4 * D, B * self.H * ws.ntok, dev)
+        ws.scratch = _BlockScratch(M, D, self.H, 4 * D, B * self.H * ws.ntok, dev, depth=self.depth)
         ws.nstats = torch.empty(2, M, **f32)
         ws.xn = torch.empty(M, D, **f32)                       # norm(x) incl. cls rows
         ws.t = torch.empty(B * S1, D, **f32); ws.tp = torch.empty(2, B * S1, D, **b16)

@@ -159,6 +159,20 @@ def test_layernorm_fwd_bwd(rows, D):
     assert rel_err(dx, xr.grad + dres.double()) < 2e-5
     assert rel_err(dx_bf.float(), xr.grad + dres.double()) < 1e-2
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    # partial-sum mode: per-workgroup column sums, then one reduce launch that ADDS them to dgamma / dbeta
+    import ctypes
+    from simple3d_former_amd import _lib as L
+    nblk = 13
+    part = torch.full((nblk, 2, D), float('nan'), device=DEV)                  # every slot must be written
+    dg2 = torch.full((D,), 0.5, device=DEV); db2 = torch.full((D,), -0.25, device=DEV)
+    dx2 = torch.empty_like(dx)
+    a = L.fill(L.S3dLnBwdArgs(), dy=dy, lddy=D, x=x, ldx=D, mean=mean, rstd=rstd, gamma=gamma, dres=dres, lddres=D, dx=dx2,
+               lddx=D, rows=rows, D=D, partial=part, partial_blocks=nblk)
+    L.check(L.lib().s3d_layernorm_bwd(ctypes.byref(a), L.current_stream()), 'ln_bwd partial')
+    P = (ctypes.c_void_p * 1)(part.data_ptr()); G = (ctypes.c_void_p * 1)(dg2.data_ptr()); Bp = (ctypes.c_void_p * 1)(db2.data_ptr())
+    L.check(L.lib().s3d_layernorm_grad_reduce(P, G, Bp, 1, nblk, D, L.current_stream()), 'ln_grad_reduce')
+    assert torch.equal(dx2, dx)
+    assert rel_err(dg2 - 0.5, gr.grad) < 1e-4 and rel_err(db2 + 0.25, br.grad) < 1e-4
 
 
 def _attn_ref(q, k, v):
