@@ -585,9 +585,22 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
     if (forced >= 0) return forced;
     auto count = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splitk; };
     if (count(128, 128) >= 512) return 2;
-    // split-bf16 tiles carry two planes per operand (64 KB of LDS at 64x64 -> 2 workgroups per CU): stay on 32x64 until
-    // there are plenty of workgroups (measured on fc1 fwd: 19.5 us vs 21.5 us)
-    if (count(64, 64) >= (split ? 1024 : 384)) return 1;
+    if (split) {
+        // split-bf16 tiles carry two planes per operand: 64 KB of LDS at 64x64 (2 workgroups per CU = 512 slots), 48 KB at
+        // 32x64 (3 per CU).  Measured at M = 1664 after the staged epilogue (us, tiles 32x64 / 64x64 / 32x32):
+        //   qkv  N=1152 K=384  14.4 / 12.1 / 15.7      proj N=384 K=384    8.4 /  8.0 /  7.8
+        //   fc1  N=1536 K=384  18.1 / 19.2 / 20.2      fc2  N=384 K=1536  21.3 / 20.1 / 19.6
+        // i.e. 64x64 wins when its grid fits one round of slots (or is large), 32x32 when even 32x64 leaves the chip
+        // under-filled, 32x64 otherwise.
+        const long c64 = count(64, 64), c32 = count(32, 64);
+        if (c64 >= 1024 || (c64 > 384 && c64 <= 512)) return 1;
+        if (c32 < 512) return 3;
+        return 0;
+    }
+    // plain bf16 (backward): 24 KB of LDS per 64x64 workgroup.  In the full cfg-2 step the dgrad+wgrad pair launches run
+    // 2.54 ms/step with 32-row tiles for the N = 384 dgrads vs 2.45 ms with 64x64 everywhere (fewer, fatter workgroups
+    // re-read less from L2 while the wgrad half of the grid supplies the parallelism).
+    if (count(64, 64) >= 128) return 1;
     return 0;
 }
 
@@ -619,7 +632,9 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     GemmArgs a = a_in, b = b_in;
     int splitk = 0, kchunk = 0;
     wgrad_split(b, splitk, kchunk);
-    const int tile_a = s3d_gemm_pick_tile(a.M, a.N, 1, false), tile_b = s3d_gemm_pick_tile(b.M, b.N, splitk, false);
+    static const int forced_a = env_int("S3D_GEMM_DGRAD_TILE"), forced_b = env_int("S3D_GEMM_WGRAD_TILE");
+    const int tile_a = forced_a >= 0 ? forced_a : s3d_gemm_pick_tile(a.M, a.N, 1, false);
+    const int tile_b = forced_b >= 0 ? forced_b : s3d_gemm_pick_tile(b.M, b.N, splitk, false);
     const bool ok = (a.K % 8 == 0) && (a.N % 8 == 0) && (b.M % 8 == 0) && (b.N % 8 == 0) && (a.lda % 8 == 0) && (a.ldb % 8 == 0) &&
                     (b.lda % 8 == 0) && (b.ldb % 8 == 0);
     if (no_pair > 0 || tile_a >= 2 || tile_b >= 2 || !ok) {
