@@ -12,6 +12,7 @@
 //   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
 #include "gemm.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <array>
@@ -604,18 +605,27 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
     return 0;
 }
 
-static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk) {
+// paired: the wgrad shares its launch with a dgrad that already supplies workgroups, so it needs fewer k-slices (fewer
+// fp32 atomics): full cfg-2 step 2.40 ms with the stand-alone target of 512 workgroups vs 2.33 ms with 256.
+static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
     if (splitk <= 0) {
+        static const int target_env = env_int("S3D_GEMM_WGRAD_TARGET"), cap_env = env_int("S3D_GEMM_SPLITK_MAX");
+        const long target = target_env > 0 ? target_env : (paired ? 256 : 512);
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
-        splitk = (int)((512 + tiles64 - 1) / tiles64);
+        splitk = (int)((target + tiles64 - 1) / tiles64);
+        const int cap = cap_env > 0 ? cap_env : 0;
+        if (cap > 0 && splitk > cap) splitk = cap;
         const int maxk = (a.K + 127) / 128;
         if (splitk > maxk) splitk = maxk;
         if (splitk < 1) splitk = 1;
     }
     kchunk = ((a.K + splitk - 1) / splitk + 63) / 64 * 64;
     splitk = (a.K + kchunk - 1) / kchunk;
+    static const int dbg = env_int("S3D_GEMM_DEBUG");
+    static int shown = 0;
+    if (dbg > 0 && shown < dbg) { ++shown; fprintf(stderr, "[s3d] wgrad M=%d N=%d K=%d paired=%d -> splitk=%d kchunk=%d\n", a.M, a.N, a.K, (int)paired, splitk, kchunk); }
 }
 
 template <int EPIA>
@@ -631,7 +641,7 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     static const int no_pair = env_int("S3D_GEMM_NOPAIR");
     GemmArgs a = a_in, b = b_in;
     int splitk = 0, kchunk = 0;
-    wgrad_split(b, splitk, kchunk);
+    wgrad_split(b, splitk, kchunk, true);
     static const int forced_a = env_int("S3D_GEMM_DGRAD_TILE"), forced_b = env_int("S3D_GEMM_WGRAD_TILE");
     const int tile_a = forced_a >= 0 ? forced_a : s3d_gemm_pick_tile(a.M, a.N, 1, false);
     const int tile_b = forced_b >= 0 ? forced_b : s3d_gemm_pick_tile(b.M, b.N, splitk, false);

@@ -173,7 +173,17 @@ __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const LnReduceArgs 
     float s = 0.f;
     if (col < 2 * a.D) {
         const int which = col / a.D, cc = col % a.D;
-        for (int b = rg; b < a.nblk; b += 4) s += src[((long)b * 2 + which) * a.D + cc];
+        // eight independent (clamped, then masked) loads per trip: the reduction is latency-bound, not bandwidth-bound
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b0 = rg; b0 < a.nblk; b0 += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 4 * u;
+                const float v = src[((long)min(b, a.nblk - 1) * 2 + which) * a.D + cc];
+                acc[u] += (b < a.nblk) ? v : 0.f;
+            }
+        }
+        s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
     }
     red[rg][c] = s;
     __syncthreads();
@@ -198,6 +208,7 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
     if (a.rows <= 0) return 0;
     long blocks = (a.rows + 4 * MAX_RPW - 1) / (4 * MAX_RPW);
+    if (a.rows <= 512) blocks = (a.rows + 3) / 4;         // few rows (final norm on the cls rows): one row per wave
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     if (a.partial) {
