@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
     const int QT = (p.N + 31) / 32;
     const long W = (long)p.Bb * p.H * QT;
-    long item = (long)blockIdx.x * 4 + wave;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const bool active = item < W;
     if (!active) item = W - 1;
     const int qt = (int)(item % QT);
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 
     const int QT = (p.N + 31) / 32;
     const long W = (long)p.Bb * p.H * QT;
-    long item = (long)blockIdx.x * 4 + wave;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const bool active = item < W;
     if (!active) item = W - 1;
     const int qt = (int)(item % QT);
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 
     const int KT = (p.N + 31) / 32;
     const long W = (long)p.Bb * p.H * KT;
-    long item = (long)blockIdx.x * 4 + wave;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const bool active = item < W;
     if (!active) item = W - 1;
     const int kt = (int)(item % KT);
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
     float* ldsR = reinterpret_cast<float*>(ldsDO + 32 * HD);           // [0..31] delta, [32..63] lse
 
     const long W = (long)p.Bb * p.H;
-    long item = (long)blockIdx.x * 4 + wave;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
     const bool active = item < W;
     if (!active) item = W - 1;
     const int bh = (int)item;
@@ -570,6 +570,14 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
     }
 }
 
+// One wave per work item.  With few items (cfg-2: 384 = 64 samples x 6 heads) four-wave workgroups would occupy only 96 of the
+// 256 CUs; single-wave workgroups spread them over the chip.  S3D_ATTN_WPB overrides (tuning).
+int waves_per_block(long W) {
+    static const int forced = getenv("S3D_ATTN_WPB") ? atoi(getenv("S3D_ATTN_WPB")) : 0;
+    if (forced == 1 || forced == 2 || forced == 4) return forced;
+    return W <= 1024 ? 1 : (W <= 2048 ? 2 : 4);
+}
+
 template <typename K>
 void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -578,15 +586,16 @@ void set_lds(K kern, int bytes) {
 template <int HD>
 int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
-    dim3 grid((unsigned)((W + 3) / 4));
+    const int wpb = waves_per_block(W);
+    dim3 grid((unsigned)((W + wpb - 1) / wpb));
     if (split) {
-        const int lds = 4 * 2 * 32 * HD * 2;
-        set_lds(attn_fwd_kernel<HD, true>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(256), lds, s, a);
+        const int lds = wpb * 2 * 32 * HD * 2;
+        set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * HD * 2);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
     } else {
-        const int lds = 4 * 32 * HD * 2;
-        set_lds(attn_fwd_kernel<HD, false>, lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(256), lds, s, a);
+        const int lds = wpb * 32 * HD * 2;
+        set_lds(attn_fwd_kernel<HD, false>, 4 * 32 * HD * 2);
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(64 * wpb), lds, s, a);
     }
     S3D_CHECK_LAUNCH("attention_fwd");
     return 0;
@@ -595,28 +604,29 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
 template <int HD, int DSPLIT>
 int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
-    dim3 grid((unsigned)((W + 3) / 4));
+    const int wpb = waves_per_block(W);
+    dim3 grid((unsigned)((W + wpb - 1) / wpb));
     if constexpr (HD <= 96) {
         static const bool no_small = getenv("S3D_ATTN_NO_SMALL") != nullptr;
         if (a.N <= 32 && !no_small) {
-            const int lds = 4 * (3 * 32 * HD * 2 + 256);
-            set_lds(attn_bwd_small_kernel<HD>, lds);
-            hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(256), lds, s, a);
+            const int lds = wpb * (3 * 32 * HD * 2 + 256);
+            set_lds(attn_bwd_small_kernel<HD>, 4 * (3 * 32 * HD * 2 + 256));
+            hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
             S3D_CHECK_LAUNCH("attention_bwd_small");
             return 0;
         }
     }
     {
-        const int lds = 4 * 32 * HD * 2;
-        set_lds(attn_bwd_dq_kernel<HD>, lds);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(256), lds, s, a);
+        const int lds = wpb * 32 * HD * 2;
+        set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dq");
     }
     {
-        const int lds = 4 * 2 * 32 * HD * 2;
-        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, lds);
+        const int lds = wpb * 2 * 32 * HD * 2;
+        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * 2 * 32 * HD * 2);
         dim3 g2(grid.x, DSPLIT);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dkv");
     }
     return 0;
