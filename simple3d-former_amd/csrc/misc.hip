@@ -58,16 +58,22 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------- pos / cls / bias grads
-__global__ void posgrad_kernel(const PosGradArgs p, long gchunk) {
-    const int t = blockIdx.x;
+// One wave per (64 feature columns, slice of groups): the wave walks all tokens, so the bias gradient (a sum over every
+// non-cls token) is accumulated in registers and costs ONE atomic per column per workgroup instead of one per token --
+// same-address fp32 atomics serialise, and the per-token version spent most of its 17 us there.
+__global__ __launch_bounds__(64) void posgrad_kernel(const PosGradArgs p, long gchunk) {
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    if (d >= p.D) return;
     const long g0 = (long)blockIdx.y * gchunk, g1 = min(p.groups, g0 + gchunk);
-    for (int d = threadIdx.x; d < p.D; d += blockDim.x) {
+    float bias_acc = 0.f;
+    for (int t = 0; t < p.ntok; ++t) {
         float s = 0.f;
         for (long g = g0; g < g1; ++g) s += p.dx[(g * p.ntok + t) * p.D + d];
         if (p.dpos) atomic_add_f32(p.dpos + (long)t * p.D + d, s);
         if (t == 0) { if (p.dcls) atomic_add_f32(p.dcls + d, s); }
-        else if (p.dbias) atomic_add_f32(p.dbias + d, s);
+        else bias_acc += s;
     }
+    if (p.dbias) atomic_add_f32(p.dbias + d, bias_acc);
 }
 
 // ------------------------------------------------------------------------------------------- token assemble (pass 2)
@@ -141,15 +147,29 @@ __global__ void head_bwd_linear_kernel(const HeadArgs p) {
     const long nf = (long)p.B * p.D, nw = (long)p.C * p.D;
     if (idx < nf) {
         const int b = (int)(idx / p.D), d = (int)(idx % p.D);
-        float s = 0.f;
-        for (int c = 0; c < p.C; ++c) s += p.dlogits[(long)b * p.C + c] * p.W[(long)c * p.D + d];
-        p.dfeat[idx] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // four independent chains: the loop is latency-bound
+        int c = 0;
+        for (; c + 3 < p.C; c += 4) {
+            s0 += p.dlogits[(long)b * p.C + c] * p.W[(long)c * p.D + d];
+            s1 += p.dlogits[(long)b * p.C + c + 1] * p.W[(long)(c + 1) * p.D + d];
+            s2 += p.dlogits[(long)b * p.C + c + 2] * p.W[(long)(c + 2) * p.D + d];
+            s3 += p.dlogits[(long)b * p.C + c + 3] * p.W[(long)(c + 3) * p.D + d];
+        }
+        for (; c < p.C; ++c) s0 += p.dlogits[(long)b * p.C + c] * p.W[(long)c * p.D + d];
+        p.dfeat[idx] = (s0 + s1) + (s2 + s3);
     } else if (idx < nf + nw) {
         const long j = idx - nf;
         const int c = (int)(j / p.D), d = (int)(j % p.D);
-        float s = 0.f;
-        for (int b = 0; b < p.B; ++b) s += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d];
-        atomic_add_f32(p.dW + j, s);
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = 0;
+        for (; b + 3 < p.B; b += 4) {
+            s0 += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d];
+            s1 += p.dlogits[(long)(b + 1) * p.C + c] * p.feat[(long)(b + 1) * p.D + d];
+            s2 += p.dlogits[(long)(b + 2) * p.C + c] * p.feat[(long)(b + 2) * p.D + d];
+            s3 += p.dlogits[(long)(b + 3) * p.C + c] * p.feat[(long)(b + 3) * p.D + d];
+        }
+        for (; b < p.B; ++b) s0 += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d];
+        atomic_add_f32(p.dW + j, (s0 + s1) + (s2 + s3));
     } else if (idx < nf + nw + p.C) {
         const int c = (int)(idx - nf - nw);
         float s = 0.f;
@@ -312,12 +332,11 @@ int s3d_launch_fold(const FoldArgs& a, hipStream_t s) {
 }
 
 int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
-    long gs = (a.groups + 3) / 4;          // group slices per token: a thread sums <= 4 rows serially (latency-bound otherwise)
-    if (gs > 64) gs = 64;
+    long gs = a.groups < 64 ? a.groups : 64;   // group slices
     if (gs < 1) gs = 1;
     const long gchunk = (a.groups + gs - 1) / gs;
-    const int threads = a.D >= 256 ? 256 : 64;
-    hipLaunchKernelGGL(posgrad_kernel, dim3(a.ntok, (unsigned)gs), dim3(threads), 0, s, a, gchunk);
+    gs = (a.groups + gchunk - 1) / gchunk;
+    hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((a.D + 63) / 64), (unsigned)gs), dim3(64), 0, s, a, gchunk);
     S3D_CHECK_LAUNCH("posgrad");
     return 0;
 }
