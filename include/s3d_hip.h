@@ -63,10 +63,13 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int sp
 
 /* Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
  * launch stream.  s3d_prof_collect synchronises those events and fills rows of 4 doubles
- * {kernel key, launches, total ms, total algorithmic flops (2*M*N*K)}; key = BM*100000 + ta*10000 + tb*1000 +
- * split*100 + epilogue.  Returns the number of distinct kernels.  Must be off during graph capture. */
+ * {kernel key, launches, total ms, total algorithmic flops (2*M*N*K)}; key digits = 1|BM|BN|ta|tb|split|epilogue for a
+ * single problem, 2|BM dgrad|BM wgrad|000|epilogue for a fused dgrad + wgrad launch (decoded in bench.py).  Returns the number
+ * of distinct kernels.  Must be off during graph capture.  s3d_prof_event_overhead measures what the bracket itself adds:
+ * the median time between two events recorded back-to-back on the stream with nothing in between (microseconds). */
 int s3d_prof_enable(int on);
 int s3d_prof_collect(double* rows, int cap);
+int s3d_prof_event_overhead(s3d_stream_t stream, double* microseconds);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps=1e-6) of timm Block.norm1/.norm2 and VisionTransformer.norm (vit_3d_2d_pretrain.py:287,469). */

@@ -273,6 +273,20 @@ size_t s3d_sizeof(const char* n) {
 
 int s3d_prof_enable(int on) { s3d_gemm_prof_enable(on != 0); return 0; }
 int s3d_prof_collect(double* rows, int cap) { return s3d_gemm_prof_collect(rows, cap); }
+int s3d_prof_event_overhead(s3d_stream_t stream, double* us) {
+    S3D_REQUIRE(us != nullptr, "s3d_prof_event_overhead: null result pointer");
+    constexpr int R = 33;
+    hipEvent_t e[2 * R];
+    float t[R];
+    for (auto& ev : e) (void)hipEventCreate(&ev);
+    for (int i = 0; i < R; ++i) { (void)hipEventRecord(e[2 * i], st(stream)); (void)hipEventRecord(e[2 * i + 1], st(stream)); }
+    (void)hipEventSynchronize(e[2 * R - 1]);
+    for (int i = 0; i < R; ++i) { t[i] = 0.f; (void)hipEventElapsedTime(&t[i], e[2 * i], e[2 * i + 1]); }
+    for (auto& ev : e) (void)hipEventDestroy(ev);
+    for (int i = 1; i < R; ++i) { const float v = t[i]; int j = i - 1; while (j >= 0 && t[j] > v) { t[j + 1] = t[j]; --j; } t[j + 1] = v; }
+    *us = (double)t[R / 2] * 1e3;
+    return 0;
+}
 
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int splitk, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");

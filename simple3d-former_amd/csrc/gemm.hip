@@ -23,7 +23,7 @@
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch, keyed by kernel
 // instantiation.  Off by default; never active during graph capture.
 namespace {
-struct ProfSlot { int key; double flops; hipEvent_t e0, e1; };
+struct ProfSlot { long long key; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfSlot> g_prof;
 }  // namespace
@@ -33,7 +33,7 @@ void s3d_gemm_prof_enable(bool on) {
 }
 // fills up to `cap` rows of {key, launches, total_ms, total_flops}; returns the number of distinct keys
 int s3d_gemm_prof_collect(double* rows, int cap) {
-    std::map<int, std::array<double, 3>> agg;
+    std::map<long long, std::array<double, 3>> agg;
     for (auto& sl : g_prof) {
         float ms = 0.f;
         if (hipEventSynchronize(sl.e1) == hipSuccess && hipEventElapsedTime(&ms, sl.e0, sl.e1) == hipSuccess) {
@@ -43,7 +43,7 @@ int s3d_gemm_prof_collect(double* rows, int cap) {
     }
     int n = 0;
     for (auto& kv : agg) {
-        if (n < cap) { rows[4 * n] = kv.first; rows[4 * n + 1] = kv.second[0]; rows[4 * n + 2] = kv.second[1]; rows[4 * n + 3] = kv.second[2]; }
+        if (n < cap) { rows[4 * n] = (double)kv.first; rows[4 * n + 1] = kv.second[0]; rows[4 * n + 2] = kv.second[1]; rows[4 * n + 3] = kv.second[2]; }
         ++n;
     }
     return n;
@@ -503,7 +503,7 @@ int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_
     const int nA = ntxA * ntyA, nB = ntxB * ntyB * splitk;
     if (g_prof_on) {
         ProfSlot sl;
-        sl.key = 9000000 + BMA * 10000 + BMB * 100 + EPIA;
+        sl.key = 200000000000LL + BMA * 100000000LL + BMB * 100000LL + EPIA;   // 2 | BM dgrad (3) | BM wgrad (3) | 000 | EPI dgrad (2)
         sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
@@ -530,8 +530,8 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, splitk);
     if (g_prof_on) {
         ProfSlot sl;
-        // key = BM*100000 + TA*10000 + TB*1000 + SPLIT*100 + EPI ; flops = algorithmic 2*M*N*K
-        sl.key = BM * 100000 + (TA ? 10000 : 0) + (TB ? 1000 : 0) + (SPLIT ? 100 : 0) + EPI;
+        // key digits: 1 | BM (3) | BN (3) | TA | TB | SPLIT | EPI (2) ; flops = algorithmic 2*M*N*K
+        sl.key = 100000000000LL + BM * 100000000LL + BN * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + (SPLIT ? 100 : 0) + EPI;
         sl.flops = 2.0 * a.M * a.N * a.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
