@@ -97,6 +97,8 @@ def main():
     ap.add_argument('--plain-bf16', action='store_true', help='one-MFMA forward (fails the 1e-3 logit bar; for comparison only)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='diagnostic: run the segmented multi-GPU step (RCCL calls between graph segments) even at N=1')
     ap.add_argument('--buckets', type=int, default=4)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
@@ -119,8 +121,9 @@ def main():
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29541')
         dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
 
     # model + optimizer state (reference init, seed 9), per-rank synthetic shard of the global batch
@@ -129,7 +132,8 @@ def main():
     eng.load_state_dict(sd)
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
     x, y = x_cpu.to(dev), y_cpu.to(dev)
-    trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs)
+    trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
+                                  force_collectives=args.force_collectives)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
 
     def barrier():

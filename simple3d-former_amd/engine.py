@@ -491,9 +491,16 @@ class VoxelEngine:
 
     def grad_buckets(self, n_buckets=3):
         """Splits the backward into `n_buckets` block ranges and returns (segments, [(start, end) arena slices]) such
-        that slice i holds exactly the gradients that are final once segment i has run (arena is in forward order)."""
+        that slice i holds exactly the gradients that are final once segment i has run (arena is in forward order).
+        Bucket sizes shrink geometrically in backward order (depth 12, 4 buckets: blocks 11-6, 5-3, 2-1, 0 + tokenizer):
+        the all-reduce of the LAST bucket cannot hide behind any compute, so it is the smallest; the first one has the
+        whole rest of backward to hide behind, so it is the largest."""
         n = max(1, min(n_buckets, self.depth))
-        bounds = [round(self.depth * k / n) for k in range(n + 1)]            # 0 .. depth
+        # boundaries (in blocks from the input side): depth / 2^(n-1), ..., depth / 2, depth
+        bounds = [0] + [max(k, self.depth // 2 ** (n - k)) for k in range(1, n)] + [self.depth]
+        for k in range(1, n + 1):                       # strictly increasing even for tiny depths
+            bounds[k] = max(bounds[k], bounds[k - 1] + 1)
+        bounds[n] = self.depth
         segments, slices = [], []
         end = self.arena.numel
         for k in range(n, 0, -1):

@@ -189,7 +189,7 @@ def test_dp_trainer_segmented_graphs_and_rccl_path():
         ref = make_engine(cfg, sd)
         eng = make_engine(cfg, sd)
         tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
-        assert len(tr.slices) == 3 and tr.segments == [(11, 8), (7, 4), (3, 0)]
+        assert len(tr.slices) == 3 and tr.segments == [(11, 6), (5, 3), (2, 0)]
         for step in range(3):
             l_ref = float(ref.train_step(x.to(DEV), y.to(DEV)))
             l_dp = float(tr.step(x.to(DEV), y.to(DEV)))

@@ -120,8 +120,8 @@ def test_two_rank_data_parallel_equals_single_process_full_batch():
     assert torch.equal(p0, p1), 'replicas diverged'
     assert float((p0 - ref.arena.p).abs().max()) < 1e-6, 'DP on two half batches != full batch'
     assert torch.equal(res[0][2], torch.full((10,), 3.0))       # 1 + 2 summed over both buckets
-    assert res[0][3] == [(5, 4), (3, 2), (1, 0)]                 # backward order, 3 buckets of 2 blocks
-    assert res[0][4] == [(256, 384), (128, 256), (0, 128)]       # contiguous arena slices tiling [0, numel)
+    assert res[0][3] == [(5, 3), (2, 1), (0, 0)]                 # backward order, 3 buckets shrinking towards the input
+    assert res[0][4] == [(192, 384), (64, 192), (0, 64)]         # contiguous arena slices tiling [0, numel)
 
 
 def test_shard_indices_matches_distributed_sampler():
