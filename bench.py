@@ -58,6 +58,29 @@ def kernel_name(key):
     return f'gemm_kernel<{b0},{b1},{"T" if ta else "N"}{"T" if not tb else "N"},{"split3" if sp else "bf16"},{epi}>'
 
 
+def rocprof_name(key):
+    """The same kernel as rocprofv3 prints it (template arguments), for looking it up in profiles/*.json."""
+    key = int(key)
+    kind, rest = key // 10 ** 11, key % 10 ** 11
+    b0, b1, tail = rest // 10 ** 8, (rest // 10 ** 5) % 1000, rest % 10 ** 5
+    if kind == 2:
+        return f'gemm_pair_kernel<{b0}, {tail % 100}, {b1}>'
+    tf = lambda v: 'true' if v else 'false'
+    return f'gemm_kernel<{b0}, {b1}, {tf((tail // 10000) % 10)}, {tf((tail // 1000) % 10)}, {tf((tail // 100) % 10)}, {tail % 100}>'
+
+
+def pmc_traffic(key):
+    """HBM-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_step.sh -> profiles/), or None.
+    bench.py cannot collect PMC counters itself (they need rocprofv3 around the process, one pass per counter group)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_step_traffic.json')
+    try:
+        with open(path) as f:
+            k = json.load(f)['kernels'].get(rocprof_name(key))
+        return (k['hbm_bytes_per_launch'], k) if k else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def cpu_baseline(x, y, budget_s=15.0):
     """The oracle's training step (forward + CE + autograd backward + Adam on every used parameter) on host cores."""
     from oracle import voxel_oracle as vo
@@ -209,9 +232,14 @@ def main():
             avg_us = dom[2] / dom[1] * 1e3
             achieved = dom[3] / (dom[2] * 1e-3) / 1e12                       # algorithmic TFLOP/s of the dominant kernel
             all_ach = sum(k[3] for k in ks) / (tot_ms * 1e-3) / 1e12
+            traffic, tdetail = pmc_traffic(dom[0])
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': kernel_name(dom[0]), 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': traffic,
+                'traffic_unit': 'bytes per launch (memory side of L2: HBM + Infinity Cache)',
+                'traffic_source': ('profiles/r01_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + '
+                                   'WRITE_SIZE, separate passes, ' + rocprof_name(dom[0])) if traffic else None,
+                'traffic_detail': tdetail,
                 'avg_launch_us': round(avg_us, 3), 'event_bracket_overhead_us': round(ov.value, 3),
                 'timing': 'HIP events on the launch stream around every GEMM launch (instrumented eager pass), minus the '
                           'time an empty event pair measures',

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""rocprofv3 --pmc CSVs of tools/pmc_step.sh -> per-kernel HBM-side traffic per launch (JSON + text).
+
+    python tools/pmc_step_summary.py gpurun_out/pmcstep profiles/r01_pmc_step_traffic
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies the 128-byte
+requests of wide coalesced streaming reads at 64 bytes, so `fetch_bytes_corrected` = 2 x raw; WRITE_SIZE is uncalibrated and
+given raw."""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def load(path, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row['Counter_Name'] != counter:
+                continue
+            name = re.sub(r'\(anonymous namespace\)::|^void ', '', row['Kernel_Name'])
+            name = re.sub(r'\(.*$', '', name)
+            a = agg[name]
+            a[0] += 1
+            a[1] += float(row['Counter_Value'])
+    return agg
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    fetch = load(f'{src}/fetch/p_counter_collection.csv', 'FETCH_SIZE')
+    write = load(f'{src}/write/p_counter_collection.csv', 'WRITE_SIZE')
+    hit = load(f'{src}/tcc/p_counter_collection.csv', 'TCC_HIT_sum')
+    miss = load(f'{src}/tcc/p_counter_collection.csv', 'TCC_MISS_sum')
+    out = {}
+    for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+        n = fetch[k][0]
+        f_kb = fetch[k][1] / n
+        w_kb = write[k][1] / write[k][0] if k in write and write[k][0] else 0.0
+        h, m = hit.get(k, [0, 0.0])[1], miss.get(k, [0, 0.0])[1]
+        out[k] = dict(launches=n, fetch_bytes_raw=round(f_kb * 1024), fetch_bytes_corrected=round(2 * f_kb * 1024),
+                      write_bytes_raw=round(w_kb * 1024), hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024),
+                      l2_hit_rate=round(h / (h + m), 4) if h + m else None)
+    with open(dst + '.json', 'w') as f:
+        json.dump(dict(command='bench.py --no-graphs --steps 4 --warmup 2 (cfg-2, batch 64), rocprofv3 --kernel-trace --pmc, '
+                               'one pass per counter group', correction='fetch x2 (gfx950 wide-read tally), write raw',
+                       kernels=out), f, indent=1)
+    with open(dst + '.txt', 'w') as f:
+        f.write('# HBM-side bytes per launch (FETCH_SIZE x2 corrected + WRITE_SIZE raw), L2 hit rate; cfg-2 step, eager launches\n')
+        f.write(f'{"launches":>8} {"fetch_MB":>9} {"write_MB":>9} {"total_MB":>9} {"L2hit":>6}  kernel\n')
+        for k, v in out.items():
+            f.write(f'{v["launches"]:8d} {v["fetch_bytes_corrected"] / 1e6:9.2f} {v["write_bytes_raw"] / 1e6:9.2f} '
+                    f'{v["hbm_bytes_per_launch"] / 1e6:9.2f} {v["l2_hit_rate"] if v["l2_hit_rate"] is not None else float("nan"):6.3f}  {k[:110]}\n')
+    print(open(dst + '.txt').read())
+
+
+if __name__ == '__main__':
+    main()
