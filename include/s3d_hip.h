@@ -135,6 +135,11 @@ typedef struct S3dFoldArgs {
     int B, V, c, P, mode;
 } S3dFoldArgs;
 int s3d_voxel_fold(const S3dFoldArgs* args, s3d_stream_t stream);
+/* 2-D branch (Feature3D_ViT2D_V2.forward_images, vit_3d_2d_pretrain.py:435-451): timm PatchEmbed's Conv2d(C, D, p, stride p)
+ * as a patch-GEMM operand.  img [B,C,H,W] fp32 -> rows b*(np+1)+1+patch of split-bf16 planes, k in (c, i, j) order; the row
+ * b*(np+1) (cls slot) is zeroed.  Followed by s3d_gemm(.., S3D_EPI_TOKEN) with pos = pos_embed, ntok = np+1. */
+int s3d_image_patchify(const float* img, uint16_t* a_hi, uint16_t* a_lo, long lda, int B, int C, int H, int W, int p,
+                       s3d_stream_t stream);
 
 typedef struct S3dPosGradArgs {
     const float* dx; long groups; int ntok, D;

@@ -233,6 +233,28 @@ def forward(sd, x, **kw):
     return voxel_head(forward_features(sd, x, **kw), sd)
 
 
+def forward_images(sd, img, *, backbone, bf16=False):
+    """Feature3D_ViT2D_V2.forward_images (vit_3d_2d_pretrain.py:435-451): timm PatchEmbed (Conv2d(3, D, 16, stride 16) ->
+    flatten(2).transpose(1, 2)), cls concat, + pos_embed, the SAME blocks, norm, 2-D head on the cls row."""
+    cfg = BACKBONES[backbone]
+    depth, H = cfg['depth'], cfg['num_heads']
+    t = F.conv2d(img, sd['patch_embed.proj.weight'], sd['patch_embed.proj.bias'], stride=16).flatten(2).transpose(1, 2)
+    t = torch.cat((sd['cls_token'].expand(img.shape[0], -1, -1), t), dim=1) + sd['pos_embed']
+    return linear(run_blocks(t, sd, depth, H, bf16)[:, 0], sd['head.weight'], sd['head.bias'])
+
+
+def lwf_loss_and_grads(sd, x, target, img, img_target, lambda_weight=0.1, **kw):
+    """One learning-without-forgetting step's loss (train_cls_voxel.py:250-267): CE(model(voxel)) + lambda * CE(forward_images)."""
+    names = sorted(set(used_param_names(sd, kw.get('pos_embedding', 'default'))) |
+                   {'patch_embed.proj.weight', 'patch_embed.proj.bias', 'pos_embed', 'head.weight', 'head.bias'})
+    leaf = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    lv = forward(leaf, x, **kw)
+    li = forward_images(leaf, img, backbone=kw['backbone'])
+    loss = F.cross_entropy(lv, target) + lambda_weight * F.cross_entropy(li, img_target)
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
+    return lv.detach(), li.detach(), loss.detach(), {k: g for k, g in zip(names, grads) if g is not None}
+
+
 def cross_entropy(logits, target, weight=None):
     return F.cross_entropy(logits, target, weight=weight)
 

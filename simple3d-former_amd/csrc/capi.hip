@@ -336,6 +336,10 @@ int s3d_cross_entropy(const S3dCeArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_cross_entropy: null args");
     return s3d_launch_ce(*a, st(s));
 }
+int s3d_image_patchify(const float* img, uint16_t* a_hi, uint16_t* a_lo, long lda, int B, int C, int H, int W, int p, s3d_stream_t s) {
+    S3D_REQUIRE(img && a_hi, "s3d_image_patchify: null args");
+    return s3d_launch_patchify(img, a_hi, a_lo, lda, B, C, H, W, p, st(s));
+}
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t s) {
     return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, st(s));

@@ -17,6 +17,7 @@ int s3d_launch_fold(const FoldArgs& a, hipStream_t s);
 
 // d(pos_embed)[t][:] += sum_g dx[g*ntok+t][:], d(cls) += rows t==0, d(conv bias) += rows t>=1
 typedef S3dPosGradArgs PosGradArgs;
+int s3d_launch_patchify(const float* img, bf16_t* a_hi, bf16_t* a_lo, long lda, int B, int C, int H, int W, int p, hipStream_t s);
 int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s);
 
 // pass-2 token assembly of group_embed: out = cat(cls, src) + pos  (and the gather of its backward)

@@ -57,6 +57,36 @@ __global__ __launch_bounds__(256) void fold_kernel(const FoldArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- 2-D patchify (LwF branch)
+// timm PatchEmbed = Conv2d(C, D, p, stride p) -> flatten(2).transpose(1, 2): as a GEMM operand, row b*(np+1) + 1 + py*PW + px
+// holds the patch in (c, i, j) order (the conv weight's own flattening); row b*(np+1) is the cls slot (zeros: the TOKEN epilogue
+// substitutes the cls token).  One thread per 8 consecutive k (32 contiguous bytes of an image row).
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ a_hi, bf16_t* __restrict__ a_lo, long lda,
+                                int B, int C, int H, int W, int p) {
+    const int PW = W / p, np_ = (H / p) * PW, K = C * p * p, K8 = K / 8;
+    const long total = (long)B * (np_ + 1) * K8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int k8 = (int)(idx % K8) * 8;
+        const long row = idx / K8;
+        const int t = (int)(row % (np_ + 1));
+        const long b = row / (np_ + 1);
+        union { u32x4 u; bf16_t h[8]; } hi, lo;
+        if (t == 0) {
+            hi.u = u32x4{0u, 0u, 0u, 0u};
+            lo.u = hi.u;
+        } else {
+            const int q = t - 1, py = q / PW, px = q % PW;
+            const int c = k8 / (p * p), rem = k8 % (p * p), i = rem / p, j = rem % p;
+            const float* src = img + (((long)b * C + c) * H + (py * p + i)) * W + px * p + j;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(src), v1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { split_bf16(v0[r], hi.h[r], lo.h[r]); split_bf16(v1[r], hi.h[4 + r], lo.h[4 + r]); }
+        }
+        *reinterpret_cast<u32x4*>(a_hi + row * lda + k8) = hi.u;
+        if (a_lo) *reinterpret_cast<u32x4*>(a_lo + row * lda + k8) = lo.u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- pos / cls / bias grads
 // One wave per (64 feature columns, slice of groups): the wave walks all tokens, so the bias gradient (a sum over every
 // non-cls token) is accumulated in registers and costs ONE atomic per column per workgroup instead of one per token --
@@ -169,12 +199,12 @@ __global__ void head_bwd_linear_kernel(const HeadArgs p) {
             s3 += p.dlogits[(long)(b + 3) * p.C + c] * p.feat[(long)(b + 3) * p.D + d];
         }
         for (; b < p.B; ++b) s0 += p.dlogits[(long)b * p.C + c] * p.feat[(long)b * p.D + d];
-        atomic_add_f32(p.dW + j, (s0 + s1) + (s2 + s3));
+        if (p.dW) atomic_add_f32(p.dW + j, (s0 + s1) + (s2 + s3));
     } else if (idx < nf + nw + p.C) {
         const int c = (int)(idx - nf - nw);
         float s = 0.f;
         for (int b = 0; b < p.B; ++b) s += p.dlogits[(long)b * p.C + c];
-        atomic_add_f32(p.dbias + c, s);
+        if (p.dbias) atomic_add_f32(p.dbias + c, s);
     }
 }
 
@@ -328,6 +358,18 @@ int s3d_launch_fold(const FoldArgs& a, hipStream_t s) {
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(fold_kernel, dim3((unsigned)(a.B * a.P * a.c)), dim3(256), lds, s, a);
     S3D_CHECK_LAUNCH("fold");
+    return 0;
+}
+
+int s3d_launch_patchify(const float* img, bf16_t* a_hi, bf16_t* a_lo, long lda, int B, int C, int H, int W, int p, hipStream_t s) {
+    S3D_REQUIRE(p > 0 && p % 8 == 0 && H % p == 0 && W % p == 0, "patchify: patch %d must be a multiple of 8 dividing %dx%d", p, H, W);
+    S3D_REQUIRE(lda >= (long)C * p * p && lda % 8 == 0, "patchify: lda=%ld too small for K=%d", lda, C * p * p);
+    const long total = (long)B * ((H / p) * (W / p) + 1) * (C * p * p / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)blocks), dim3(256), 0, s, img, a_hi, a_lo, lda, B, C, H, W, p);
+    S3D_CHECK_LAUNCH("patchify");
     return 0;
 }
 

@@ -35,13 +35,17 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_embedding='default', head='default'):
+def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_embedding='default', head='default',
+                       image_branch=False):
     """Ordered {state_dict key: shape} of the parameters the voxel forward touches (forward order, so that
     gradient buckets complete back-to-front during backward)."""
     cfg = BACKBONES[backbone]
     D, depth = cfg['embed_dim'], cfg['depth']
     c = cell
     shapes = {}
+    if image_branch:                         # 2-D stem of forward_images (vit_3d_2d_pretrain.py:435-451)
+        from .image_branch import image_param_shapes
+        shapes.update(image_param_shapes(D)[0])
     if embed_layer == 'VoxelNaiveProjection':
         shapes['voxel_embed.proj.conv2d_1.weight'] = (D, 1, c, c)
         shapes['voxel_embed.proj.conv2d_1.bias'] = (D,)
@@ -79,6 +83,9 @@ def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_emb
     else:
         shapes['voxel_head.weight'] = (n_classes, D)
         shapes['voxel_head.bias'] = (n_classes,)
+    if image_branch:
+        from .image_branch import image_param_shapes
+        shapes.update(image_param_shapes(D)[1])
     return shapes
 
 
@@ -183,7 +190,7 @@ class VoxelEngine:
     positional embedding (vit_3d_2d_pretrain.py:455-470) and Linear / AM-softmax head."""
 
     def __init__(self, *, backbone, embed_layer, voxel_size, cell, patch, n_classes, pos_embedding='default',
-                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
         if pos_embedding not in (None, 'default', 'group_embed'):
@@ -216,9 +223,14 @@ class VoxelEngine:
         self.split = bool(split)
         self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
         self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
-                                         n_classes=n_classes, head=head, pos_embedding=self.cfg['pos_embedding'])
+                                         n_classes=n_classes, head=head, pos_embedding=self.cfg['pos_embedding'],
+                                         image_branch=image_branch)
         self.arena = ParamArena(self.shapes, self.device)
         self._build_param_tables()
+        self.images = None
+        if image_branch:                    # forward_images / LwF (vit_3d_2d_pretrain.py:435-451, train_cls_voxel.py:250-267)
+            from .image_branch import ImageBranch
+            self.images = ImageBranch(self)
         if self.Kpad != self.Kc:   # padded conv-weight planes (row pitch Kpad) refreshed from the arena each step
             self.conv_hi = torch.zeros(self.D, self.Kpad, dtype=torch.bfloat16, device=self.device)
             self.conv_lo = torch.zeros_like(self.conv_hi)
@@ -557,6 +569,22 @@ class VoxelEngine:
         self.backward(B)
         self.adam_step(zero_grad=True)
         return loss
+
+    def lwf_train_step(self, x, target, img, img_target, lambda_weight=0.1, weight=None):
+        """One learning-without-forgetting step (train_cls_voxel.py:240-268): loss = CE(model(voxel), cls_idx) +
+        lambda * CE(model.forward_images(images), teacher labels); both backward passes accumulate into the same gradient
+        arena, then Adam.  Returns (total loss, voxel loss, image loss) as device scalars."""
+        if self.images is None:
+            raise RuntimeError('the engine was built without image_branch=True')
+        B, Bi = x.shape[0], img.shape[0]
+        self.forward(x)
+        lv = self.cross_entropy(B, target, weight)
+        self.images.forward(img)
+        li = self.images.cross_entropy(Bi, img_target, grad_scale=lambda_weight)
+        self.backward(B)
+        self.images.backward(Bi)
+        self.adam_step(zero_grad=True)
+        return lv + lambda_weight * li, lv, li
 
     def capture_train_step(self, B, weight=None):
         """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""

@@ -113,6 +113,10 @@ class AMSoftmaxLayer(nn.Module):
         nn.init.xavier_normal_(self.W, gain=1)
 
 
+_IMAGE_ONLY = ('patch_embed.', 'pos_embed', 'head.')                                  # not in the graph of model(voxel)
+_VOXEL_ONLY = ('voxel_embed.', 'voxel_pos_embed', 'voxel_head.', 'group_')            # not in the graph of forward_images
+
+
 class _VoxelForward(torch.autograd.Function):
     """model(voxel) as one autograd node: forward/backward of the entire path run on the HIP engine."""
 
@@ -131,8 +135,30 @@ class _VoxelForward(torch.autograd.Function):
         eng.zero_grad()
         eng.backward(ctx.batch, dlogits.contiguous().float())
         grads = []
+        for k, need in zip(eng.shapes, ctx.needs_input_grad[2:]):       # clones: a second node (forward_images) reuses the arena
+            grads.append(eng.arena.grad(k).clone() if need and not k.startswith(_IMAGE_ONLY) else None)
+        return (None, None) + tuple(grads)
+
+
+class _ImageForward(torch.autograd.Function):
+    """model.forward_images(images) as one autograd node (2-D branch on the same HIP engine and the same parameters)."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        eng = model._engine
+        eng.refresh_weight_planes()
+        logits = eng.images.forward(x.contiguous().float()).clone()
+        ctx.model, ctx.batch = model, x.shape[0]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.model._engine
+        eng.zero_grad()
+        eng.images.backward(ctx.batch, dlogits.contiguous().float())
+        grads = []
         for k, need in zip(eng.shapes, ctx.needs_input_grad[2:]):
-            grads.append(eng.arena.grad(k) if need else None)     # views; autograd copies them into .grad
+            grads.append(eng.arena.grad(k).clone() if need and not k.startswith(_VOXEL_ONLY) else None)
         return (None, None) + tuple(grads)
 
 
@@ -211,8 +237,9 @@ class Feature3D_ViT2D_V2(VisionTransformer):
         te = self.voxel_embed
         eng = VoxelEngine(backbone=self.transformer_backbone, embed_layer=type(te).__name__,
                           voxel_size=te.voxel_size[0], cell=te.cell_size[0], patch=te.patch_size,
-                          n_classes=self.n_classes, head=self.head_type, device=device,
+                          n_classes=self.n_classes, head=self.head_type, device=device, image_branch=True,
                           pos_embedding='group_embed' if self.pos_embed_type == 'group_embed' else 'default')
+        eng.images.frozen = bool(self.pretrained)             # __load_backbone_weight freezes the 2-D stem / head
         own = dict(self.named_parameters())
         eng.load_state_dict({k: own[k].detach() for k in eng.shapes})
         for k in eng.shapes:                      # same Parameter objects (optimizers keep working), new storage
@@ -229,5 +256,9 @@ class Feature3D_ViT2D_V2(VisionTransformer):
         return _VoxelForward.apply(self, x, *[own[k] for k in eng.shapes])
 
     def forward_images(self, x):
-        raise NotImplementedError('forward_images (2-D LwF branch, vit_3d_2d_pretrain.py:435-451) is out of scope: '
-                                  'it needs ImageNet + downloaded DeiT weights (SURVEY.md section 8(f) rank 4)')
+        """The 2-D branch (vit_3d_2d_pretrain.py:435-451): PatchEmbed -> cls + pos_embed -> the same blocks -> norm -> head."""
+        if not x.is_cuda:
+            raise RuntimeError('Feature3D_ViT2D_V2 runs on the HIP engine: move the model and the images to the MI355X')
+        eng = self.s3d_engine(x.device)
+        own = dict(self.named_parameters())
+        return _ImageForward.apply(self, x, *[own[k] for k in eng.shapes])

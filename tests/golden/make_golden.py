@@ -113,6 +113,49 @@ def run_case(name, cfg):
           f'{len(names)} grads')
 
 
+def lwf_case(name='tiny_v12_lwf_b2'):
+    """forward_images + the LwF loss of train_cls_voxel.py:250-267 (teacher labels are just seeded integers here)."""
+    cfg = dict(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed', voxel_size=12, cell=4, patch=3, n_classes=10,
+               pos_embedding='default', head='default', batch=2, lambda_weight=0.1)
+    kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')}
+    sd = vo.init_state_dict(seed=9, exercise_all=True, portable=True, **kw)
+    model = build_reference_model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    x, y = vo.synthetic_batch(cfg['batch'], cfg['voxel_size'], cfg['n_classes'], seed=9, portable=True)
+    img = (vo.portable_uniform((cfg['batch'], 3, 224, 224), 9, 7001) * 2 - 1).float()
+    yi = (vo.portable_uniform((cfg['batch'],), 9, 7002) * 1000).long()
+    pred = model(x)
+    img_pred = model.forward_images(img)
+    loss_v = torch.nn.functional.cross_entropy(pred, y)
+    loss_i = torch.nn.functional.cross_entropy(img_pred, yi)
+    loss = loss_v + cfg['lambda_weight'] * loss_i
+    loss.backward()
+    out = dict(cfg=np.array(json.dumps(cfg)), fingerprint=fingerprint(sd), logits=pred.detach().numpy(),
+               img_logits=img_pred.detach().numpy(), loss=np.array(loss.item()), loss_voxel=np.array(loss_v.item()),
+               loss_image=np.array(loss_i.item()), target=y.numpy(), img_target=yi.numpy(),
+               img_argmax=img_pred.argmax(1).numpy())
+    top2 = img_pred.detach().topk(2, dim=1).values
+    out['img_top2_gap'] = (top2[:, 0] - top2[:, 1]).numpy()
+    names = []
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        g = p.grad.detach().flatten()
+        names.append(k)
+        idx = sample_idx(g.numel())
+        out['gnorm/' + k] = np.array(float(g.double().norm()))
+        out['gsum/' + k] = np.array(float(g.double().sum()))
+        out['gidx/' + k] = idx
+        out['gval/' + k] = g[idx].numpy()
+        if g.numel() <= 4096:
+            out['gfull/' + k] = p.grad.detach().numpy()
+    out['grad_names'] = np.array(json.dumps(names))
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print(f'{name}: loss {loss.item():.6f} (voxel {loss_v.item():.6f}, image {loss_i.item():.6f}) img argmax '
+          f'{img_pred.argmax(1).tolist()} gap_min {out["img_top2_gap"].min():.4f} {len(names)} grads')
+
+
 def tokenizer_cases():
     from models import embed_layer_3d_modality as ref_embed
     out = {}
@@ -156,3 +199,5 @@ if __name__ == '__main__':
     for n, c in CASES.items():
         if not only or n in only:
             run_case(n, c)
+    if not only or 'lwf' in only:
+        lwf_case()

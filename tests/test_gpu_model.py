@@ -231,3 +231,92 @@ def test_group_embed_training_mode_dropout_matches_oracle():
     s0 = int(eng.dropout_seed)
     eng.train_step(x.to(DEV), y.to(DEV))
     assert int(eng.dropout_seed) == s0 + 1
+
+
+# ---------------------------------------------------------------------------------------------- 2-D branch / LwF
+def _lwf_fixture():
+    z, cfg = load_case('tiny_v12_lwf_b2')
+    sd, x, y = rebuild_inputs(cfg, z)
+    img = (vo.portable_uniform((cfg['batch'], 3, 224, 224), 9, 7001) * 2 - 1).float()
+    yi = (vo.portable_uniform((cfg['batch'],), 9, 7002) * 1000).long()
+    return z, cfg, sd, x, y, img, yi
+
+
+def test_forward_images_and_lwf_gradients_match_reference_golden():
+    """forward_images (vit_3d_2d_pretrain.py:435-451) and d(CE_voxel + 0.1 * CE_image)/d(params) (train_cls_voxel.py:250-267)."""
+    z, cfg, sd, x, y, img, yi = _lwf_fixture()
+    eng = make_engine(cfg, sd, image_branch=True)
+    B = cfg['batch']
+    lv = eng.forward(x.to(DEV)).cpu()
+    li = eng.images.forward(img.to(DEV)).cpu()
+    err_v = float(np.abs(lv.numpy() - z['logits']).max())
+    err_i = float(np.abs(li.numpy() - z['img_logits']).max())
+    assert err_v <= LOGIT_TOL and err_i <= LOGIT_TOL, f'logits err voxel {err_v:.3e} image {err_i:.3e}'
+    np.testing.assert_array_equal(li.argmax(1).numpy(), z['img_argmax'])
+    assert float(z['img_top2_gap'].min()) > 2 * LOGIT_TOL
+    loss_v = float(eng.cross_entropy(B, y.to(DEV)))
+    loss_i = float(eng.images.cross_entropy(B, yi.to(DEV), grad_scale=cfg['lambda_weight']))
+    assert abs(loss_v - float(z['loss_voxel'])) <= LOGIT_TOL and abs(loss_i - float(z['loss_image'])) <= LOGIT_TOL
+    assert abs(loss_v + cfg['lambda_weight'] * loss_i - float(z['loss'])) <= LOGIT_TOL
+    eng.zero_grad()
+    eng.backward(B)
+    eng.images.backward(B)                                    # accumulates on top of the voxel gradients
+    grads = {k: eng.arena.grad(k) for k in eng.shapes}
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    worst = check_grads_against_golden(z, grads, rtol=3e-3, atol=1e-7)
+    print(f'lwf: logits err voxel {err_v:.2e} image {err_i:.2e}, worst sampled grad err / rms {worst:.3f}')
+
+
+def test_drop_in_module_lwf_step_and_frozen_stem():
+    """model(voxel) + model.forward_images(images) under autograd, as the LwF loop uses them; with the reference's freezing of
+    the 2-D stem / head (pretrained checkpoints) those parameters get no gradient while the shared blocks still do."""
+    z, cfg, sd, x, y, img, yi = _lwf_fixture()
+    model = s3d.Feature3D_ViT2D_V2(embed_layer=s3d.VoxelEmbed(voxel_size=12, cell_size=4, patch_size=3, embed_dim=192),
+                                   n_classes=10, transformer_backbone='deit_tiny_patch16_224', pretrained=False,
+                                   pos_embedding='default')
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV)
+    pred, img_pred = model(x.to(DEV)), model.forward_images(img.to(DEV))
+    assert float((img_pred.detach().cpu() - torch.from_numpy(z['img_logits'])).abs().max()) <= LOGIT_TOL
+    loss = F.cross_entropy(pred, y.to(DEV)) + cfg['lambda_weight'] * F.cross_entropy(img_pred, yi.to(DEV))
+    assert abs(float(loss) - float(z['loss'])) <= LOGIT_TOL
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    check_grads_against_golden(z, grads, rtol=3e-3, atol=1e-7)
+    with pytest.raises(AssertionError, match="doesn't match model"):
+        model.forward_images(torch.zeros(1, 3, 192, 192, device=DEV))
+    # frozen 2-D stem / head
+    for p in model.parameters():
+        p.grad = None
+    for k in ('head.weight', 'head.bias', 'pos_embed', 'patch_embed.proj.weight', 'patch_embed.proj.bias'):
+        dict(model.named_parameters())[k].requires_grad = False
+    model._engine.images.frozen = True
+    F.cross_entropy(model.forward_images(img.to(DEV)), yi.to(DEV)).backward()
+    named = dict(model.named_parameters())
+    assert all(named[k].grad is None for k in ('head.weight', 'pos_embed', 'patch_embed.proj.weight'))
+    assert float(named['blocks.0.attn.qkv.weight'].grad.abs().sum()) > 0 and float(named['cls_token'].grad.abs().sum()) > 0
+    g = model._engine.arena
+    assert float(g.grad('head.weight').abs().sum()) == 0 and float(g.grad('patch_embed.proj.weight').abs().sum()) == 0
+
+
+def test_lwf_train_step_matches_oracle_adam_step():
+    z, cfg, sd, x, y, img, yi = _lwf_fixture()
+    eng = make_engine(cfg, sd, image_branch=True)
+    eng.set_optimizer(lr=1e-3)
+    loss, lv, li = eng.lwf_train_step(x.to(DEV), y.to(DEV), img.to(DEV), yi.to(DEV), lambda_weight=cfg['lambda_weight'])
+    assert abs(float(loss) - float(z['loss'])) <= LOGIT_TOL
+    _, _, _, grads = vo.lwf_loss_and_grads(sd, x, y, img, yi, lambda_weight=cfg['lambda_weight'], **fwd_kwargs(cfg))
+    after = eng.state_dict()
+    moved = 0
+    for k, g in grads.items():
+        want, m0, v0 = sd[k].clone(), torch.zeros_like(sd[k]), torch.zeros_like(sd[k])
+        vo.adam_step(want, g, m0, v0, 1, lr=1e-3)
+        # first Adam step = -lr * sign(g) wherever |g| >> eps: compare where the oracle gradient is not tiny
+        mask = g.abs() > 1e-6
+        if mask.any():
+            d = (after[k].cpu() - want.reshape(after[k].shape))[mask.reshape(after[k].shape)].abs().max()
+            assert float(d) <= 2.1e-3, f'{k}: {float(d):.3e}'          # a sign flip of a ~0 gradient moves 2*lr
+            moved += 1
+    assert moved > 100
+    assert float(eng.arena.g.abs().sum()) == 0.0                # Adam zeroed the gradients

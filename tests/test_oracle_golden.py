@@ -91,3 +91,24 @@ def test_adam_step_matches_torch_optim():
         opt.step()
         vo.adam_step(pp, g * step, m, v, step)
         np.testing.assert_allclose(pp.numpy(), q.detach().numpy(), rtol=0, atol=1e-7)
+
+
+def _lwf_inputs(cfg):
+    img = (vo.portable_uniform((cfg['batch'], 3, 224, 224), 9, 7001) * 2 - 1).float()
+    yi = (vo.portable_uniform((cfg['batch'],), 9, 7002) * 1000).long()
+    return img, yi
+
+
+def test_forward_images_and_lwf_loss_match_reference():
+    """2-D branch (vit_3d_2d_pretrain.py:435-451) + the LwF loss of train_cls_voxel.py:250-267, reference-generated fixture."""
+    z, cfg = load_case('tiny_v12_lwf_b2')
+    sd, x, y = rebuild_inputs(cfg, z)
+    img, yi = _lwf_inputs(cfg)
+    np.testing.assert_array_equal(yi.numpy(), z['img_target'])
+    lv, li, loss, grads = vo.lwf_loss_and_grads(sd, x, y, img, yi, lambda_weight=cfg['lambda_weight'], **fwd_kwargs(cfg))
+    np.testing.assert_allclose(lv.numpy(), z['logits'], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(li.numpy(), z['img_logits'], rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(li.argmax(1).numpy(), z['img_argmax'])
+    assert abs(float(loss) - float(z['loss'])) <= 1e-5
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    check_grads_against_golden(z, grads, rtol=1e-4, atol=1e-7)
