@@ -113,6 +113,22 @@ class AMSoftmaxLayer(nn.Module):
         nn.init.xavier_normal_(self.W, gain=1)
 
 
+def _fire_attention_hooks(model, bw):
+    """visualize_attention_map_voxel.py:120-146 registers forward hooks on model.blocks[i].attn and recomputes the attention
+    map from the hook's input (norm1(x)) with the module's own .qkv / .num_heads / .scale.  The blocks run inside the engine,
+    so the hooks are fired here with the same (module, (input,), output) triple a torch Block would have produced: input =
+    the saved LayerNorm-1 output, output = the attention branch's contribution x_mid - x_in.  No hooks -> no work."""
+    for i, blk in enumerate(model.blocks):
+        hooks = list(blk.attn._forward_hooks.values())
+        if not hooks:
+            continue
+        with torch.no_grad():
+            xn = (bw.xn1[i, 0].float() + bw.xn1[i, 1].float()).view(bw.Bb, bw.N, -1)
+            out = (bw.x_mid[i] - bw.x[i]).view(bw.Bb, bw.N, -1)
+        for h in hooks:
+            h(blk.attn, (xn,), out)
+
+
 _IMAGE_ONLY = ('patch_embed.', 'pos_embed', 'head.')                                  # not in the graph of model(voxel)
 _VOXEL_ONLY = ('voxel_embed.', 'voxel_pos_embed', 'voxel_head.', 'group_')            # not in the graph of forward_images
 
@@ -126,6 +142,7 @@ class _VoxelForward(torch.autograd.Function):
         eng.refresh_weight_planes()          # parameters may have been changed by a torch optimizer
         logits = eng.forward(x.contiguous().float()).clone()
         ctx.model, ctx.batch = model, x.shape[0]
+        _fire_attention_hooks(model, eng.workspace(x.shape[0]).last)
         return logits
 
     @staticmethod

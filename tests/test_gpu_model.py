@@ -320,3 +320,51 @@ def test_lwf_train_step_matches_oracle_adam_step():
             moved += 1
     assert moved > 100
     assert float(eng.arena.g.abs().sum()) == 0.0                # Adam zeroed the gradients
+
+
+def test_attention_visualisation_hooks_fire_with_reference_semantics():
+    """visualize_attention_map_voxel.py:120-146: forward hooks on model.blocks[i].attn that rebuild softmax(q k^T * scale) from
+    the hook input with the module's .qkv / .num_heads / .scale."""
+    z, cfg = load_case('tiny_v12_default_b3')
+    sd, x, y = rebuild_inputs(cfg, z)
+    model = s3d.Feature3D_ViT2D_V2(embed_layer=s3d.VoxelEmbed(voxel_size=12, cell_size=4, patch_size=3, embed_dim=192),
+                                   n_classes=10, transformer_backbone='deit_tiny_patch16_224', pretrained=False,
+                                   pos_embedding='default')
+    model.load_state_dict(sd, strict=True)
+    model.to(DEV).eval()
+    activation = {}
+
+    def get_attn_softmax(name):
+        def hook(m, inp, out):
+            with torch.no_grad():
+                t = inp[0]
+                B, N, C = t.shape
+                qkv = m.qkv(t).reshape(B, N, 3, m.num_heads, C // m.num_heads).permute(2, 0, 3, 1, 4)
+                activation[name] = ((qkv[0] @ qkv[1].transpose(-2, -1)) * m.scale).softmax(dim=-1)
+                activation[name + '/out'] = out
+        return hook
+
+    for idx, blk in enumerate(model.blocks.children()):
+        blk.attn.register_forward_hook(get_attn_softmax(f'attn{idx}'))
+    with torch.no_grad():
+        model(x.to(DEV))
+    assert len([k for k in activation if not k.endswith('/out')]) == 12
+    # oracle: the same maps from the fp32 restatement
+    kw = fwd_kwargs(cfg)
+    t = vo.voxel_embed(x, sd['voxel_embed.proj.conv3d_1.weight'], sd['voxel_embed.proj.conv3d_1.bias'], cfg['cell'])
+    t = t.flatten(2).transpose(1, 2)
+    t = torch.cat((sd['cls_token'].expand(x.shape[0], -1, -1), t), dim=1) + sd['voxel_pos_embed']
+    H = vo.BACKBONES[kw['backbone']]['num_heads']
+    for i in range(12):
+        pre = f'blocks.{i}.'
+        xn = vo.layer_norm(t, sd[pre + 'norm1.weight'], sd[pre + 'norm1.bias'])
+        B, N, C = xn.shape
+        qkv = vo.linear(xn, sd[pre + 'attn.qkv.weight'], sd[pre + 'attn.qkv.bias']).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+        ref = ((qkv[0] @ qkv[1].transpose(-2, -1)) * (C // H) ** -0.5).softmax(-1)
+        got = activation[f'attn{i}'].cpu()
+        assert got.shape == ref.shape == (B, H, N, N)
+        assert float((got - ref).abs().max()) < 2e-3, f'block {i}'
+        if i == 0:      # hook output = the attention branch's contribution attn(norm1(x))
+            want = vo.attention(xn, sd, pre + 'attn.', H)
+            assert float((activation['attn0/out'].cpu() - want).abs().max()) < 1e-3
+        t = vo.vit_block(t, sd, i, H)
