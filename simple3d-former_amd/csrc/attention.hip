@@ -662,7 +662,7 @@ int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
         case 48: return bwd_hd<48, 1>(a, s);
         case 64: return bwd_hd<64, 1>(a, s);
         case 96: return bwd_hd<96, 1>(a, s);
-        case 192: return bwd_hd<192, 2>(a, s);
+        case 192: return bwd_hd<192, 1>(a, s);   // 252 VGPRs, no recompute of S / dP per d-half: 262 -> 138 ms at cfg-3
         default: return bwd_hd<256, 2>(a, s);
     }
 }

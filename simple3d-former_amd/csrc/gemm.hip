@@ -610,6 +610,15 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
 static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
+    if (splitk <= 0 && a.K >= 16384 && a.M >= 128 && a.N >= 128) {
+        // long reductions (cfg-3: k = 188k token rows): 128x128 tiles re-read 4x less than 64x64 ones, and k is long enough
+        // to give every tile several k-slices -> size the split for >= 768 workgroups of 128x128
+        const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+        splitk = (int)((768 + tiles128 - 1) / tiles128);
+        const int maxk = a.K / 2048;
+        if (splitk > maxk) splitk = maxk;
+        if (splitk < 1) splitk = 1;
+    }
     if (splitk <= 0) {
         static const int target_env = env_int("S3D_GEMM_WGRAD_TARGET"), cap_env = env_int("S3D_GEMM_SPLITK_MAX");
         const long target = target_env > 0 ? target_env : (paired ? 256 : 512);
