@@ -13,6 +13,7 @@
 // reference; backward runs in plain bf16 on the hi planes.
 #include "attention.h"
 
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace {
@@ -46,12 +47,25 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
     }
 }
 
+// Transposed operand fragment: the 8 k-slots of this lane are tokens slot_key(s2, h2, 0..7) (two runs of four consecutive
+// rows of the staged [32 tokens][HD] tile), all at column `col` = 32*block + (lane & 31).  gfx950's LDS transpose read does the
+// gather: per 16-lane group, lane t passes the address of row (t >> 2), columns 4*(t & 3) .. +3 of a [4 rows][16 columns]
+// block (any row pitch) and receives column t of that block, rows 0..3 (probed: tools/probes/tr_probe.hip).  Two reads per
+// fragment instead of eight ds_read_u16 + packing; at cfg-3 the u16 gathers had made the backward kernels LDS-bound.
 template <int HD>
 __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2, int col) {
+    const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;          // h2 == g >> 1, col & 31 == lane & 31
+    int c = (col & ~31) + 16 * (g & 1) + 4 * (t & 3);
+    if (HD % 32 != 0) c = min(c, HD - 4);                                     // partial last d-block: those outputs are dropped
+    const int row = 16 * s2 + 4 * h2 + (t >> 2);
+    const unsigned addr = (unsigned)(uintptr_t)(lds + row * HD + c);
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(8 * HD * 2)
+                 : "memory");
     U128 u;
-    const int c = (HD % 32 == 0) ? col : min(col, HD - 1);   // partial last d-block: clamp (those outputs are dropped)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) u.h[j] = lds[slot_key(s2, h2, j) * HD + c];
+    u.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
     return u.v;
 }
 
@@ -127,11 +141,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m_i, mloc);                      // finite: every key tile holds >= 1 valid key
-        const float alpha = expf(m_i - mnew);                     // exp(-inf) = 0 on the first tile
+        const float alpha = fast_exp(m_i - mnew);                     // exp(-inf) = 0 on the first tile
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sv[r] = expf(sv[r] - mnew);                           // invalid keys: exp(-inf) = 0
+            sv[r] = fast_exp(sv[r] - mnew);                           // invalid keys: exp(-inf) = 0
             lsum += sv[r];
         }
         lsum += __shfl_xor(lsum, 32, 64);
@@ -270,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j;
                 const bool ok = (k0 + acc_row(r, h2)) < p.N;
-                const float pr = ok ? expf(sacc[r] * p.scale - lse_q) : 0.f;
+                const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
                     dpn = drop_keep(drop_key(p.drop_seed, p.drop_site),
@@ -308,8 +322,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
-    bf16_t* ldsQ = reinterpret_cast<bf16_t*>(smem) + wave * (2 * 32 * HD);
+    constexpr int WAVE_LDS = 2 * 32 * HD * 2 + 256;                   // Q | dO tiles (bf16) + lse / delta of the tile (fp32)
+    bf16_t* ldsQ = reinterpret_cast<bf16_t*>(smem + wave * WAVE_LDS);
     bf16_t* ldsDO = ldsQ + 32 * HD;
+    float* ldsR = reinterpret_cast<float*>(ldsDO + 32 * HD);          // [0..31] lse, [32..63] delta
     const int dblk0 = blockIdx.y * NDB;
 
     const int KT = (p.N + 31) / 32;
@@ -350,6 +366,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
         stage_tile<HD>(ldsQ, p.qkv_hi, p.ld, base, st_ld, q0, p.N, lane);
         stage_tile<HD>(ldsDO, p.dout, p.lddo, dobase, st_lddo, q0, p.N, lane);
         const int qrow = min(q0 + l31, p.N - 1);
+        // one coalesced load per query instead of 32 broadcast loads per lane inside the register loop below
+        ldsR[lane] = (h2 == 0 ? p.lse : p.delta)[(long)bh * p.N + qrow];
         const long qoff = base + (long)qrow * st_ld + h2 * 8;
         const long dooff = dobase + (long)qrow * st_lddo + h2 * 8;
         f32x16 sacc, dpacc;
@@ -360,6 +378,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             sacc = MFMA32(ld_frag(p.qkv_hi + qoff + 16 * s), kf[s], sacc);     // S  = Q . K^T   (col = key)
             dpacc = MFMA32(ld_frag(p.dout + dooff + 16 * s), vf[s], dpacc);    // dP = dO . V^T
         }
+        __syncthreads();                                          // tiles + lse / delta are staged
         U128 pf[2], dsf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -369,9 +388,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 const int q = q0 + acc_row(r, h2);
                 const bool ok = kok && (q < p.N);
                 const int qc = min(q, p.N - 1);
-                const float lse_r = p.lse[(long)bh * p.N + qc];
-                const float del_r = p.delta[(long)bh * p.N + qc];
-                const float pr = ok ? expf(sacc[r] * p.scale - lse_r) : 0.f;
+                const float lse_r = ldsR[acc_row(r, h2)];
+                const float del_r = ldsR[32 + acc_row(r, h2)];
+                const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_r) : 0.f;
                 float dm = 1.f;
                 if (p.drop_thr)
                     dm = drop_keep(drop_key(p.drop_seed, p.drop_site), ((unsigned long long)bh * p.N + qc) * p.N + krow_c, p.drop_thr)
@@ -379,7 +398,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 pf[s2].h[j] = f2bf(pr * dm);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - del_r) * p.scale);
             }
-        __syncthreads();
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
 #pragma unroll
@@ -487,7 +505,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j, key = acc_row(r, h2);
-                const float pr = key < p.N ? expf(sacc[r] * p.scale - lse_q) : 0.f;
+                const float pr = key < p.N ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
                     dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
@@ -534,7 +552,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
                 const int r = 8 * s2 + j, q = acc_row(r, h2);
                 const bool ok = tok_ok && (q < p.N);
                 const int qc = min(q, p.N - 1);
-                const float pr = ok ? expf(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
+                const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
                 float dm = 1.f;
                 if (p.drop_thr) dm = drop_keep(dkey, ((unsigned long long)bh * p.N + qc) * p.N + tok, p.drop_thr) ? p.drop_scale : 0.f;
                 pf[s2].h[j] = f2bf(pr * dm);
@@ -623,8 +641,8 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
         S3D_CHECK_LAUNCH("attention_bwd_dq");
     }
     {
-        const int lds = wpb * 2 * 32 * HD * 2;
-        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * 2 * 32 * HD * 2);
+        const int lds = wpb * (2 * 32 * HD * 2 + 256);
+        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * (2 * 32 * HD * 2 + 256));
         dim3 g2(grid.x, DSPLIT);
         hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dkv");

@@ -96,3 +96,7 @@ void s3d_set_error(const char* fmt, ...);
             return 2;                     \
         }                                 \
     } while (0)
+
+// exp(x) through the hardware base-2 exponential (v_exp_f32, ~1 ulp): one multiply + one transcendental instead of libm's
+// ~dozen VALU instructions.  exp2(-inf) = 0, which the softmax masking relies on.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
