@@ -52,17 +52,17 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
 // gather: per 16-lane group, lane t passes the address of row (t >> 2), columns 4*(t & 3) .. +3 of a [4 rows][16 columns]
 // block (any row pitch) and receives column t of that block, rows 0..3 (probed: tools/probes/tr_probe.hip).  Two reads per
 // fragment instead of eight ds_read_u16 + packing; at cfg-3 the u16 gathers had made the backward kernels LDS-bound.
-template <int HD>
+template <int HD, int PITCH = HD>
 __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2, int col) {
     const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;          // h2 == g >> 1, col & 31 == lane & 31
     int c = (col & ~31) + 16 * (g & 1) + 4 * (t & 3);
     if (HD % 32 != 0) c = min(c, HD - 4);                                     // partial last d-block: those outputs are dropped
     const int row = 16 * s2 + 4 * h2 + (t >> 2);
-    const unsigned addr = (unsigned)(uintptr_t)(lds + row * HD + c);
+    const unsigned addr = (unsigned)(uintptr_t)(lds + row * PITCH + c);
     u32x2 lo, hi;
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(lo), "=&v"(hi)
-                 : "v"(addr), "n"(8 * HD * 2)
+                 : "v"(addr), "n"(8 * PITCH * 2)
                  : "memory");
     U128 u;
     u.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
@@ -425,6 +425,443 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- backward: dK, dV, long sequences
+// Same mathematics as attn_bwd_dkv_kernel, organised for long sequences (cfg-3's encoder layer: N = 12 544 per (batch, head)).
+// There the per-wave kernel re-streams all of Q and dO from L2 / HBM once per 32-key tile, with both the LDS staging loads and
+// the MFMA row fragments coming from global memory and nothing prefetched (PMC: 71 % of wave cycles waiting, MFMA 7 % busy).
+// Here the four waves of a workgroup own four consecutive key tiles of one (batch, head) and SHARE one stream of query tiles:
+// all 256 threads stage Q / dO / lse / delta of tile t+1 into the other LDS buffer (prefetched into registers before tile t's
+// arithmetic), every operand of the MFMAs comes from LDS (row fragments by ds_read_b128 on a padded pitch, transposed fragments
+// by transpose reads), and there is one barrier per tile: a quarter of the staging traffic, no global fragment loads, and the
+// load latency hidden behind the previous tile.
+template <int HD, int DSPLIT>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT, CPR = HD / 8;
+    constexpr int PITCH = HD + 8;                                      // 16-byte pad: conflict-free ds_read_b128 of a column of rows
+    constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256;                // Q | dO tiles + lse / delta
+    constexpr int NCH = (32 * CPR + 255) / 256;                        // 16-byte chunks per thread per tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int dblk0 = blockIdx.y * NDB;
+
+    const int KT = (p.N + 31) / 32, KTB = (KT + 3) / 4;
+    const int bh = blockIdx.x / KTB;
+    int kt = (blockIdx.x % KTB) * 4 + wave;
+    const bool active = kt < KT;
+    kt = min(kt, KT - 1);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int k0 = kt * 32, krow = k0 + l31;
+    const bool kok = krow < p.N;
+    const int krow_c = min(krow, p.N - 1);
+    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+
+    bf16x8 kf[NS], vf[NS];
+    {
+        const long koff = base + p.D + (long)krow_c * st_ld + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            kf[s] = ld_frag(p.qkv_hi + koff + 16 * s);
+            vf[s] = ld_frag(p.qkv_hi + koff + p.D + 16 * s);
+        }
+    }
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+    const long dobase = (long)b * p.sb * p.lddo + h * HD;
+    const long st_lddo = p.st * p.lddo;
+    const int QT = (p.N + 31) / 32;
+
+    u32x4 rq[NCH], rd[NCH];
+    float rr = 0.f;
+    auto gload = [&](int q0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = min(tid + 256 * i, 32 * CPR - 1);
+            const int r = c / CPR, cc = c % CPR;
+            const long t = min(q0 + r, p.N - 1);
+            rq[i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + base + t * st_ld + cc * 8);
+            rd[i] = *reinterpret_cast<const u32x4*>(p.dout + dobase + t * st_lddo + cc * 8);
+        }
+        if (tid < 64) rr = (tid < 32 ? p.lse : p.delta)[(long)bh * p.N + min(q0 + (tid & 31), p.N - 1)];
+    };
+    auto lstore = [&](int buf) {
+        bf16_t* q = reinterpret_cast<bf16_t*>(smem + buf * BUF_BYTES);
+        bf16_t* dO = q + 32 * PITCH;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i;
+            if (32 * CPR % 256 == 0 || c < 32 * CPR) {
+                const int r = c / CPR, cc = c % CPR;
+                *reinterpret_cast<u32x4*>(q + r * PITCH + cc * 8) = rq[i];
+                *reinterpret_cast<u32x4*>(dO + r * PITCH + cc * 8) = rd[i];
+            }
+        }
+        if (tid < 64) reinterpret_cast<float*>(dO + 32 * PITCH)[tid] = rr;
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q0 = qt * 32;
+        const bool more = qt + 1 < QT;                                // block-uniform
+        if (more) gload(q0 + 32);
+        const bf16_t* ldsQ = reinterpret_cast<const bf16_t*>(smem + (qt & 1) * BUF_BYTES);
+        const bf16_t* ldsDO = ldsQ + 32 * PITCH;
+        const float* ldsR = reinterpret_cast<const float*>(ldsDO + 32 * PITCH);
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int off = l31 * PITCH + 16 * s + h2 * 8;
+            sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsQ + off), kf[s], sacc);      // S  = Q . K^T   (col = key)
+            dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsDO + off), vf[s], dpacc);   // dP = dO . V^T
+        }
+        U128 pf[2], dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j, qr = acc_row(r, h2);
+                const int q = q0 + qr;
+                const bool ok = kok && (q < p.N);
+                const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[qr]) : 0.f;
+                float dm = 1.f;
+                if (p.drop_thr)
+                    dm = drop_keep(dkey, ((unsigned long long)bh * p.N + min(q, p.N - 1)) * p.N + krow_c, p.drop_thr) ? p.drop_scale : 0.f;
+                pf[s2].h[j] = f2bf(pr * dm);
+                dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[32 + qr]) * p.scale);
+            }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int col = (dblk0 + d) * 32 + l31;
+                dv[d] = MFMA32((gather_frag<HD, PITCH>(ldsDO, s2, h2, col)), pf[s2].v, dv[d]);    // dV^T = dO^T . P
+                dk[d] = MFMA32((gather_frag<HD, PITCH>(ldsQ, s2, h2, col)), dsf[s2].v, dk[d]);    // dK^T = Q^T . dS
+            }
+        if (more) lstore((qt + 1) & 1);
+        __syncthreads();
+    }
+    if (active && kok) {
+        const long orow = ((long)b * p.sb + (long)krow * p.st) * p.lddq + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } a, v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
+                const int dcol = (dblk0 + d) * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                const long off = orow + dcol;
+                *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
+                *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- long sequences: shared key stream
+// Counterparts of attn_fwd_kernel / attn_bwd_dq_kernel organised like attn_bwd_dkv_coop_kernel: the four waves of a workgroup own
+// four consecutive QUERY tiles of one (batch, head) and share one double-buffered stream of key tiles (K and V rows, hi and lo
+// planes in the split forward), staged by all 256 threads with the next tile prefetched into registers.
+template <int HD, int NT_>
+struct CoopStage {                                                     // NT_ tiles of [32 rows][HD] bf16 per buffer, padded pitch
+    static constexpr int CPR = HD / 8, PITCH = HD + 8, TILE = 32 * PITCH;
+    static constexpr int NCH = (32 * CPR + 255) / 256;
+    static constexpr int BUF_BYTES = NT_ * TILE * 2;
+    u32x4 r[NT_][NCH];
+    __device__ __forceinline__ void gload(const bf16_t* const (&src)[NT_], const long (&rowoff)[NT_], const long (&pitch)[NT_], int t0,
+                                          int N, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = min(tid + 256 * i, 32 * CPR - 1);
+            const int row = c / CPR, cc = c % CPR;
+            const long t = min(t0 + row, N - 1);
+#pragma unroll
+            for (int k = 0; k < NT_; ++k) r[k][i] = *reinterpret_cast<const u32x4*>(src[k] + rowoff[k] + t * pitch[k] + cc * 8);
+        }
+    }
+    __device__ __forceinline__ void lstore(unsigned char* buf, int tid) const {
+        bf16_t* b = reinterpret_cast<bf16_t*>(buf);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = tid + 256 * i;
+            if (32 * CPR % 256 == 0 || c < 32 * CPR) {
+                const int row = c / CPR, cc = c % CPR;
+#pragma unroll
+                for (int k = 0; k < NT_; ++k) *reinterpret_cast<u32x4*>(b + k * TILE + row * PITCH + cc * 8) = r[k][i];
+            }
+        }
+    }
+};
+
+template <int HD, bool SPLIT>
+__global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
+    using ST = CoopStage<HD, 2 * NPL>;                                 // K_hi [K_lo] V_hi [V_lo]
+    constexpr int PITCH = ST::PITCH, TILE = ST::TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+
+    const int QT = (p.N + 31) / 32, QTB = (QT + 3) / 4;
+    const int bh = blockIdx.x / QTB;
+    int qt = (blockIdx.x % QTB) * 4 + wave;
+    const bool active = qt < QT;
+    qt = min(qt, QT - 1);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int q0 = qt * 32, qrow = q0 + l31;
+    const bool qok = qrow < p.N;
+    const int qrow_c = min(qrow, p.N - 1);
+    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+
+    bf16x8 qh[NS], ql[SPLIT ? NS : 1];
+    {
+        const long off = base + (long)qrow_c * st_ld + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qh[s] = ld_frag(p.qkv_hi + off + 16 * s);
+            if constexpr (SPLIT) ql[s] = ld_frag(p.qkv_lo + off + 16 * s);
+        }
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+
+    ST st;
+    const bf16_t* src[2 * NPL];
+    long rowoff[2 * NPL], pitch[2 * NPL];
+#pragma unroll
+    for (int k = 0; k < 2 * NPL; ++k) {
+        src[k] = (SPLIT && (k & 1)) ? p.qkv_lo : p.qkv_hi;
+        rowoff[k] = base + ((SPLIT ? (k >> 1) : k) + 1) * (long)p.D;   // K then V
+        pitch[k] = st_ld;
+    }
+    const int KT = (p.N + 31) / 32;
+    st.gload(src, rowoff, pitch, 0, p.N, tid);
+    st.lstore(smem, tid);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = kt * 32;
+        const bool more = kt + 1 < KT;
+        if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
+        const bf16_t* tb = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
+        const bf16_t* ldsKh = tb;
+        const bf16_t* ldsKl = tb + TILE;                               // split only
+        const bf16_t* ldsVh = tb + NPL * TILE;
+        const bf16_t* ldsVl = ldsVh + TILE;                            // split only
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int off = l31 * PITCH + 16 * s + h2 * 8;
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(ldsKh + off);
+            if constexpr (SPLIT) {
+                const bf16x8 kl = *reinterpret_cast<const bf16x8*>(ldsKl + off);
+                sacc = MFMA32(kl, qh[s], sacc);
+                sacc = MFMA32(kh, ql[s], sacc);
+            }
+            sacc = MFMA32(kh, qh[s], sacc);
+        }
+        float sv[16], mloc = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (k0 + acc_row(r, h2)) < p.N;
+            sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
+            mloc = fmaxf(mloc, sv[r]);
+        }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m_i, mloc);
+        const float alpha = fast_exp(m_i - mnew);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sv[r] = fast_exp(sv[r] - mnew);
+            lsum += sv[r];
+        }
+        lsum += __shfl_xor(lsum, 32, 64);
+        l_i = l_i * alpha + lsum;
+        m_i = mnew;
+        if (p.drop_thr) {
+            const unsigned long long rowbase = ((unsigned long long)bh * p.N + qrow_c) * p.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                sv[r] = drop_keep(dkey, rowbase + (k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
+        }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        U128 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hi, lo;
+                split_bf16(sv[8 * s2 + j], hi, lo);
+                ph[s2].h[j] = hi;
+                pl[s2].h[j] = lo;
+            }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 vh = gather_frag<HD, PITCH>(ldsVh, s2, h2, d * 32 + l31);
+                if constexpr (SPLIT) {
+                    const bf16x8 vl = gather_frag<HD, PITCH>(ldsVl, s2, h2, d * 32 + l31);
+                    o[d] = MFMA32(vl, ph[s2].v, o[d]);
+                    o[d] = MFMA32(vh, pl[s2].v, o[d]);
+                }
+                o[d] = MFMA32(vh, ph[s2].v, o[d]);
+            }
+        if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
+        __syncthreads();
+    }
+    if (active && qok) {
+        const float inv = 1.0f / l_i;
+        const long orow = ((long)b * p.sb + (long)qrow * p.st) * p.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split_bf16(o[d][4 * c + i] * inv, hi.h[i], lo.h[i]);
+                const int dcol = d * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                const long off = orow + dcol;
+                *reinterpret_cast<uint2*>(p.out_hi + off) = hi.u;
+                if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
+            }
+        if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i + logf(l_i);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
+    using ST = CoopStage<HD, 2>;                                       // K, V
+    constexpr int PITCH = ST::PITCH, TILE = ST::TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h2 = lane >> 5, l31 = lane & 31;
+
+    const int QT = (p.N + 31) / 32, QTB = (QT + 3) / 4;
+    const int bh = blockIdx.x / QTB;
+    int qt = (blockIdx.x % QTB) * 4 + wave;
+    const bool active = qt < QT;
+    qt = min(qt, QT - 1);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int q0 = qt * 32, qrow = q0 + l31;
+    const bool qok = qrow < p.N;
+    const int qrow_c = min(qrow, p.N - 1);
+    const long tokrow = (long)b * p.sb + (long)qrow_c * p.st;
+    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+
+    bf16x8 qf[NS], dof[NS];
+    float delta = 0.f;
+    {
+        const long off = base + (long)qrow_c * st_ld + h2 * 8;
+        const long doff = tokrow * p.lddo + h * HD + h2 * 8;
+        const long ooff = tokrow * p.ldo + h * HD + h2 * 8;
+        const float lo_on = p.out_lo ? 1.f : 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            qf[s] = ld_frag(p.qkv_hi + off + 16 * s);
+            dof[s] = ld_frag(p.dout + doff + 16 * s);
+            U128 a, ol, d;
+            a.v = ld_frag(p.out_hi + ooff + 16 * s);
+            ol.v = ld_frag((p.out_lo ? p.out_lo : p.out_hi) + ooff + 16 * s);
+            d.v = dof[s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
+        }
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    const float lse_q = p.lse[(long)bh * p.N + qrow_c];
+    if (active && qok && h2 == 0) p.delta[(long)bh * p.N + qrow] = delta;
+
+    f32x16 dq[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    ST st;
+    const bf16_t* src[2] = {p.qkv_hi, p.qkv_hi};
+    long rowoff[2] = {base + p.D, base + 2 * (long)p.D}, pitch[2] = {st_ld, st_ld};
+    const int KT = (p.N + 31) / 32;
+    st.gload(src, rowoff, pitch, 0, p.N, tid);
+    st.lstore(smem, tid);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = kt * 32;
+        const bool more = kt + 1 < KT;
+        if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
+        const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
+        const bf16_t* ldsV = ldsK + TILE;
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int off = l31 * PITCH + 16 * s + h2 * 8;
+            sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsK + off), qf[s], sacc);      // S^T  = K . Q^T
+            dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsV + off), dof[s], dpacc);   // dP^T = V . dO^T
+        }
+        U128 dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j;
+                const bool ok = (k0 + acc_row(r, h2)) < p.N;
+                const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+                float dpn = dpacc[r];
+                if (p.drop_thr)
+                    dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N + (k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
+            }
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                dq[d] = MFMA32((gather_frag<HD, PITCH>(ldsK, s2, h2, d * 32 + l31)), dsf[s2].v, dq[d]);   // dQ^T = K^T . dS^T
+        if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
+        __syncthreads();
+    }
+    if (active && qok) {
+        const long orow = tokrow * p.lddq + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
+                const int dcol = d * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                *reinterpret_cast<uint2*>(p.dqkv + orow + dcol) = v.u;
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------- backward, N <= 32: one launch
 // With a single 32-token tile per (batch, head) -- cfg-1/2: N = 26 -- the two backward kernels above are each a few
 // microseconds of launch ramp and memory latency around a handful of MFMAs.  Here one wave does both for its (batch, head):
@@ -596,6 +1033,13 @@ int waves_per_block(long W) {
     return W <= 1024 ? 1 : (W <= 2048 ? 2 : 4);
 }
 
+// Cooperative (shared-stream) kernels pay off once a (batch, head) has enough tiles to stream; S3D_ATTN_COOP=0/1 forces.
+bool use_coop(int N) {
+    static const int env = getenv("S3D_ATTN_COOP") ? atoi(getenv("S3D_ATTN_COOP")) : -1;
+    if (env == 0) return false;
+    return env > 0 || (N + 31) / 32 >= 8;
+}
+
 template <typename K>
 void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -604,6 +1048,21 @@ void set_lds(K kern, int bytes) {
 template <int HD>
 int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
+    if (use_coop(a.N)) {                                        // long sequences: four query tiles share one key stream
+        const int QT = (a.N + 31) / 32;
+        dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
+        if (split) {
+            const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
+            set_lds(attn_fwd_coop_kernel<HD, true>, lds);
+            hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true>), g, dim3(256), lds, s, a);
+        } else {
+            const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
+            set_lds(attn_fwd_coop_kernel<HD, false>, lds);
+            hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false>), g, dim3(256), lds, s, a);
+        }
+        S3D_CHECK_LAUNCH("attention_fwd_coop");
+        return 0;
+    }
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
     if (split) {
@@ -634,13 +1093,26 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
             return 0;
         }
     }
-    {
+    const int KT = (a.N + 31) / 32;
+    if (use_coop(a.N)) {
+        const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
+        set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
+        dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
+        hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
+        S3D_CHECK_LAUNCH("attention_bwd_dq_coop");
+    } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dq");
     }
-    {
+    if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
+        const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256);
+        set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
+        dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
+        hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+        S3D_CHECK_LAUNCH("attention_bwd_dkv_coop");
+    } else {
         const int lds = wpb * (2 * 32 * HD * 2 + 256);
         set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * (2 * 32 * HD * 2 + 256));
         dim3 g2(grid.x, DSPLIT);
