@@ -1036,8 +1036,9 @@ int waves_per_block(long W) {
 // Cooperative (shared-stream) kernels pay off once a (batch, head) has enough tiles to stream; S3D_ATTN_COOP=0/1 forces.
 bool use_coop(int N) {
     static const int env = getenv("S3D_ATTN_COOP") ? atoi(getenv("S3D_ATTN_COOP")) : -1;
+    static const int min_tiles = getenv("S3D_ATTN_COOP_MIN_TILES") ? atoi(getenv("S3D_ATTN_COOP_MIN_TILES")) : 6;
     if (env == 0) return false;
-    return env > 0 || (N + 31) / 32 >= 8;
+    return env > 0 || (N + 31) / 32 >= min_tiles;
 }
 
 template <typename K>
