@@ -13,6 +13,7 @@
 #include "gemm.h"
 
 #include <stdio.h>
+#include <stdint.h>
 #include <stdlib.h>
 
 #include <array>
@@ -22,6 +23,11 @@
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch, keyed by kernel
 // instantiation.  Off by default; never active during graph capture.
+static int env_int(const char* name) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : -1;
+}
+
 namespace {
 struct ProfSlot { long long key; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -468,6 +474,134 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large NT GEMMs (cfg-3: M = 188 k rows): 128x128 tile whose k-tiles arrive by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave
+// instruction straight into LDS, no staging VGPRs, no ds_write pass).  The DMA writes lane-linear, so the XOR swizzle of the
+// [rows][64] bf16 tile is applied on the SOURCE side: the lane that fills 16-byte slot c of row r fetches global chunk
+// c ^ swz(r), and read_frag() finds chunk kc at slot kc ^ swz(r) as before.  NS stages are in flight; hipcc does not count
+// asm loads, so each wave retires its own pieces with a counted s_waitcnt before the one barrier per k-tile.
+__device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <bool SPLIT, int EPI, int NS, int BK>
+__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 128, BN = 128, NPL = SPLIT ? 2 : 1;
+    constexpr int ROWB = BK * 2;                                       // bytes per tile row: 128 (BK = 64) or 64 (BK = 32)
+    constexpr int CPRW = ROWB / 16, RPP = 1024 / ROWB;                 // 16-byte chunks per row, rows per 1 KB DMA piece
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + B_BYTES);
+    constexpr int PPW = STAGE / 1024 / 4;                              // DMA pieces per wave per stage
+    constexpr int FM = BM / 32, FN = BN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    {
+        const int ntile = ntx * nty;
+        const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    const int ntiles = p.K / BK;                                       // K % 64 == 0 (checked by the launcher)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    // 16-byte slot swizzle: 128-byte rows as in gemm_body; 64-byte rows (16 banks) repeat every 4 rows -> xor with (r >> 2) & 3
+    auto swz = [](int r) { return BK == 64 ? ((r ^ (r >> 3)) & 7) : ((r >> 2) & 3); };
+    auto frag = [&](const unsigned char* lds, int r, int kc) {
+        return *reinterpret_cast<const bf16x8*>(lds + r * ROWB + ((kc ^ swz(r)) << 4));
+    };
+
+    // this lane's source pointer (k-tile 0) for each of its wave's pieces
+    const bf16_t* gp[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;                              // STAGE = [A_hi][A_lo?][B_hi][B_lo?], 1 KB = RPP rows each
+        constexpr int PA = A_BYTES / 1024, PB = B_BYTES / 1024;        // pieces per plane tile
+        int q = piece;
+        const bool isB = q >= NPL * PA;
+        if (isB) q -= NPL * PA;
+        const int pl = q / (isB ? PB : PA);                            // 0 = hi, 1 = lo
+        const int rb = q % (isB ? PB : PA);
+        const int r = rb * RPP + lane / CPRW, c = lane % CPRW;
+        const bf16_t* base = isB ? (pl ? p.B_lo : p.B_hi) : (pl ? p.A_lo : p.A_hi);
+        const long ld = isB ? p.ldb : p.lda;
+        const int row = isB ? min(n0 + r, p.N - 1) : min(m0 + r, p.M - 1);
+        gp[j] = base + (long)row * ld + ((c ^ swz(r)) << 3);
+    }
+    auto issue = [&](int t) {                                          // k-tile t -> buffer t % NS
+        const unsigned dst = lds0 + (unsigned)((t % NS) * STAGE + wave * PPW * 1024);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) glds16(gp[j] + (long)t * BK, dst + j * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < ntiles) issue(u);
+    for (int t = 0; t < ntiles; ++t) {
+        // stage t is complete once at most the younger stages' pieces of this wave are outstanding
+        if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // everyone's pieces landed; buffer (t-1) % NS is free
+        if (t + NS - 1 < ntiles) issue(t + NS - 1);
+        const unsigned char* sA = smem + (t % NS) * STAGE;
+        const unsigned char* sB = sA + NPL * A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            const int kc = ks * 4 + (lane >> 4);
+            bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+                a_hi[i] = frag(sA, r, kc);
+                if constexpr (SPLIT) a_lo[i] = frag(sA + A_BYTES, r, kc);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * (BN / 2) + j * 16 + (lane & 15);
+                b_hi[j] = frag(sB, r, kc);
+                if constexpr (SPLIT) b_lo[j] = frag(sB + B_BYTES, r, kc);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // staged epilogue (see gemm_body)
+    constexpr int LDC = BN + 4, CPR = BN / 8;
+    float* ct = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int c = tid; c < BM * CPR; c += 256) {
+        const int row = c / CPR, col = (c % CPR) * 8;
+        float v[8];
+        ld_f32<8>(v, ct + row * LDC + col);
+        epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
+    }
+}
+
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -545,6 +679,39 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     return 0;
 }
 
+template <bool SPLIT, int EPI>
+int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
+    // two workgroups per CU matter more than stage depth.  Measured at M = 65 536, deit_base shapes, TFLOP/s algorithmic
+    // (register-staged kernel -> this one): plain bf16 qkv 575 -> 625, fc2 692 -> 761 with two 32 KB stages of k = 64 (three
+    // stages = 96 KB = one workgroup per CU: 472 / 618, slower than register staging; four stages of k = 32: 529 / 661);
+    // split-bf16 (two planes per operand) qkv 233 -> 303, proj 190 -> 249, fc1 207 -> 266, fc2 257 -> 328 with two 32 KB
+    // stages of k = 32 (two 64 KB stages of k = 64, one workgroup per CU: 250 / 208 / 223 / 291).
+    constexpr int NS = 2, BK = SPLIT ? 32 : 64;
+    constexpr int STAGE = (SPLIT ? 2 : 1) * 256 * BK * 2;
+    constexpr int LDS = cmax(NS * STAGE, 128 * 132 * 4);
+    static bool attr_set = false;
+    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, 1);
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = 300000000000LL + 128 * 100000000LL + 128 * 100000LL + (SPLIT ? 100 : 0) + EPI;
+        sl.flops = 2.0 * a.M * a.N * a.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+    }
+    S3D_CHECK_LAUNCH("gemm_nt_dma");
+    return 0;
+}
+
 template <bool TA, bool TB, bool SPLIT, int EPI>
 int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
     switch (tile) {
@@ -557,6 +724,8 @@ int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
 
 template <bool SPLIT, int EPI>
 int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
+    static const int dma = env_int("S3D_GEMM_DMA");                  // S3D_GEMM_DMA=0: register-staged 128x128 kernel instead
+    if (dma != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
     return launch_tiles<false, false, SPLIT, EPI>(tile, a, 1, s);
 }
 
@@ -576,10 +745,6 @@ int launch_nt(int epi, int tile, const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // tuning overrides (tools/gemm_bench.py): S3D_GEMM_TILE=0|1|2, S3D_GEMM_SPLITK=n
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : -1;
-}
 
 int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
     static const int forced = env_int("S3D_GEMM_TILE");
