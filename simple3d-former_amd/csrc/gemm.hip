@@ -488,10 +488,11 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
-template <bool SPLIT, int EPI, int NS, int BK>
+template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BM = 128, BN = 128, NPL = SPLIT ? 2 : 1;
+    constexpr int NPL = SPLIT ? 2 : 1;
+    static_assert((NPL * (BM + BN) * BK * 2) % 4096 == 0, "a stage must split into whole 1 KB pieces per wave");
     constexpr int ROWB = BK * 2;                                       // bytes per tile row: 128 (BK = 64) or 64 (BK = 32)
     constexpr int CPRW = ROWB / 16, RPP = 1024 / ROWB;                 // 16-byte chunks per row, rows per 1 KB DMA piece
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + B_BYTES);
@@ -685,7 +686,9 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     // (register-staged kernel -> this one): plain bf16 qkv 575 -> 625, fc2 692 -> 761 with two 32 KB stages of k = 64 (three
     // stages = 96 KB = one workgroup per CU: 472 / 618, slower than register staging; four stages of k = 32: 529 / 661);
     // split-bf16 (two planes per operand) qkv 233 -> 303, proj 190 -> 249, fc1 207 -> 266, fc2 257 -> 328 with two 32 KB
-    // stages of k = 32 (two 64 KB stages of k = 64, one workgroup per CU: 250 / 208 / 223 / 291).
+    // stages of k = 32 (two 64 KB stages of k = 64, one workgroup per CU: 250 / 208 / 223 / 291).  On the small cfg-2 tiles
+    // (64x64 / 32x64 / 32x32, three k = 32 stages) the same kernel is neutral (12.3 / 7.5 / 18.8 / 21.4 us vs 12.0 / 7.9 /
+    // 18.6 / 19.9 us): those launches are not limited by how the tiles are staged.
     constexpr int NS = 2, BK = SPLIT ? 32 : 64;
     constexpr int STAGE = (SPLIT ? 2 : 1) * 256 * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, 128 * 132 * 4);
