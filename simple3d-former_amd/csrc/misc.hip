@@ -88,22 +88,27 @@ __global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------- pos / cls / bias grads
-// One wave per (64 feature columns, slice of groups): the wave walks all tokens, so the bias gradient (a sum over every
-// non-cls token) is accumulated in registers and costs ONE atomic per column per workgroup instead of one per token --
-// same-address fp32 atomics serialise, and the per-token version spent most of its 17 us there.
+// One wave per (token, 64 feature columns, slice of groups): a thread sums its slice's rows of one (token, column) with
+// independent loads and issues one atomic per destination.  Few slices (<= 4) keep the same-address depth low -- the bias
+// gradient collects (ntok - 1) * slices atomics per column, and same-address fp32 atomics serialise at ~12 ns each -- while
+// ntok * D / 64 * slices waves keep the loads parallel (a token loop inside the thread ran 26 dependent rounds: 14 us).
 __global__ __launch_bounds__(64) void posgrad_kernel(const PosGradArgs p, long gchunk) {
-    const int d = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.x, d = blockIdx.y * 64 + threadIdx.x;
     if (d >= p.D) return;
-    const long g0 = (long)blockIdx.y * gchunk, g1 = min(p.groups, g0 + gchunk);
-    float bias_acc = 0.f;
-    for (int t = 0; t < p.ntok; ++t) {
-        float s = 0.f;
-        for (long g = g0; g < g1; ++g) s += p.dx[(g * p.ntok + t) * p.D + d];
-        if (p.dpos) atomic_add_f32(p.dpos + (long)t * p.D + d, s);
-        if (t == 0) { if (p.dcls) atomic_add_f32(p.dcls + d, s); }
-        else bias_acc += s;
+    const long g0 = (long)blockIdx.z * gchunk, g1 = min(p.groups, g0 + gchunk);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long g = g0; g < g1; g += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long gg = g + u;
+            const float v = p.dx[(min(gg, g1 - 1) * p.ntok + t) * p.D + d];
+            acc[u] += gg < g1 ? v : 0.f;
+        }
     }
-    if (p.dbias) atomic_add_f32(p.dbias + d, bias_acc);
+    const float s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    if (p.dpos) atomic_add_f32(p.dpos + (long)t * p.D + d, s);
+    if (t == 0) { if (p.dcls) atomic_add_f32(p.dcls + d, s); }
+    else if (p.dbias) atomic_add_f32(p.dbias + d, s);
 }
 
 // ------------------------------------------------------------------------------------------- token assemble (pass 2)
@@ -374,11 +379,13 @@ int s3d_launch_patchify(const float* img, bf16_t* a_hi, bf16_t* a_lo, long lda, 
 }
 
 int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
-    long gs = a.groups < 64 ? a.groups : 64;   // group slices
+    long gs = (a.groups + 15) / 16;            // >= 16 rows per thread
+    if (gs > 4) gs = 4;
     if (gs < 1) gs = 1;
     const long gchunk = (a.groups + gs - 1) / gs;
     gs = (a.groups + gchunk - 1) / gchunk;
-    hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)((a.D + 63) / 64), (unsigned)gs), dim3(64), 0, s, a, gchunk);
+    S3D_REQUIRE(a.ntok <= 65535, "posgrad: ntok=%d too large", a.ntok);
+    hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)a.ntok, (unsigned)((a.D + 63) / 64), (unsigned)gs), dim3(64), 0, s, a, gchunk);
     S3D_CHECK_LAUNCH("posgrad");
     return 0;
 }
