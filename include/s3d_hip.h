@@ -70,6 +70,10 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int sp
 int s3d_prof_enable(int on);
 int s3d_prof_collect(double* rows, int cap);
 int s3d_prof_event_overhead(s3d_stream_t stream, double* microseconds);
+/* Difference timing: while key != 0, launches of the GEMM instantiation with that key (as reported by s3d_prof_collect) are
+ * suppressed (they return 0 without enqueuing anything).  bench.py captures the training step once with and once without the
+ * dominant kernel and takes (t_full - t_without) / launches as that kernel's duration inside the busy, gap-free graph. */
+int s3d_prof_skip(double key);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps=1e-6) of timm Block.norm1/.norm2 and VisionTransformer.norm (vit_3d_2d_pretrain.py:287,469). */

@@ -273,6 +273,7 @@ size_t s3d_sizeof(const char* n) {
 
 int s3d_prof_enable(int on) { s3d_gemm_prof_enable(on != 0); return 0; }
 int s3d_prof_collect(double* rows, int cap) { return s3d_gemm_prof_collect(rows, cap); }
+int s3d_prof_skip(double key) { s3d_gemm_prof_skip((long long)key); return 0; }
 int s3d_prof_event_overhead(s3d_stream_t stream, double* us) {
     S3D_REQUIRE(us != nullptr, "s3d_prof_event_overhead: null result pointer");
     constexpr int R = 33;

@@ -26,3 +26,4 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad
 // bench-only timing of every GEMM launch with HIP events on the launch stream (see gemm.hip)
 void s3d_gemm_prof_enable(bool on);
 int s3d_gemm_prof_collect(double* rows, int cap);
+void s3d_gemm_prof_skip(long long key);
