@@ -493,3 +493,18 @@ class PointEngine:
         self.backward(B)
         self.sgd_step()
         return loss
+
+    def capture_train_step(self, x, target, starts):
+        """Captures train_step over the given (static) input buffers into a HIP graph -- the step enqueues ~400 kernels and no
+        host synchronisation, so replaying it removes the Python / launch pacing.  Copy new batches (and FPS start indices)
+        into x / target / starts, then graph.replay().  Returns (graph, loss scalar tensor)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up on a side stream: kernel attributes, workspaces
+            self.train_step(x, target, starts)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = self.train_step(x, target, starts)
+        return graph, loss

@@ -29,13 +29,22 @@ def main():
     for _ in range(3):
         loss = eng.train_step(x, y, starts)
     torch.cuda.synchronize()
+    use_graph = os.environ.get('GRAPH', '1') != '0'
+    if use_graph:                                   # the step has no host synchronisation: capture it once, replay it
+        graph, loss = eng.capture_train_step(x, y, starts)
+        step = graph.replay
+    else:
+        def step():
+            return eng.train_step(x, y, starts)
+    step()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = eng.train_step(x, y, starts)
+        step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     out = dict(config=name, batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
-               points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='eager')
+               points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='hipGraph replay' if use_graph else 'eager')
     print(json.dumps(out))
 
 
