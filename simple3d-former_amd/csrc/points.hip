@@ -8,6 +8,9 @@
 // would flip near-ties at the 16th/17th neighbour.
 #include "kernels.h"
 
+#include <stdint.h>
+#include <stdlib.h>
+
 namespace {
 
 __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
@@ -292,6 +295,194 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int ld, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------- BatchNorm, vectorised (C % 4 == 0)
+// The element-indexed kernels above pay a 64-bit division per element, scalar 4-byte accesses and (backward) two fp64
+// divisions per element: ~2.5 TB/s on streams that are pure HBM traffic.  Here a thread owns ONE quad of channels for the
+// whole launch (q = tid % (C/4), row lane = tid / (C/4)), so every per-channel constant lives in registers, rows are walked
+// with a fixed stride and all accesses are 16-byte (8-byte for bf16 / 4-byte for the arg-max bytes).
+struct BnLane {
+    int q, sub, rpb;      // channel quad, row lane within the block, rows per block iteration
+    bool on;
+};
+__device__ __forceinline__ BnLane bn_lane(int C) {
+    BnLane l;
+    const int c4 = C >> 2;
+    l.rpb = 256 / c4;
+    l.q = threadIdx.x % c4;
+    l.sub = threadIdx.x / c4;
+    l.on = l.sub < l.rpb;
+    return l;
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// block-level fold of the per-thread (sum, sum-of-products) partials of one channel quad, then ONE fp64 atomic per channel
+// per workgroup (every row lane adding its own partial put 256/(C/4) x more same-address atomics on the sums than the scalar
+// kernel had and made the vector kernels slower than it)
+__device__ __forceinline__ void bn_fold_sums(const BnLane& l, int C, const double (&s)[4], const double (&q)[4], double* __restrict__ sums) {
+    __shared__ double red[2048];                       // [rpb][2C]: (256 / (C/4)) * 2C = 2048 doubles for any C
+    if (l.on) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            red[l.sub * 2 * C + 4 * l.q + i] = s[i];
+            red[l.sub * 2 * C + C + 4 * l.q + i] = q[i];
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) {
+        double t = 0.0;
+        for (int r = 0; r < l.rpb; ++r) t += red[r * 2 * C + j];
+        atomicAdd(sums + j, t);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_vec_kernel(const float* __restrict__ x, long rows, int C, int ld, double* __restrict__ sums) {
+    const BnLane l = bn_lane(C);
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (l.on)
+        for (long r = (long)blockIdx.x * l.rpb + l.sub; r < rows; r += (long)gridDim.x * l.rpb) {
+            const f32x4 v = ld4(x + r * ld + 4 * l.q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const double d = v[i]; s[i] += d; q[i] += d * d; }
+        }
+    bn_fold_sums(l, C, s, q, sums);
+}
+
+__global__ __launch_bounds__(256) void bn_relu_vec_kernel(const float* __restrict__ x, long rows, int C, int ld, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ y,
+                                                          bf16_t* __restrict__ y_hi, bf16_t* __restrict__ y_lo, int ldo) {
+    const BnLane l = bn_lane(C);
+    if (!l.on) return;
+    const int c = 4 * l.q;
+    const f32x4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    for (long r = (long)blockIdx.x * l.rpb + l.sub; r < rows; r += (long)gridDim.x * l.rpb) {
+        const f32x4 v = ld4(x + r * ld + c);
+        f32x4 o;
+        union { u32x2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[i] = fmaxf((v[i] - m[i]) * rs[i] * g[i] + be[i], 0.f);         // same expression order as the scalar kernel
+            split_bf16(o[i], hi.h[i], lo.h[i]);
+        }
+        if (y) *reinterpret_cast<f32x4*>(y + r * ldo + c) = o;
+        if (y_hi) {
+            *reinterpret_cast<u32x2*>(y_hi + r * ldo + c) = hi.u;
+            if (y_lo) *reinterpret_cast<u32x2*>(y_lo + r * ldo + c) = lo.u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_max_vec_kernel(const float* __restrict__ x, long groups, int K, int C,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              float* __restrict__ out, unsigned char* __restrict__ arg) {
+    const BnLane l = bn_lane(C);
+    if (!l.on) return;
+    const int c = 4 * l.q;
+    const f32x4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = rs[i] * g[i]; b[i] = be[i] - m[i] * a[i]; }
+    for (long s = (long)blockIdx.x * l.rpb + l.sub; s < groups; s += (long)gridDim.x * l.rpb) {
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bk[4] = {0, 0, 0, 0};
+        for (int k = 0; k < K; ++k) {
+            const f32x4 v = ld4(x + (s * K + k) * (long)C + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float t = fmaxf(v[i] * a[i] + b[i], 0.f);
+                if (t > best[i]) { best[i] = t; bk[i] = k; }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + s * C + c) = best;
+        *reinterpret_cast<unsigned*>(arg + s * C + c) = (unsigned)bk[0] | ((unsigned)bk[1] << 8) | ((unsigned)bk[2] << 16) | ((unsigned)bk[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_stats_vec_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
+                                                               const unsigned char* __restrict__ arg, int K, long rows, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               double* __restrict__ sums) {
+    const BnLane l = bn_lane(C);
+    const int c = 4 * l.q;
+    const f32x4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    f32x4 a, b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = rs[i] * g[i]; b[i] = be[i] - m[i] * a[i]; }
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const long n = arg ? rows / K : rows;          // max mode iterates groups
+    for (long r = (long)blockIdx.x * l.rpb + l.sub; l.on && r < n; r += (long)gridDim.x * l.rpb) {
+        const f32x4 d = ld4(dy + r * lddy + c);
+        f32x4 xv;
+        if (arg) {
+            const unsigned ab = *reinterpret_cast<const unsigned*>(arg + r * C + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = x[(r * K + ((ab >> (8 * i)) & 255u)) * ld + c + i];
+        } else {
+            xv = ld4(x + r * ld + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float gg = (xv[i] * a[i] + b[i] > 0.f) ? d[i] : 0.f;
+            s[i] += gg;
+            q[i] += (double)gg * (double)((xv[i] - m[i]) * rs[i]);
+        }
+    }
+    bn_fold_sums(l, C, s, q, sums);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
+                                                               const unsigned char* __restrict__ arg, int K, long rows, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               const double* __restrict__ sums, bf16_t* __restrict__ dx, int lddx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            atomic_add_f32(dgamma + c, (float)sums[C + c]);
+            atomic_add_f32(dbeta + c, (float)sums[c]);
+        }
+    const BnLane l = bn_lane(C);
+    if (!l.on) return;
+    const int c = 4 * l.q;
+    const f32x4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
+    f32x4 a, b, s1, s2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = rs[i] * g[i];
+        b[i] = be[i] - m[i] * a[i];
+        s1[i] = (float)(sums[c + i] / rows);
+        s2[i] = (float)(sums[C + c + i] / rows);
+    }
+    const unsigned uK = (unsigned)(K > 0 ? K : 1);
+    for (long r = (long)blockIdx.x * l.rpb + l.sub; r < rows; r += (long)gridDim.x * l.rpb) {
+        const f32x4 xv = ld4(x + r * ld + c);
+        f32x4 gq = {0.f, 0.f, 0.f, 0.f};
+        if (arg) {
+            const long sg = r / uK;
+            const unsigned kk = (unsigned)(r - sg * uK);
+            const unsigned ab = *reinterpret_cast<const unsigned*>(arg + sg * C + c);
+            const f32x4 d = ld4(dy + sg * lddy + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (kk == ((ab >> (8 * i)) & 255u) && xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
+        } else {
+            const f32x4 d = ld4(dy + r * lddy + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
+        }
+        union { u32x2 u; bf16_t h[4]; } o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float xh = (xv[i] - m[i]) * rs[i];
+            o.h[i] = f2bf(a[i] * (gq[i] - s1[i] - xh * s2[i]));
+        }
+        *reinterpret_cast<u32x2*>(dx + r * lddx + c) = o.u;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- 3-NN interpolation
 // out[b, n] = sum_j w[b, n, j] * f1[b, idx[b, n, j]] + f2[b, n]     (TransitionUp, models/3DViT/model.py:67-72)
 __global__ void interp3_kernel(const float* __restrict__ f1, int S, const float* __restrict__ f2, const int* __restrict__ idx,
@@ -415,6 +606,13 @@ int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, in
     S3D_CHECK_LAUNCH("group_scatter");
     return 0;
 }
+// vector kernels: 4 | C, C/4 <= 256 lanes, 16-byte aligned rows
+static bool bn_vec_ok(const S3dBnArgs& a) {
+    static const bool off = getenv("S3D_BN_SCALAR") != nullptr;
+    return !off && a.C % 4 == 0 && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
+}
+static bool al(const void* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
+
 int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
     if (a.eval_mode) {
@@ -423,18 +621,29 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
     } else {
         (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
         const int per = 256 / a.C;
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
+        if (bn_vec_ok(a))
+            hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
+        else
+            hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
                            a.run_mean, a.run_var);
     }
     if (a.K > 0) {
         S3D_REQUIRE(a.rows % a.K == 0 && a.ldx == a.C, "batchnorm(max): rows must be groups*K and x compact");
         const long groups = a.rows / a.K;
-        hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * a.C)), dim3(256), 0, s, a.x, groups, a.K, a.C, a.mean, a.rstd,
-                           a.gamma, a.beta, a.y, a.arg);
+        if (bn_vec_ok(a) && a.K <= 255 && al(a.y, 16) && al(a.arg, 4))
+            hipLaunchKernelGGL(bn_relu_max_vec_kernel, dim3(grid_for(groups, 256 / (a.C / 4), 8192)), dim3(256), 0, s, a.x, groups, a.K,
+                               a.C, a.mean, a.rstd, a.gamma, a.beta, a.y, a.arg);
+        else
+            hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * a.C)), dim3(256), 0, s, a.x, groups, a.K, a.C, a.mean, a.rstd,
+                               a.gamma, a.beta, a.y, a.arg);
     } else {
-        hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.mean, a.rstd,
-                           a.gamma, a.beta, a.y, a.y_hi, a.y_lo, a.ldo);
+        if (bn_vec_ok(a) && a.ldo % 4 == 0 && al(a.y, 16) && al(a.y_hi, 8) && al(a.y_lo, 8))
+            hipLaunchKernelGGL(bn_relu_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), 8192)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx,
+                               a.mean, a.rstd, a.gamma, a.beta, a.y, a.y_hi, a.y_lo, a.ldo);
+        else
+            hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.mean, a.rstd,
+                               a.gamma, a.beta, a.y, a.y_hi, a.y_lo, a.ldo);
     }
     S3D_CHECK_LAUNCH("batchnorm_fwd");
     return 0;
@@ -445,6 +654,15 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     const int per = 256 / a.C;
     const unsigned char* arg = a.K > 0 ? a.arg : nullptr;
     const long n = a.K > 0 ? a.rows / a.K : a.rows;
+    if (bn_vec_ok(a) && a.lddy % 4 == 0 && a.lddx % 4 == 0 && a.K <= 255 && al(a.dy, 16) && al(a.dx, 8) && al(arg, 4)) {
+        const int rpb = 256 / (a.C / 4);
+        hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
+                           a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums);
+        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(a.rows, rpb, 8192)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg,
+                           a.K, a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta);
+        S3D_CHECK_LAUNCH("batchnorm_bwd");
+        return 0;
+    }
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid_for(n, per, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
                        a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
