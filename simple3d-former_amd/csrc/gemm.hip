@@ -606,6 +606,170 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large backward GEMMs with k-major operands (NN dgrad: B = W [K][N]; TN wgrad: A = dy [K][M] and B = x [K][N]) on the same
+// LDS-DMA pipeline.  A k-major tile is DMA'd as it lies in memory ([64 k rows][128 columns], 256-byte rows, four rows per 1 KB
+// piece) and the MFMA fragments (8 consecutive k of one column) come from gfx950's LDS TRANSPOSE read: per 16-lane group,
+// lane t passes the address of row t>>2, columns 4(t&3)..+3 of a [4 k][16 columns] block and receives column t (two reads per
+// fragment, see attention.hip).  The four rows of a block are 256 bytes apart = the same banks, so 16-byte slot c of row r is
+// stored at slot c ^ ((r & 3) << 1) -- applied, as always with DMA, to the SOURCE address.  No register transposes, no
+// ds_write at all.  k must tile by 64 (zero-fill is impossible without registers); the launcher falls back otherwise.
+__device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int col16, int kq8, int lane) {
+    const int t = lane & 15;
+    const int row = kq8 + (t >> 2), col = col16 + 4 * (t & 3);
+    const int slot = (col >> 3) ^ ((row & 3) << 1);
+    const unsigned addr = (unsigned)(uintptr_t)(tile + row * 256 + slot * 16 + (col & 7) * 2);
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr)
+                 : "memory");
+    U128 u;
+    u.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    return u.v;
+}
+
+template <bool TA, bool TB, int EPI, int NS>
+__global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 128, BN = 128, BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int PPW = STAGE / 1024 / 4;
+    constexpr int FM = BM / 32, FN = BN / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    {
+        const int ntile = ntx * nty;
+        const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    const int kbeg = blockIdx.z * p.kchunk;
+    const int ntiles = (min(p.K, kbeg + p.kchunk) - kbeg) >> 6;        // every k-slice tiles by 64 (checked by the launcher)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+
+    const bf16_t* gp[PPW];
+    long gstep[PPW];                                                   // elements per k-tile
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int piece = wave * PPW + j;
+        const bool isB = piece >= A_BYTES / 1024;
+        const int q = isB ? piece - A_BYTES / 1024 : piece;
+        const bool kmajor = isB ? TB : TA;
+        const bf16_t* base = isB ? p.B_hi : p.A_hi;
+        const long ld = isB ? p.ldb : p.lda;
+        const int R = isB ? p.N : p.M, r0 = isB ? n0 : m0;
+        if (kmajor) {                                                  // piece = 4 k rows x 16 slots
+            const int r = q * 4 + (lane >> 4), c = lane & 15;
+            const int cg = c ^ ((r & 3) << 1);
+            gp[j] = base + (long)(kbeg + r) * ld + min(r0 + cg * 8, R - 8);
+            gstep[j] = 64 * ld;
+        } else {                                                       // piece = 8 tile rows x 8 slots (k-contiguous operand)
+            const int r = q * 8 + (lane >> 3), c = lane & 7;
+            const int sw = (r ^ (r >> 3)) & 7;
+            gp[j] = base + (long)min(r0 + r, R - 1) * ld + kbeg + ((c ^ sw) << 3);
+            gstep[j] = 64;
+        }
+    }
+    auto issue = [&](int t) {
+        const unsigned dst = lds0 + (unsigned)((t % NS) * STAGE + wave * PPW * 1024);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) glds16(gp[j] + (long)t * gstep[j], dst + j * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient (wgrad): row sums of A over k = A . ones, one extra MFMA per A fragment in the first tile column
+    const bool want_bsum = TA && EPI == EPI_ATOMIC && p.bias_grad != nullptr && (tile_id % ntx) == 0 && wn == 0;
+    f32x4 bacc[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    U128 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones.h[i] = (bf16_t)0x3F80;
+
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < ntiles) issue(u);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + NS - 1 < ntiles) issue(t + NS - 1);
+        const unsigned char* sA = smem + (t % NS) * STAGE;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a_hi[FM], b_hi[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                if constexpr (TA) a_hi[i] = frag_kmajor(sA, wm * (BM / 2) + i * 16, ks * 32 + (lane >> 4) * 8, lane);
+                else a_hi[i] = read_frag(sA, wm * (BM / 2) + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (TB) b_hi[j] = frag_kmajor(sB, wn * (BN / 2) + j * 16, ks * 32 + (lane >> 4) * 8, lane);
+                else b_hi[j] = read_frag(sB, wn * (BN / 2) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (EPI == EPI_ATOMIC) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+                }
+            if (want_bsum) {                                           // wave-uniform
+#pragma unroll
+                for (int i = 0; i < FM; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], ones.v, bacc[i], 0, 0, 0);
+            }
+        }
+    }
+    if constexpr (EPI == EPI_ATOMIC) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < p.M && n < p.N) atomic_add_f32(&p.C[(long)m * p.ldc + n], acc[i][j][r] * p.alpha);
+                }
+            }
+        if (want_bsum && (lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    if (m < p.M) atomic_add_f32(&p.bias_grad[m], bacc[i][r] * p.alpha);
+                }
+        }
+    } else {
+        constexpr int LDC = BN + 4, CPR = BN / 8;
+        float* ct = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) = acc[i][j];
+        __syncthreads();
+#pragma unroll
+        for (int c = tid; c < BM * CPR; c += 256) {
+            const int row = c / CPR, col = (c % CPR) * 8;
+            float v[8];
+            ld_f32<8>(v, ct + row * LDC + col);
+            epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
+        }
+    }
+}
+
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -721,6 +885,35 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
     }
     S3D_CHECK_LAUNCH("gemm_nt_dma");
+    return 0;
+}
+
+template <bool TA, bool TB, int EPI>
+int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
+    constexpr int NS = 2, STAGE = 2 * 128 * 64 * 2;
+    constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : 128 * 132 * 4);
+    static bool attr_set = false;
+    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, splitk);
+    constexpr long long KEY = 400000000000LL + 128 * 100000000LL + 128 * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + EPI;
+    if (g_skip_key == KEY) return 0;
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = KEY;
+        sl.flops = 2.0 * a.M * a.N * a.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+    }
+    S3D_CHECK_LAUNCH("gemm_dmat");
     return 0;
 }
 
@@ -866,6 +1059,9 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         wgrad_split(a, splitk, kchunk);
         a.kchunk = kchunk;
         const int tile = s3d_gemm_pick_tile(a.M, a.N, splitk, false);
+        static const int dmat = env_int("S3D_GEMM_DMAT");               // S3D_GEMM_DMAT=0: register-staged kernel instead
+        if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
+            return launch_dmat<true, true, EPI_ATOMIC>(a, splitk, stream);
         return launch_tiles<true, true, false, EPI_ATOMIC>(tile, a, splitk, stream);
     }
     a.kchunk = (a.K + 63) / 64 * 64;
@@ -877,6 +1073,17 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     }
     if (!ta && tb) {
         S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
+        static const int dmat = env_int("S3D_GEMM_DMAT");
+        if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+            switch (epi) {
+                case EPI_F32: return launch_dmat<false, true, EPI_F32>(a, 1, stream);
+                case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU>(a, 1, stream);
+                case EPI_DRELU: return launch_dmat<false, true, EPI_DRELU>(a, 1, stream);
+                case EPI_RESID: return launch_dmat<false, true, EPI_RESID>(a, 1, stream);
+                case EPI_BF16_BIAS: return launch_dmat<false, true, EPI_BF16_BIAS>(a, 1, stream);
+                default: break;
+            }
+        }
         switch (epi) {
             case EPI_F32: return launch_tiles<false, true, false, EPI_F32>(tile, a, 1, stream);
             case EPI_DGELU: return launch_tiles<false, true, false, EPI_DGELU>(tile, a, 1, stream);
