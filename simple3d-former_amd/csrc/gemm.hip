@@ -980,7 +980,8 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
 static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
-    if (splitk <= 0 && a.K >= 16384 && a.M >= 128 && a.N >= 128) {
+    static const int big_min = env_int("S3D_WGRAD_BIG_MIN") > 0 ? env_int("S3D_WGRAD_BIG_MIN") : 48;   // narrow long-k wgrads (point path: 96 x 56 x 2.1 M) stream well on the DMA kernel too
+    if (splitk <= 0 && a.K >= 16384 && a.M >= big_min && a.N >= big_min) {
         // long reductions (cfg-3: k = 188k token rows): 128x128 tiles re-read 4x less than 64x64 ones, and k is long enough
         // to give every tile several k-slices -> size the split for >= 768 workgroups of 128x128
         const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
