@@ -614,39 +614,43 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
 // fragment, see attention.hip).  The four rows of a block are 256 bytes apart = the same banks, so 16-byte slot c of row r is
 // stored at slot c ^ ((r & 3) << 1) -- applied, as always with DMA, to the SOURCE address.  No register transposes, no
 // ds_write at all.  k must tile by 64 (zero-fill is impossible without registers); the launcher falls back otherwise.
+// slot swizzle of a k-major tile row: 256-byte rows (128 columns) put all four rows of a transpose-read block on the same banks
+// -> xor (r & 3) << 1; 128-byte rows (64 columns) alias rows two apart -> xor ((r >> 1) & 1) << 1
+template <int COLS> __device__ __forceinline__ int kmajor_swz(int r) { return COLS == 128 ? ((r & 3) << 1) : (((r >> 1) & 1) << 1); }
+
+template <int COLS = 128>
 __device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int col16, int kq8, int lane) {
     const int t = lane & 15;
     const int row = kq8 + (t >> 2), col = col16 + 4 * (t & 3);
-    const int slot = (col >> 3) ^ ((row & 3) << 1);
-    const unsigned addr = (unsigned)(uintptr_t)(tile + row * 256 + slot * 16 + (col & 7) * 2);
+    const int slot = (col >> 3) ^ kmajor_swz<COLS>(row);
+    const unsigned addr = (unsigned)(uintptr_t)(tile + row * (COLS * 2) + slot * 16 + (col & 7) * 2);
     u32x2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024\n\ts_waitcnt lgkmcnt(0)"
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(lo), "=&v"(hi)
-                 : "v"(addr)
+                 : "v"(addr), "n"(4 * COLS * 2)
                  : "memory");
     U128 u;
     u.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
     return u.v;
 }
 
-template <bool TA, bool TB, int EPI, int NS>
-__global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BM = 128, BN = 128, BK = 64;
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128>
+__device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
+                                               const int bz) {
+    constexpr int BK = 64;
+    static_assert(BM == BN && (BM == 128 || BM == 64), "square 128 / 64 tiles");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int PPW = STAGE / 1024 / 4;
     constexpr int FM = BM / 32, FN = BN / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
-    const int ntx = gridDim.x, nty = gridDim.y;
     {
         const int ntile = ntx * nty;
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
-    const int kbeg = blockIdx.z * p.kchunk;
+    const int kbeg = bz * p.kchunk;
     const int ntiles = (min(p.K, kbeg + p.kchunk) - kbeg) >> 6;        // every k-slice tiles by 64 (checked by the launcher)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
@@ -661,9 +665,10 @@ __global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
         const bf16_t* base = isB ? p.B_hi : p.A_hi;
         const long ld = isB ? p.ldb : p.lda;
         const int R = isB ? p.N : p.M, r0 = isB ? n0 : m0;
-        if (kmajor) {                                                  // piece = 4 k rows x 16 slots
-            const int r = q * 4 + (lane >> 4), c = lane & 15;
-            const int cg = c ^ ((r & 3) << 1);
+        if (kmajor) {                                                  // piece = 1 KB of k rows: 4 rows x 16 slots (8 x 8 at 64 columns)
+            constexpr int SPR = BM / 8;                                // 16-byte slots per row
+            const int r = q * (64 / SPR) + lane / SPR, c = lane % SPR;
+            const int cg = c ^ kmajor_swz<BM>(r);
             gp[j] = base + (long)(kbeg + r) * ld + min(r0 + cg * 8, R - 8);
             gstep[j] = 64 * ld;
         } else {                                                       // piece = 8 tile rows x 8 slots (k-contiguous operand)
@@ -708,12 +713,12 @@ __global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
             bf16x8 a_hi[FM], b_hi[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                if constexpr (TA) a_hi[i] = frag_kmajor(sA, wm * (BM / 2) + i * 16, ks * 32 + (lane >> 4) * 8, lane);
+                if constexpr (TA) a_hi[i] = frag_kmajor<BM>(sA, wm * (BM / 2) + i * 16, ks * 32 + (lane >> 4) * 8, lane);
                 else a_hi[i] = read_frag(sA, wm * (BM / 2) + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if constexpr (TB) b_hi[j] = frag_kmajor(sB, wn * (BN / 2) + j * 16, ks * 32 + (lane >> 4) * 8, lane);
+                if constexpr (TB) b_hi[j] = frag_kmajor<BN>(sB, wn * (BN / 2) + j * 16, ks * 32 + (lane >> 4) * 8, lane);
                 else b_hi[j] = read_frag(sB, wn * (BN / 2) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
             }
 #pragma unroll
@@ -767,6 +772,26 @@ __global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
             ld_f32<8>(v, ct + row * LDC + col);
             epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
         }
+    }
+}
+
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128>
+__global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    gemm_dmat_body<TA, TB, EPI, NS, BM, BN>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+}
+
+// dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
+template <int EPIA, int NS>
+__global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, const GemmArgs pb, int nA, int ntxA, int ntyA,
+                                                             int ntxB, int ntyB) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int bid = blockIdx.x;
+    if (bid < nA) {
+        gemm_dmat_body<false, true, EPIA, NS, 64, 64>(pa, smem, bid, ntxA, ntyA, 0);
+    } else {
+        const int b = bid - nA, tiles = ntxB * ntyB;
+        gemm_dmat_body<true, true, EPI_ATOMIC, NS, 64, 64>(pb, smem, b % tiles, ntxB, ntyB, b / tiles);
     }
 }
 
@@ -888,18 +913,18 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <bool TA, bool TB, int EPI>
+template <bool TA, bool TB, int EPI, int BT = 128>
 int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
-    constexpr int NS = 2, STAGE = 2 * 128 * 64 * 2;
-    constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : 128 * 132 * 4);
+    constexpr int NS = BT == 128 ? 2 : 3, STAGE = 2 * BT * 64 * 2;
+    constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : BT * (BT + 4) * 4);
     static bool attr_set = false;
-    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS>;
+    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS, BT, BT>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, splitk);
-    constexpr long long KEY = 400000000000LL + 128 * 100000000LL + 128 * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + EPI;
+    dim3 grid((a.N + BT - 1) / BT, (a.M + BT - 1) / BT, splitk);
+    constexpr long long KEY = 400000000000LL + BT * 100000000LL + BT * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + EPI;
     if (g_skip_key == KEY) return 0;
     if (g_prof_on) {
         ProfSlot sl;
@@ -1009,6 +1034,37 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
 }
 
 template <int EPIA>
+int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream) {
+    // three 16 KB stages (A 64x64 + B 64x64 bf16): 2.04 ms per cfg-2 step; two stages 2.15 ms, four 2.07 ms
+    constexpr int NS = 3;
+    constexpr int LDS = cmax(NS * 2 * 64 * 64 * 2, 64 * 68 * 4);
+    static bool attr_set = false;
+    auto kern = gemm_pair_dmat_kernel<EPIA, NS>;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    const int ntxA = (a.N + 63) / 64, ntyA = (a.M + 63) / 64, ntxB = (b.N + 63) / 64, ntyB = (b.M + 63) / 64;
+    const int nA = ntxA * ntyA, nB = ntxB * ntyB * splitk;
+    constexpr long long KEY = 600000000000LL + 64 * 100000000LL + 64 * 100000LL + EPIA;     // 6 | 064 | 064 | 000 | EPI dgrad
+    if (g_skip_key == KEY) return 0;
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = KEY;
+        sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+    }
+    S3D_CHECK_LAUNCH("gemm_pair_dmat");
+    return 0;
+}
+
+template <int EPIA>
 static int launch_pair_tiles(int ta_, int tb_, const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t s) {
     if (ta_ == 0 && tb_ == 0) return launch_pair_one<32, EPIA, 32>(a, b, splitk, s);
     if (ta_ == 0 && tb_ == 1) return launch_pair_one<32, EPIA, 64>(a, b, splitk, s);
@@ -1033,6 +1089,15 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     }
     a.kchunk = (a.K + 63) / 64 * 64;
     b.kchunk = kchunk;
+    static const int pair_dmat = env_int("S3D_GEMM_PAIR_DMAT");          // S3D_GEMM_PAIR_DMAT=0: register-staged pair kernel
+    if (pair_dmat != 0 && tile_a == 1 && tile_b == 1 && (a.K & 63) == 0 && (b.K & 63) == 0 && (kchunk & 63) == 0) {
+        switch (epi_a) {
+            case EPI_F32: return launch_pair_dmat<EPI_F32>(a, b, splitk, stream);
+            case EPI_DGELU: return launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream);
+            case EPI_BF16_BIAS: return launch_pair_dmat<EPI_BF16_BIAS>(a, b, splitk, stream);
+            default: break;
+        }
+    }
     switch (epi_a) {
         case EPI_F32: return launch_pair_tiles<EPI_F32>(tile_a, tile_b, a, b, splitk, stream);
         case EPI_DGELU: return launch_pair_tiles<EPI_DGELU>(tile_a, tile_b, a, b, splitk, stream);
@@ -1063,6 +1128,9 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         static const int dmat = env_int("S3D_GEMM_DMAT");               // S3D_GEMM_DMAT=0: register-staged kernel instead
         if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
             return launch_dmat<true, true, EPI_ATOMIC>(a, splitk, stream);
+        static const int dmat_small = env_int("S3D_GEMM_DMAT_SMALL");   // the same pipeline on 64x64 tiles (=0: register-staged)
+        if (dmat_small != 0 && tile == 1 && (a.K & 63) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
+            return launch_dmat<true, true, EPI_ATOMIC, 64>(a, splitk, stream);
         return launch_tiles<true, true, false, EPI_ATOMIC>(tile, a, splitk, stream);
     }
     a.kchunk = (a.K + 63) / 64 * 64;
@@ -1075,6 +1143,15 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     if (!ta && tb) {
         S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
         static const int dmat = env_int("S3D_GEMM_DMAT");
+        static const int dmat_small = env_int("S3D_GEMM_DMAT_SMALL");
+        if (dmat_small != 0 && tile == 1 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+            switch (epi) {
+                case EPI_F32: return launch_dmat<false, true, EPI_F32, 64>(a, 1, stream);
+                case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 64>(a, 1, stream);
+                case EPI_BF16_BIAS: return launch_dmat<false, true, EPI_BF16_BIAS, 64>(a, 1, stream);
+                default: break;
+            }
+        }
         if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 7) == 0) {
             switch (epi) {
                 case EPI_F32: return launch_dmat<false, true, EPI_F32>(a, 1, stream);
