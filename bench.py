@@ -45,28 +45,45 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0           # /opt/skills/guides/MI355X_MICROARCH.m
 EPI_NAMES = {0: 'bf16_bias', 1: 'gelu', 2: 'resid', 3: 'token', 4: 'f32', 5: 'dgelu', 6: 'atomic', 7: 'relu', 8: 'drelu'}
 
 
-def kernel_name(key):
-    """Decodes the library's profiling key (gemm.hip: 1|BM|BN|TA|TB|SPLIT|EPI for one problem, 2|BMdgrad|BMwgrad|000|EPI
-    for a fused dgrad + wgrad launch)."""
+def _key_fields(key):
     key = int(key)
     kind, rest = key // 10 ** 11, key % 10 ** 11
-    b0, b1, tail = rest // 10 ** 8, (rest // 10 ** 5) % 1000, rest % 10 ** 5
+    return kind, rest // 10 ** 8, (rest // 10 ** 5) % 1000, rest % 10 ** 5
+
+
+def kernel_name(key):
+    """Decodes the library's profiling key (gemm.hip).  First digit = kernel family: 1 register-staged gemm_kernel
+    (BM|BN|TA|TB|SPLIT|EPI), 2 register-staged dgrad+wgrad pair (BMdgrad|BMwgrad|EPI), 3 LDS-DMA forward kernel, 4 LDS-DMA kernel
+    with transpose reads for k-major operands, 6 the dgrad+wgrad pair on that pipeline."""
+    kind, b0, b1, tail = _key_fields(key)
     epi = EPI_NAMES.get(tail % 100, tail % 100)
+    ta, tb, sp = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10
+    lay = f'{"T" if ta else "N"}{"T" if not tb else "N"}'
     if kind == 2:
         return f'gemm_pair_kernel<dgrad {b0}x64 NN {epi} || wgrad {b1}x64 TN atomic>'
-    ta, tb, sp = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10
-    return f'gemm_kernel<{b0},{b1},{"T" if ta else "N"}{"T" if not tb else "N"},{"split3" if sp else "bf16"},{epi}>'
+    if kind == 6:
+        return f'gemm_pair_dmat_kernel<dgrad {b0}x{b1} NN {epi} || wgrad {b0}x{b1} TN atomic; LDS-DMA + transpose reads>'
+    if kind == 3:
+        return f'gemm_nt_dma_kernel<{b0},{b1},NT,{"split3" if sp else "bf16"},{epi}>'
+    if kind == 4:
+        return f'gemm_dmat_kernel<{b0},{b1},{lay},bf16,{epi}>'
+    return f'gemm_kernel<{b0},{b1},{lay},{"split3" if sp else "bf16"},{epi}>'
 
 
 def rocprof_name(key):
     """The same kernel as rocprofv3 prints it (template arguments), for looking it up in profiles/*.json."""
-    key = int(key)
-    kind, rest = key // 10 ** 11, key % 10 ** 11
-    b0, b1, tail = rest // 10 ** 8, (rest // 10 ** 5) % 1000, rest % 10 ** 5
-    if kind == 2:
-        return f'gemm_pair_kernel<{b0}, {tail % 100}, {b1}>'
+    kind, b0, b1, tail = _key_fields(key)
     tf = lambda v: 'true' if v else 'false'
-    return f'gemm_kernel<{b0}, {b1}, {tf((tail // 10000) % 10)}, {tf((tail // 1000) % 10)}, {tf((tail // 100) % 10)}, {tail % 100}>'
+    ta, tb, sp, epi = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10, tail % 100
+    if kind == 2:
+        return f'gemm_pair_kernel<{b0}, {epi}, {b1}>'
+    if kind == 6:
+        return f'gemm_pair_dmat_kernel<{epi}, 3>'
+    if kind == 3:
+        return f'gemm_nt_dma_kernel<{tf(sp)}, {epi}, 2, {32 if sp else 64}, {b0}, {b1}>'
+    if kind == 4:
+        return f'gemm_dmat_kernel<{tf(ta)}, {tf(tb)}, {epi}, {2 if b0 == 128 else 3}, {b0}, {b1}>'
+    return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
 
 
 def pmc_traffic(key):
