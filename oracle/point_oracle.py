@@ -12,6 +12,9 @@ Pure functions over a flat {state_dict key: tensor} mapping with the reference's
   transition_up                      models/3DViT/model.py:42-72 -> PointNetFeaturePropagation.forward data/pointnet_util.py:381-420
                                      with mlp=[] and points1=None (3-NN by full sort, weights 1/(d+1e-8) normalised)
   forward_features / forward         models/3DViT/model.py:297-337 (cls: mean over points then head) and :494-535 (seg: per-point head)
+  variants (VARIANTS / level_plan)   models/3DViT_1_layer/model.py:216-249,294-319 (one level), models/3DViT_0_layer/model.py:216-239,
+                                     284-307 (no level), models/3DViT_LWF/model.py:216-249,294-321 (two levels, N/4 and N/16 points);
+                                     forward_images :323-337 of each; LwF loss train_partseg_lwf.py:207-228
   timm blocks                        oracle.voxel_oracle.run_blocks (timm==0.3.2, un-vendored)
   losses                             train_cls.py:70,119-121 (CrossEntropyLoss), train_partseg.py:143-150 (CE over B*N rows)
   metrics                            train_cls.py:22-41 (instance / class accuracy), train_partseg.py:172-220 (part IoU, mIoU)
@@ -19,7 +22,8 @@ Pure functions over a flat {state_dict key: tensor} mapping with the reference's
 PINNING: tests/golden/make_golden_points.py runs the reference's own models/3DViT/model.py + data/pointnet_util.py (on
 oracle/timm_shim, `data` package stubbed because data/__init__.py imports missing modules) with this module's deterministic
 parameters and records logits / loss / gradients / BatchNorm running statistics and the FPS start indices it drew;
-tests/test_oracle_points.py replays them here.
+tests/test_oracle_points.py replays them here -- four fixtures for models/3DViT/model.py and four for the PointTransformerSeg of
+models/3DViT_1_layer, 3DViT_0_layer, 3DViT_LWF (incl. forward_images and the LwF gradient).
 """
 import math
 
@@ -31,6 +35,29 @@ from . import voxel_oracle as vo
 BACKBONES = vo.BACKBONES
 NSAMPLE = 16           # config/model/3DViT.yaml: nneighbor 16
 BN_EPS = 1e-5
+
+# The four model directories a trainer can name (train_partseg.py:74 / train_partseg_lwf.py import models.<name>.model):
+#   levels     number of TransitionDown / TransitionUp pairs around the transformer
+#   first_div  td 0 keeps N / first_div points (models/3DViT/model.py:242 `npoints // 4 ** i` vs
+#              models/3DViT_1_layer/model.py:231 `npoints // 4 ** (i + 1)`)
+#   head       state_dict key of the per-point head: the variants keep timm's 2-D `head` (Linear(D, 1000)) for
+#              forward_images and add `new_head` (3DViT_1_layer/model.py:218-221)
+#   image      forward_images exists (3DViT_1_layer/model.py:323-337); the base model replaces patch_embed by PointEmbed
+# Base width C0 = D / 2**levels (fc1 / fc_pos_embed / head input): D/4, D/4, D/2, D.
+VARIANTS = {
+    '3DViT': dict(levels=2, first_div=1, head='head', image=False),
+    '3DViT_LWF': dict(levels=2, first_div=4, head='new_head', image=True),
+    '3DViT_1_layer': dict(levels=1, first_div=4, head='new_head', image=True),
+    '3DViT_0_layer': dict(levels=0, first_div=1, head='new_head', image=True),
+}
+
+
+def level_plan(variant, D, n_points):
+    """-> (C0, [npoint of td i], [out channels of td i])."""
+    v = VARIANTS[variant]
+    C0 = D >> v['levels']
+    S = [n_points // (v['first_div'] * 4 ** i) for i in range(v['levels'])]
+    return C0, S, [C0 * 2 ** (i + 1) for i in range(v['levels'])]
 
 
 # ----------------------------------------------------------------------------- geometry
@@ -117,46 +144,76 @@ def mlp2(x, sd, pre):
 
 
 # ----------------------------------------------------------------------------- model
-def forward_features(sd, x, *, backbone, starts, training=True, momentum=0.1, stats_out=None, bf16=False):
-    """x: [B,N,d_points] (xyz first); starts = (start0 [B], start1 [B]) FPS start indices of the two TransitionDowns."""
+def forward_features(sd, x, *, backbone, starts, training=True, momentum=0.1, stats_out=None, bf16=False, variant='3DViT'):
+    """x: [B,N,d_points] (xyz first); starts = one FPS start-index tensor [B] per TransitionDown.
+    3DViT / 3DViT_LWF: models/3DViT/model.py:297-327; 3DViT_1_layer/model.py:294-319; 3DViT_0_layer/model.py:284-307."""
     cfg = BACKBONES[backbone]
     D, depth, H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
     B, N, _ = x.shape
+    _, S, _ = level_plan(variant, D, N)
     xyz = x[..., :3]
     f = mlp2(x, sd, 'fc1.') + mlp2(xyz, sd, 'fc_pos_embed.')
-    xyz0, p0, _, _ = set_abstraction(xyz, f, sd, 'transition_downs.0.', N, starts[0], training, momentum, stats_out)
-    xyz1, p1, _, _ = set_abstraction(xyz0, p0, sd, 'transition_downs.1.', N // 4, starts[1], training, momentum, stats_out)
-    t = torch.cat((sd['cls_token'].expand(B, -1, -1), p1), dim=1)
+    pyramid = [(xyz, f)]                                          # (coordinates, features) of every resolution, fine -> coarse
+    for i, npoint in enumerate(S):
+        cx, cp = pyramid[-1]
+        nx, np_, _, _ = set_abstraction(cx, cp, sd, f'transition_downs.{i}.', npoint, starts[i], training, momentum, stats_out)
+        pyramid.append((nx, np_))
+    t = torch.cat((sd['cls_token'].expand(B, -1, -1), pyramid[-1][1]), dim=1)
     t = vo.run_blocks(t, sd, depth, H, bf16)[:, 1:]
-    t = transition_up(xyz1, t, xyz0, p0, sd, 'transition_ups.0.', training, momentum, stats_out)
-    return transition_up(xyz0, t, xyz, f, sd, 'transition_ups.1.', training, momentum, stats_out)
+    for j in range(len(S)):
+        (cx, _), (fx, fp) = pyramid[len(S) - j], pyramid[len(S) - j - 1]
+        t = transition_up(cx, t, fx, fp, sd, f'transition_ups.{j}.', training, momentum, stats_out)
+    return t
 
 
-def forward(sd, x, *, task, **kw):
-    feats = forward_features(sd, x, **kw)
+def forward(sd, x, *, task, variant='3DViT', **kw):
+    feats = forward_features(sd, x, variant=variant, **kw)
     if task == 'cls':
         feats = feats.mean(1)
-    return feats @ sd['head.weight'].t() + sd['head.bias']
+    hk = VARIANTS[variant]['head']
+    return feats @ sd[hk + '.weight'].t() + sd[hk + '.bias']
+
+
+def forward_images(sd, img, *, backbone, bf16=False):
+    """PointTransformerSeg.forward_images of the variants (models/3DViT_1_layer/model.py:323-337): the same arithmetic as
+    Feature3D_ViT2D_V2.forward_images -- timm PatchEmbed, cls concat, + pos_embed, the shared blocks, norm, 2-D `head`."""
+    return vo.forward_images(sd, img, backbone=backbone, bf16=bf16)
 
 
 def loss_fn(logits, target):
     return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1))
 
 
-def used_param_names(sd):
-    skip = ('pos_embed', 'patch_embed.')
+IMAGE_ONLY = ('pos_embed', 'patch_embed.', 'head.')
+
+
+def used_param_names(sd, variant='3DViT', images=False):
+    """Parameters reached by the point forward (+ the 2-D stem / head when the LwF image loss is added)."""
+    skip = ('pos_embed', 'patch_embed.') if VARIANTS[variant]['head'] == 'head' else IMAGE_ONLY
     return [k for k in sd if sd[k].dtype.is_floating_point and 'running_' not in k and 'last_pos_embed' not in k
-            and not k.startswith(skip)]
+            and (images or not k.startswith(skip))]
 
 
 def loss_and_grads(sd, x, target, **kw):
-    names = used_param_names(sd)
+    names = used_param_names(sd, kw.get('variant', '3DViT'))
     leaf = {k: (v.detach().clone().requires_grad_(k in names) if v.dtype.is_floating_point else v) for k, v in sd.items()}
     stats = {}
     logits = forward(leaf, x, stats_out=stats, **kw)
     loss = loss_fn(logits, target)
     grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
     return logits.detach(), loss.detach(), {k: g for k, g in zip(names, grads) if g is not None}, stats
+
+
+def lwf_loss_and_grads(sd, x, target, img, img_target, lambda_weight=0.1, **kw):
+    """train_partseg_lwf.py:207-228: CE(seg_pred, target) + lambda * CE(forward_images(images), label_teacher), one backward."""
+    names = used_param_names(sd, kw['variant'], images=True)
+    leaf = {k: (v.detach().clone().requires_grad_(k in names) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+    stats = {}
+    logits = forward(leaf, x, stats_out=stats, **kw)
+    li = forward_images(leaf, img, backbone=kw['backbone'])
+    loss = loss_fn(logits, target) + lambda_weight * F.cross_entropy(li, img_target)
+    grads = torch.autograd.grad(loss, [leaf[k] for k in names], allow_unused=True)
+    return logits.detach(), li.detach(), loss.detach(), {k: g for k, g in zip(names, grads) if g is not None}, stats
 
 
 def sgd_momentum_step(p, g, buf, lr=0.01, momentum=0.9, first=False):
@@ -195,13 +252,15 @@ def part_iou(logits, target, seg_classes):
 
 
 # ----------------------------------------------------------------------------- parameters / inputs
-def init_state_dict(*, backbone, n_classes, d_points, seed=9):
+def init_state_dict(*, backbone, n_classes, d_points, seed=9, variant='3DViT'):
     """Deterministic (integer-hash) parameters with the reference's key names and shapes for every tensor the point
     forward touches (+ BatchNorm buffers).  Unused reference parameters (pos_embed, patch_embed.*, sa.last_pos_embed.*)
     are not generated."""
     cfg = BACKBONES[backbone]
     D, depth = cfg['embed_dim'], cfg['depth']
-    C0 = D // 4
+    vv = VARIANTS[variant]
+    levels = vv['levels']
+    C0 = D >> levels
     sid = [0]
     sd = {}
 
@@ -219,7 +278,7 @@ def init_state_dict(*, backbone, n_classes, d_points, seed=9):
 
     lin('fc1.0', C0, d_points); lin('fc1.2', C0, C0)
     lin('fc_pos_embed.0', C0, 3); lin('fc_pos_embed.2', C0, C0)
-    for i in range(2):
+    for i in range(levels):
         ch = C0 * 2 ** (i + 1)
         cin = ch // 2 + 3
         p = f'transition_downs.{i}.sa.'
@@ -237,16 +296,20 @@ def init_state_dict(*, backbone, n_classes, d_points, seed=9):
         sd[p + 'mlp.fc1.weight'] = u((4 * D, D), 0.02 * math.sqrt(3)); sd[p + 'mlp.fc1.bias'] = u((4 * D,), 0.05)
         sd[p + 'mlp.fc2.weight'] = u((D, 4 * D), 0.02 * math.sqrt(3)); sd[p + 'mlp.fc2.bias'] = u((D,), 0.05)
     sd['norm.weight'] = 1 + u((D,), 0.1); sd['norm.bias'] = u((D,), 0.1)
-    for j, i in enumerate(reversed(range(2))):
+    for j, i in enumerate(reversed(range(levels))):
         ch = C0 * 2 ** i
         p = f'transition_ups.{j}.'
         lin(p + 'fc1.0', ch, ch * 2); bn(p + 'fc1.2', ch)
         lin(p + 'fc2.0', ch, ch); bn(p + 'fc2.2', ch)
-    lin('head', n_classes, C0)
+    lin(vv['head'], n_classes, C0)
+    if vv['image']:                       # timm's 2-D stem / head, kept by the variants for forward_images
+        sd['patch_embed.proj.weight'] = u((D, 3, 16, 16), 1.0 / math.sqrt(768)); sd['patch_embed.proj.bias'] = u((D,), 1.0 / math.sqrt(768))
+        sd['pos_embed'] = u((1, 197, D), 0.02 * math.sqrt(3))
+        lin('head', 1000, D)
     return sd
 
 
-def synthetic_points(batch, n_points, d_points, n_classes, task, seed=9):
+def synthetic_points(batch, n_points, d_points, n_classes, task, seed=9, variant='3DViT'):
     """xyz uniform in the unit ball (cf. pc_normalize, pointnet_util.py:15-20), unit normals, for
     part-seg a one-hot(16) object label appended (train_partseg.py:143); targets randint.  Integer-hash generator."""
     u = lambda shape, s: vo.portable_uniform(shape, seed, 7000 + s)
@@ -264,5 +327,7 @@ def synthetic_points(batch, n_points, d_points, n_classes, task, seed=9):
         y = (u((batch,), 4) * n_classes).long().clamp(max=n_classes - 1)
     else:
         y = (u((batch, n_points), 4) * n_classes).long().clamp(max=n_classes - 1)
-    starts = tuple((u((batch,), 10 + i) * n).long().clamp(max=n - 1) for i, n in enumerate((n_points, n_points)))
+    _, S, _ = level_plan(variant, 4, n_points)
+    n_in = ([n_points] + S)[:len(S)]                                 # FPS of level i draws its start among that level's INPUT points
+    starts = tuple((u((batch,), 10 + i) * n).long().clamp(max=n - 1) for i, n in enumerate(n_in))
     return x, y, starts

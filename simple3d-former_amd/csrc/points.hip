@@ -613,19 +613,23 @@ static bool bn_vec_ok(const S3dBnArgs& a) {
 }
 static bool al(const void* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
 
+// Channel limits: the scalar statistics kernels map 256 / C rows onto a workgroup (C <= 256); the vector kernels give every
+// lane one channel quad (C <= 1024, 4 | C, aligned rows) -- deit_small / deit_base widths of the 1-level model need those.
 int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
-    S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
+    S3D_REQUIRE(a.C > 0 && (a.C <= 256 || (a.C <= 1024 && bn_vec_ok(a))),
+                "batchnorm: C=%d must be in 1..256 (or a multiple of 4 up to 1024 with 16-byte aligned rows)", a.C);
+    const unsigned cblocks = (unsigned)((a.C + 255) / 256);
     if (a.eval_mode) {
         S3D_REQUIRE(a.run_mean && a.run_var, "batchnorm(eval): running statistics required");
-        hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(1), dim3(256), 0, s, a.run_mean, a.run_var, a.C, a.eps, a.mean, a.rstd);
+        hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cblocks), dim3(256), 0, s, a.run_mean, a.run_var, a.C, a.eps, a.mean, a.rstd);
     } else {
         (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
-        const int per = 256 / a.C;
+        const int per = a.C <= 256 ? 256 / a.C : 1;
         if (bn_vec_ok(a))
             hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
         else
             hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
                            a.run_mean, a.run_var);
     }
     if (a.K > 0) {
@@ -649,12 +653,14 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
     return 0;
 }
 int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
-    S3D_REQUIRE(a.C > 0 && a.C <= 256, "batchnorm: C=%d must be in 1..256", a.C);
-    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
-    const int per = 256 / a.C;
     const unsigned char* arg = a.K > 0 ? a.arg : nullptr;
+    const bool vec = bn_vec_ok(a) && a.lddy % 4 == 0 && a.lddx % 4 == 0 && a.K <= 255 && al(a.dy, 16) && al(a.dx, 8) && al(arg, 4);
+    S3D_REQUIRE(a.C > 0 && (a.C <= 256 || (a.C <= 1024 && vec)),
+                "batchnorm: C=%d must be in 1..256 (or a multiple of 4 up to 1024 with 16-byte aligned rows)", a.C);
+    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+    const int per = a.C <= 256 ? 256 / a.C : 1;
     const long n = a.K > 0 ? a.rows / a.K : a.rows;
-    if (bn_vec_ok(a) && a.lddy % 4 == 0 && a.lddx % 4 == 0 && a.K <= 255 && al(a.dy, 16) && al(a.dx, 8) && al(arg, 4)) {
+    if (vec) {
         const int rpb = 256 / (a.C / 4);
         hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
                            a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums);

@@ -5,7 +5,9 @@ learning-without-forgetting loop (train_cls_voxel.py:250-267): timm PatchEmbed (
 Everything runs on the library's kernels: s3d_image_patchify + the TOKEN-epilogue GEMM, s3d_blocks_fwd/bwd on a second activation
 workspace (N = 197 tokens), the strided final norm, the linear head.  Gradients ACCUMULATE into the engine's arena, so a voxel
 backward followed by an image backward yields d(CE_voxel + lambda * CE_image)/d(parameters) exactly as one autograd backward
-does in the reference.  `frozen` mirrors __load_backbone_weight (:427-432): patch_embed / pos_embed / head get no gradient."""
+does in the reference.  `frozen` mirrors __load_backbone_weight (:427-432): patch_embed / pos_embed / head get no gradient;
+the point variants (models/3DViT_1_layer/model.py:285-289) freeze patch_embed and head but keep pos_embed trainable, hence the
+three separate flags.  The same class serves PointEngine (PointTransformerSeg.forward_images of the 3DViT_* variants)."""
 import ctypes
 
 import torch
@@ -31,8 +33,16 @@ class ImageBranch:
         self.ntok = self.np + 1
         self.K = IMG_CHANS * IMG_PATCH * IMG_PATCH
         self.C = IMG_CLASSES
-        self.frozen = False
+        self.frozen_stem = self.frozen_pos = self.frozen_head = False
         self._ws = {}
+
+    @property
+    def frozen(self):
+        return self.frozen_stem and self.frozen_pos and self.frozen_head
+
+    @frozen.setter
+    def frozen(self, on):
+        self.frozen_stem = self.frozen_pos = self.frozen_head = bool(on)
 
     def workspace(self, B):
         ws = self._ws.get(B)
@@ -60,8 +70,8 @@ class ImageBranch:
         a = self.eng.arena
         return L.fill(L.S3dHeadArgs(), feat=ws.feat, B=ws.B, D=self.eng.D, C=self.C, W=a.param('head.weight'),
                       bias=a.param('head.bias'), logits=ws.logits, am_softmax=0, am_scale=1.0, dlogits=ws.dlogits,
-                      dfeat=ws.dfeat, dW=None if self.frozen else a.grad('head.weight'),
-                      dbias=None if self.frozen else a.grad('head.bias'), scratch=ws.head_scratch)
+                      dfeat=ws.dfeat, dW=None if self.frozen_head else a.grad('head.weight'),
+                      dbias=None if self.frozen_head else a.grad('head.bias'), scratch=ws.head_scratch)
 
     # ------------------------------------------------------------------ forward
     def forward(self, img):
@@ -116,11 +126,11 @@ class ImageBranch:
         L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd (images)')
         L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), e.bparams, e.bgrads, ws.blocks.acts, ctypes.byref(sc.c),
                                    e.depth - 1, 0, s), 'blocks_bwd (images)')
-        if not self.frozen:                                  # d(patch_embed.proj.weight) += dx^T patches
+        if not self.frozen_stem:                             # d(patch_embed.proj.weight) += dx^T patches
             g = L.fill(L.S3dGemmArgs(), A_hi=sc.dx_a_bf, lda=D, B_hi=ws.a[0], ldb=self.K, M=D, N=self.K, K=ws.M,
                        C=a.grad('patch_embed.proj.weight'), ldc=self.K, alpha=1.0)
             L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), 'patch-embed wgrad')
         pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=B, ntok=self.ntok, D=D,
-                    dpos=None if self.frozen else a.grad('pos_embed'), dcls=a.grad('cls_token'),
-                    dbias=None if self.frozen else a.grad('patch_embed.proj.bias'))
+                    dpos=None if self.frozen_pos else a.grad('pos_embed'), dcls=a.grad('cls_token'),
+                    dbias=None if self.frozen_stem else a.grad('patch_embed.proj.bias'))
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'image token grads')

@@ -9,7 +9,13 @@ Pipeline (deit_tiny: D = 192, C0 = D/4 = 48):
   TransitionUp 0/1: Linear+BN+ReLU on both inputs, 3-NN inverse-distance interpolation, add
   cls: mean over points -> Linear head -> CE          seg: per-point Linear head -> CE over B*N rows
 Train-mode BatchNorm (batch statistics, running-stat update).  The FPS start indices (torch.randint in the reference,
-data/pointnet_util.py:65) are an explicit input so that runs are reproducible / comparable with the oracle."""
+data/pointnet_util.py:65) are an explicit input so that runs are reproducible / comparable with the oracle.
+
+`variant` selects one of the reference's four model directories (config/model/*.yaml `name`, imported by
+train_partseg.py:74 / train_partseg_lwf.py): the same layers around the same transformer with 2, 1 or 0 TransitionDown /
+TransitionUp pairs (VARIANTS below).  The three variants are part-segmentation only, keep timm's 2-D stem / `head` for
+forward_images (models/3DViT_1_layer/model.py:323-337 -> ImageBranch on the shared blocks) and name the point head
+`new_head`; `lwf_train_step` is the train_partseg_lwf.py:207-228 step."""
 import ctypes
 import math
 
@@ -22,17 +28,40 @@ from .engine import BACKBONES, LN_EPS, ParamArena, _BlockScratch, _BlockWorkspac
 KNN = 16
 BN_EPS = 1e-5
 
+# levels: TransitionDown/Up pairs; first_div: td 0 keeps N / first_div points (models/3DViT/model.py:242 `npoints // 4 ** i`,
+# the variants `npoints // 4 ** (i + 1)`, 3DViT_1_layer/model.py:231); head: key of the point head; image: forward_images exists.
+VARIANTS = {
+    '3DViT': dict(levels=2, first_div=1, head='head', image=False),
+    '3DViT_LWF': dict(levels=2, first_div=4, head='new_head', image=True),
+    '3DViT_1_layer': dict(levels=1, first_div=4, head='new_head', image=True),
+    '3DViT_0_layer': dict(levels=0, first_div=1, head='new_head', image=True),
+}
 
-def point_param_shapes(backbone, n_classes, d_points):
+
+def level_plan(variant, D, n_points):
+    """-> (C0 = D / 2**levels, [points kept by td i], [out channels of td i])."""
+    if variant not in VARIANTS:
+        raise ValueError(f'unknown point model {variant!r}; expected one of {sorted(VARIANTS)}')
+    v = VARIANTS[variant]
+    C0 = D >> v['levels']
+    return C0, [n_points // (v['first_div'] * 4 ** i) for i in range(v['levels'])], [C0 * 2 ** (i + 1) for i in range(v['levels'])]
+
+
+def point_param_shapes(backbone, n_classes, d_points, variant='3DViT'):
     cfg = BACKBONES[backbone]
     D, depth = cfg['embed_dim'], cfg['depth']
-    C0 = D // 4
+    vv = VARIANTS[variant]
+    levels = vv['levels']
+    C0 = D >> levels
     sh = {}
+    if vv['image']:
+        from .image_branch import image_param_shapes
+        sh.update(image_param_shapes(D)[0])
     sh['fc1.0.weight'] = (C0, d_points); sh['fc1.0.bias'] = (C0,)
     sh['fc1.2.weight'] = (C0, C0); sh['fc1.2.bias'] = (C0,)
     sh['fc_pos_embed.0.weight'] = (C0, 3); sh['fc_pos_embed.0.bias'] = (C0,)
     sh['fc_pos_embed.2.weight'] = (C0, C0); sh['fc_pos_embed.2.bias'] = (C0,)
-    for i in range(2):
+    for i in range(levels):
         ch = C0 * 2 ** (i + 1)
         cin = ch // 2 + 3
         p = f'transition_downs.{i}.sa.'
@@ -50,23 +79,27 @@ def point_param_shapes(backbone, n_classes, d_points):
         sh[p + 'mlp.fc1.weight'] = (4 * D, D); sh[p + 'mlp.fc1.bias'] = (4 * D,)
         sh[p + 'mlp.fc2.weight'] = (D, 4 * D); sh[p + 'mlp.fc2.bias'] = (D,)
     sh['norm.weight'] = (D,); sh['norm.bias'] = (D,)
-    for j, i in enumerate(reversed(range(2))):
+    for j, i in enumerate(reversed(range(levels))):
         ch = C0 * 2 ** i
         p = f'transition_ups.{j}.'
         sh[p + 'fc1.0.weight'] = (ch, ch * 2); sh[p + 'fc1.0.bias'] = (ch,)
         sh[p + 'fc1.2.weight'] = (ch,); sh[p + 'fc1.2.bias'] = (ch,)
         sh[p + 'fc2.0.weight'] = (ch, ch); sh[p + 'fc2.0.bias'] = (ch,)
         sh[p + 'fc2.2.weight'] = (ch,); sh[p + 'fc2.2.bias'] = (ch,)
-    sh['head.weight'] = (n_classes, C0); sh['head.bias'] = (n_classes,)
+    hk = vv['head']
+    sh[hk + '.weight'] = (n_classes, C0); sh[hk + '.bias'] = (n_classes,)
+    if vv['image']:
+        sh.update(image_param_shapes(D)[1])
     return sh
 
 
-def bn_buffer_names(backbone):
+def bn_buffer_names(backbone, variant='3DViT'):
     names = []
-    for i in range(2):
+    levels = VARIANTS[variant]['levels']
+    for i in range(levels):
         for j in range(2):
             names.append(f'transition_downs.{i}.sa.mlp_bns.{j}')
-    for j in range(2):
+    for j in range(levels):
         names += [f'transition_ups.{j}.fc1.2', f'transition_ups.{j}.fc2.2']
     return names
 
@@ -155,27 +188,35 @@ class _BatchNorm:
 
 class PointEngine:
     def __init__(self, *, backbone='deit_tiny_patch16_224', n_points, d_points, n_classes, task='cls', device='cuda', split=True,
-                 lr=0.01, momentum=0.9, bn_momentum=0.1):
+                 lr=0.01, momentum=0.9, bn_momentum=0.1, variant='3DViT'):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")
         if task not in ('cls', 'seg'):
             raise ValueError(f'unknown task {task!r}')
+        if variant not in VARIANTS:
+            raise ValueError(f'unknown point model {variant!r}; expected one of {sorted(VARIANTS)}')
+        if variant != '3DViT' and task != 'seg':
+            raise ValueError(f'models/{variant}/model.py defines PointTransformerSeg only')
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('PointEngine runs on an MI355X (cuda/HIP device) only; the CPU reference lives in oracle/')
         cfg = BACKBONES[backbone]
         self.D, self.depth, self.H = cfg['embed_dim'], cfg['depth'], cfg['num_heads']
-        self.C0 = self.D // 4
+        self.hidden = 4 * self.D
+        self.variant, self.vv = variant, VARIANTS[variant]
+        self.levels = self.vv['levels']
         self.N, self.dp, self.ncls, self.task = n_points, d_points, n_classes, task
-        assert n_points % 4 == 0 and n_points <= 2048, 'num_point must be a multiple of 4 and <= 2048'
-        self.S = [n_points, n_points // 4]
-        self.ch = [2 * self.C0, 4 * self.C0]
-        self.cin = [self.C0 + 3, self.ch[0] + 3]
+        self.C0, self.S, self.ch = level_plan(variant, self.D, n_points)
+        div = self.vv['first_div'] * 4 ** max(self.levels - 1, 0)
+        assert n_points % div == 0 and n_points <= 2048, f'num_point must be a multiple of {div} and <= 2048'
+        self.Nin = ([n_points] + self.S)[:self.levels]          # points entering td i
+        assert all(n >= KNN for n in self.Nin), f'every TransitionDown needs >= {KNN} input points'
+        self.cin = [c // 2 + 3 for c in self.ch]
         self.split, self.bn_momentum = bool(split), bn_momentum
         self.lr, self.momentum = lr, momentum
         self.training = True                # BatchNorm mode: batch statistics (model.train()) vs running statistics
-        self.shapes = point_param_shapes(backbone, n_classes, d_points)
+        self.shapes = point_param_shapes(backbone, n_classes, d_points, variant)
         self.arena = ParamArena(self.shapes, self.device)
         self.buf = torch.zeros_like(self.arena.p)                   # SGD momentum buffer
         self.sgd_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -186,17 +227,18 @@ class PointEngine:
         self.fc1 = [_Linear(self, 'fc1.0'), _Linear(self, 'fc1.2')]
         self.fcp = [_Linear(self, 'fc_pos_embed.0'), _Linear(self, 'fc_pos_embed.2')]
         self.td = []
-        for i in range(2):
+        for i in range(self.levels):
             p = f'transition_downs.{i}.sa.'
             self.td.append(dict(c0=_Linear(self, p + 'mlp_convs.0'), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
                                 c1=_Linear(self, p + 'mlp_convs.1'), b1=_BatchNorm(self, p + 'mlp_bns.1', self.ch[i])))
         self.tu = []
-        for j, i in enumerate(reversed(range(2))):
+        for j, i in enumerate(reversed(range(self.levels))):
             ch = self.C0 * 2 ** i
             p = f'transition_ups.{j}.'
             self.tu.append(dict(l1=_Linear(self, p + 'fc1.0'), b1=_BatchNorm(self, p + 'fc1.2', ch),
                                 l2=_Linear(self, p + 'fc2.0'), b2=_BatchNorm(self, p + 'fc2.2', ch), ch=ch))
-        self.head = _Linear(self, 'head', out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
+        self.head_key = self.vv['head']
+        self.head = _Linear(self, self.head_key, out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
         self._linears = self.fc1 + self.fcp + [t[k] for t in self.td for k in ('c0', 'c1')] + \
             [t[k] for t in self.tu for k in ('l1', 'l2')] + ([self.head] if self.head else [])
         self.bns = {t[k].key: t[k] for t in self.td for k in ('b0', 'b1')}
@@ -218,6 +260,10 @@ class PointEngine:
                    proj_w=a.grad(p + 'attn.proj.weight'), proj_b=a.grad(p + 'attn.proj.bias'), fc1_w=a.grad(p + 'mlp.fc1.weight'),
                    fc1_b=a.grad(p + 'mlp.fc1.bias'), fc2_w=a.grad(p + 'mlp.fc2.weight'), fc2_b=a.grad(p + 'mlp.fc2.bias'))
         self._ws = {}
+        self.images = None
+        if self.vv['image']:
+            from .image_branch import ImageBranch
+            self.images = ImageBranch(self)
 
     # ------------------------------------------------------------------ parameters / buffers
     def load_state_dict(self, sd):
@@ -260,7 +306,7 @@ class PointEngine:
         ws.td = []
         xyz_n = N
         cprev = C0
-        for i in range(2):
+        for i in range(self.levels):
             S, ch, cinp = self.S[i], self.ch[i], _round_up(self.cin[i], 8)
             R = B * S * KNN
             t = type('TD', (), {})()
@@ -277,7 +323,8 @@ class PointEngine:
             t.dout = torch.empty(B * S, ch, **f32)            # gradient wrt this level's output features
             ws.td.append(t)
             xyz_n, cprev = S, ch
-        S1 = self.S[1]
+        S1 = self.S[-1] if self.levels else N                   # points that become tokens
+        ws.S1 = S1
         ws.ntok = S1 + 1
         M = B * ws.ntok
         ws.zero_pos = torch.zeros(ws.ntok, D, **f32)
@@ -289,8 +336,9 @@ class PointEngine:
         ws.dxn = torch.empty(M, D, **f32); ws.dt = torch.empty(B * S1, D, **f32)
         ws.zero_cls = torch.zeros(D, **f32)
         ws.tu = []
-        lvl = [(S1, self.S[0], self.ch[0], ws.td[0]), (self.S[0], N, C0, None)]          # (coarse pts, fine pts, channels)
-        for j, (Sc, Sf, ch, _) in enumerate(lvl):
+        pts = [N] + self.S                                      # points per resolution, fine -> coarse
+        lvl = [(pts[self.levels - j], pts[self.levels - j - 1], C0 * 2 ** (self.levels - 1 - j)) for j in range(self.levels)]
+        for j, (Sc, Sf, ch) in enumerate(lvl):                  # (coarse pts, fine pts, channels)
             u = type('TU', (), {})()
             u.Sc, u.Sf, u.ch = Sc, Sf, ch
             u.u1 = torch.empty(B * Sc, ch, **f32); u.f1 = torch.empty(B * Sc, ch, **f32)
@@ -298,7 +346,7 @@ class PointEngine:
             u.idx = torch.empty(B, Sf, 3, **i32); u.w = torch.empty(B, Sf, 3, **f32)
             u.out = torch.empty(B * Sf, ch, **f32)
             u.inp2 = torch.empty(2, B * Sf, ch, **b16)         # planes of the fine-level input (p0 / f)
-            u.inp1 = torch.empty(2, B * Sc, 2 * ch, **b16) if j == 1 else None     # planes of the coarse input (tu1: v0)
+            u.inp1 = torch.empty(2, B * Sc, 2 * ch, **b16) if j >= 1 else None     # planes of the coarse input (tu j-1's output)
             u.df1 = torch.empty(B * Sc, ch, **f32)
             u.dxb1 = torch.empty(B * Sc, ch, **b16); u.dxb2 = torch.empty(B * Sf, ch, **b16)
             u.din1 = torch.empty(B * Sc, 2 * ch, **f32)        # gradient wrt the coarse input
@@ -312,7 +360,7 @@ class PointEngine:
             ws.logits = torch.empty(B, self.ncls, **f32); ws.dlogits = torch.empty(B, self.ncls, **f32)
         else:
             cp = self.head.opad
-            ws.v1p = torch.empty(2, BN, C0, **b16)
+            ws.v1p = torch.empty(2, BN, C0, **b16) if self.levels else None
             ws.logits = torch.empty(BN, cp, **f32); ws.dlogits = torch.empty(BN, cp, **f32)
             ws.dlb = torch.empty(BN, cp, **b16)
         self._ws[B] = ws
@@ -328,7 +376,7 @@ class PointEngine:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, starts, training=True):
-        """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = (start0, start1) int64 [B] each.
+        """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = one int64 [B] tensor per TransitionDown.
         training=False normalises with the BatchNorm running statistics (model.eval()); backward needs training=True."""
         self.training = bool(training)
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
@@ -346,8 +394,9 @@ class PointEngine:
         self.fcp[0].fwd(ws.xyzp[0], ws.xyzp[1], BN, 7, O_hi=ws.h2[0], O_lo=ws.h2[1], ldo=C0, aux=ws.h2pre, ldaux=C0)
         self.fcp[1].fwd(ws.h2[0], ws.h2[1], BN, 2, C=ws.f, ldc=C0, R=ws.f, ldr=C0)
         # transition downs
+        assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
         xyz_in, feats, cin_feats = ws.xyz, ws.f, C0
-        for i in range(2):
+        for i in range(self.levels):
             t, lay = ws.td[i], self.td[i]
             L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
             L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
@@ -360,8 +409,8 @@ class PointEngine:
             lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
             xyz_in, feats, cin_feats = t.new_xyz, t.out, ch
         # tokens -> blocks -> norm -> drop cls
-        S1 = self.S[1]
-        L.check(lib.s3d_assemble_tokens(L.ptr(ws.td[1].out), L.ptr(a.param('cls_token')), L.ptr(ws.zero_pos), L.ptr(ws.blocks.x[0]),
+        S1 = ws.S1
+        L.check(lib.s3d_assemble_tokens(L.ptr(feats), L.ptr(a.param('cls_token')), L.ptr(ws.zero_pos), L.ptr(ws.blocks.x[0]),
                                         ctypes.c_long(B), S1, D, s), 'assemble')
         L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, s), 'blocks_fwd')
         M = B * ws.ntok
@@ -372,10 +421,13 @@ class PointEngine:
         self._pack(ws.t, D, D, B * S1, ws.tp)
         # transition ups
         coarse_planes = ws.tp
-        coarse_xyz = [ws.td[1].new_xyz, ws.td[0].new_xyz]
-        fine_xyz = [ws.td[0].new_xyz, ws.xyz]
-        fine_feats = [ws.td[0].out, ws.f]
-        for j in range(2):
+        nl = self.levels
+        res_xyz = [ws.xyz] + [t.new_xyz for t in ws.td]          # per resolution, fine -> coarse
+        res_feats = [ws.f] + [t.out for t in ws.td]
+        coarse_xyz = [res_xyz[nl - j] for j in range(nl)]
+        fine_xyz = [res_xyz[nl - j - 1] for j in range(nl)]
+        fine_feats = [res_feats[nl - j - 1] for j in range(nl)]
+        for j in range(nl):
             u, lay = ws.tu[j], self.tu[j]
             ch = u.ch
             lay['l1'].fwd(coarse_planes[0], coarse_planes[1], B * u.Sc, 4, C=u.u1, ldc=ch)
@@ -385,10 +437,14 @@ class PointEngine:
             lay['b2'].fwd(u.u2, B * u.Sf, y=u.f2, ldo=ch)
             L.check(lib.s3d_knn(L.ptr(fine_xyz[j]), L.ptr(coarse_xyz[j]), B, u.Sf, u.Sc, 3, L.ptr(u.idx), L.ptr(u.w), s), 'knn3')
             L.check(lib.s3d_interp3(L.ptr(u.f1), u.Sc, L.ptr(u.f2), L.ptr(u.idx), L.ptr(u.w), B, u.Sf, ch, L.ptr(u.out), s), 'interp3')
-            if j == 0:
-                self._pack(u.out, ch, ch, B * u.Sf, ws.tu[1].inp1)
-                coarse_planes = ws.tu[1].inp1
-        v1 = ws.tu[1].out
+            if j + 1 < nl:
+                self._pack(u.out, ch, ch, B * u.Sf, ws.tu[j + 1].inp1)
+                coarse_planes = ws.tu[j + 1].inp1
+        if nl == 0:                                              # 3DViT_0_layer: the head reads the tokens (C0 = D)
+            ws.v1p = ws.tp
+            self.head.fwd(ws.v1p[0], ws.v1p[1], BN, 4, C=ws.logits, ldc=self.head.opad)
+            return ws.logits.view(B, N, self.head.opad)[..., :self.ncls]
+        v1 = ws.tu[-1].out
         if self.task == 'cls':
             L.check(lib.s3d_mean_points(L.ptr(v1), B, N, C0, L.ptr(ws.feat), s), 'mean')
             L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
@@ -399,9 +455,10 @@ class PointEngine:
 
     def _head_args(self, ws):
         a = self.arena
-        return L.fill(L.S3dHeadArgs(), feat=ws.feat, B=ws.B, D=self.C0, C=self.ncls, W=a.param('head.weight'), bias=a.param('head.bias'),
-                      logits=ws.logits, am_softmax=0, am_scale=1.0, dlogits=ws.dlogits, dfeat=ws.dfeat, dW=a.grad('head.weight'),
-                      dbias=a.grad('head.bias'))
+        hk = self.head_key
+        return L.fill(L.S3dHeadArgs(), feat=ws.feat, B=ws.B, D=self.C0, C=self.ncls, W=a.param(hk + '.weight'), bias=a.param(hk + '.bias'),
+                      logits=ws.logits, am_softmax=0, am_scale=1.0, dlogits=ws.dlogits, dfeat=ws.dfeat, dW=a.grad(hk + '.weight'),
+                      dbias=a.grad(hk + '.bias'))
 
     # ------------------------------------------------------------------ loss
     def cross_entropy(self, B, target):
@@ -427,26 +484,27 @@ class PointEngine:
         else:
             cp = self.head.opad
             self._pack_bf(ws.dlogits, cp, BN, ws.dlb)
-            self.head.bwd(ws.dlb, ws.v1p[0], BN, dx=ws.dv1, dx_epi=4)
+            self.head.bwd(ws.dlb, ws.v1p[0], BN, dx=ws.dv1 if self.levels else ws.dt, dx_epi=4)
         # transition ups (reverse)
-        dfine = ws.dv1                                           # gradient wrt tu1 output [BN, C0]
-        for j in (1, 0):
+        nl = self.levels
+        dfine = ws.dv1                                           # gradient wrt the last tu's output [BN, C0]
+        for j in reversed(range(nl)):
             u, lay = ws.tu[j], self.tu[j]
             ch = u.ch
             u.df1.zero_()
             L.check(lib.s3d_interp3_bwd(L.ptr(dfine), L.ptr(u.idx), L.ptr(u.w), B, u.Sc, u.Sf, ch, L.ptr(u.df1), s), 'interp3_bwd')
             # fine branch: f2 = relu(bn(l2(inp2)));  d(f2) = dfine
             lay['b2'].bwd(u.u2, B * u.Sf, dfine, u.dxb2)
-            dfine_in = ws.df if j == 1 else ws.td[0].dout        # gradient wrt the fine-level input features (f / p0)
+            dfine_in = ws.df if j == nl - 1 else ws.td[nl - 2 - j].dout      # gradient wrt the fine-level input features (f / p_i)
             lay['l2'].bwd(u.dxb2, u.inp2[0], B * u.Sf, dx=dfine_in, dx_epi=4)
             # coarse branch
             lay['b1'].bwd(u.u1, B * u.Sc, u.df1, u.dxb1)
-            coarse_x = ws.tu[1].inp1[0] if j == 1 else ws.tp[0]
-            dcoarse = u.din1 if j == 1 else ws.dt
+            coarse_x = u.inp1[0] if j >= 1 else ws.tp[0]
+            dcoarse = u.din1 if j >= 1 else ws.dt
             lay['l1'].bwd(u.dxb1, coarse_x, B * u.Sc, dx=dcoarse, dx_epi=4)
-            dfine = dcoarse                                      # tu1's coarse input is tu0's output
+            dfine = dcoarse                                      # tu j's coarse input is tu j-1's output
         # drop-cls backward -> final norm -> blocks
-        S1 = self.S[1]
+        S1 = ws.S1
         M = B * ws.ntok
         L.check(lib.s3d_assemble_tokens(L.ptr(ws.dt), L.ptr(ws.zero_cls), L.ptr(ws.zero_pos), L.ptr(ws.dxn), ctypes.c_long(B), S1, D, s), 'undrop')
         sc = ws.scratch
@@ -458,16 +516,17 @@ class PointEngine:
                                    self.depth - 1, 0, s), 'blocks_bwd')
         pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=B, ntok=ws.ntok, D=D, dcls=a.grad('cls_token'))
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'cls grad')
-        L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.td[1].dout), ctypes.c_long(B), S1, D, s), 'tokens bwd')
-        # transition downs (reverse): dout of level 1 is complete; level 0's dout already holds tu0's contribution
-        for i in (1, 0):
+        dtok = ws.td[-1].dout if nl else ws.df                   # 3DViT_0_layer: the tokens are f itself
+        L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(dtok), ctypes.c_long(B), S1, D, s), 'tokens bwd')
+        # transition downs (reverse): dout of the top level is complete; the lower levels' dout already hold their tu's contribution
+        for i in reversed(range(nl)):
             t, lay = ws.td[i], self.td[i]
             ch = self.ch[i]
             lay['b1'].bwd(t.x2, t.R, t.dout, t.dx, K=KNN, arg=t.arg)
             lay['c1'].bwd(t.dx, t.y1[0], t.R, dx=t.dy1, dx_epi=4)
             lay['b0'].bwd(t.x1, t.R, t.dy1, t.dx)
             lay['c0'].bwd(t.dx, t.A[0], t.R, dx=t.dA, dx_epi=4)
-            dprev = ws.td[0].dout if i == 1 else ws.df
+            dprev = ws.td[i - 1].dout if i >= 1 else ws.df
             L.check(lib.s3d_group_scatter(L.ptr(t.dA), t.cinp, L.ptr(t.idx), B, t.Nin, t.S, KNN, t.Cin, L.ptr(dprev), s), 'group_scatter')
         # the two input MLPs: f = fc1(x) + fc_pos_embed(xyz)
         self._pack_bf(ws.df, C0, BN, ws.dfb)
@@ -493,6 +552,23 @@ class PointEngine:
         self.backward(B)
         self.sgd_step()
         return loss
+
+    def lwf_train_step(self, x, target, starts, img, img_target, lambda_weight=0.1):
+        """train_partseg_lwf.py:207-228: loss = CE(seg_pred, target) + lambda * CE(forward_images(images), label_teacher); one
+        backward (here: the image backward accumulates into the same gradient arena), one SGD step.
+        Returns (point loss, image loss) device scalars."""
+        if self.images is None:
+            raise RuntimeError(f'{self.variant} has no forward_images (models/3DViT/model.py replaces patch_embed by PointEmbed)')
+        B = x.shape[0]
+        self.forward(x, starts)
+        loss = self.cross_entropy(B, target)
+        self.backward(B)
+        Bi = img.shape[0]
+        self.images.forward(img)
+        loss_i = self.images.cross_entropy(Bi, img_target, grad_scale=lambda_weight)
+        self.images.backward(Bi)
+        self.sgd_step()
+        return loss, loss_i
 
     def capture_train_step(self, x, target, starts):
         """Captures train_step over the given (static) input buffers into a HIP graph -- the step enqueues ~400 kernels and no

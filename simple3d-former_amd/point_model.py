@@ -5,7 +5,12 @@ input_dim, model.{nneighbor, transformer_backbone, pretrained, head} -- and the 
 same attribute tree and state_dict keys (incl. the parameters the reference creates but never uses: pos_embed,
 patch_embed = PointEmbed, sa.last_pos_embed).  forward() runs the HIP PointEngine through one autograd.Function, so
 `pred = classifier(points); loss = criterion(pred, target); loss.backward(); optimizer.step()` (train_cls.py:117-123,
-train_partseg.py:143-152) works unchanged.  No CPU fallback."""
+train_partseg.py:143-152) works unchanged.  No CPU fallback.
+
+`model_module(name)` stands in for `importlib.import_module('models.{}.model'.format(args.model.name))` (train_partseg.py:74,
+train_partseg_lwf.py) for the four model directories: 3DViT (Cls + Seg) and the part-segmentation variants 3DViT_1_layer,
+3DViT_0_layer, 3DViT_LWF, which keep timm's 2-D stem / `head`, name the point head `new_head`, take
+`forward(x, type='points')` and add `forward_images(images)` (models/3DViT_1_layer/model.py:294-354)."""
 from collections import OrderedDict
 from functools import partial
 
@@ -13,7 +18,7 @@ import torch
 from torch import nn
 
 from .engine import BACKBONES
-from .point_engine import PointEngine
+from .point_engine import VARIANTS, PointEngine, level_plan
 from .voxel_model import VisionTransformer
 
 
@@ -96,12 +101,40 @@ class _PointForward(torch.autograd.Function):
             ws.dlogits.zero_()
             ws.dlogits.view(ctx.batch, eng.N, -1)[..., :eng.ncls].copy_(dlogits)
         eng.backward(ctx.batch)
-        grads = [eng.arena.grad(k) if need else None for k, need in zip(eng.shapes, ctx.needs_input_grad[3:])]
+        two = eng.images is not None      # a second node (forward_images) reuses the arena before autograd has accumulated -> copy
+        grads = [None if not need or (two and k.startswith(_IMAGE_ONLY)) else (eng.arena.grad(k).clone() if two else eng.arena.grad(k))
+                 for k, need in zip(eng.shapes, ctx.needs_input_grad[3:])]
         return (None, None, None) + tuple(grads)
+
+
+_IMAGE_ONLY = ('patch_embed.', 'pos_embed', 'head.')              # not in the graph of model(points) (variants)
+_POINT_ONLY = ('fc1.', 'fc_pos_embed.', 'transition_', 'new_head.')   # not in the graph of forward_images
+
+
+class _PointImageForward(torch.autograd.Function):
+    """PointTransformerSeg.forward_images(images) of the variants as one autograd node on the shared blocks."""
+
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        eng = model._engine
+        eng.refresh_weight_planes()
+        logits = eng.images.forward(x.contiguous().float()).clone()
+        ctx.model, ctx.batch = model, x.shape[0]
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.model._engine
+        eng.zero_grad()
+        eng.images.backward(ctx.batch, dlogits.contiguous().float())
+        grads = [eng.arena.grad(k).clone() if need and not k.startswith(_POINT_ONLY) else None
+                 for k, need in zip(eng.shapes, ctx.needs_input_grad[2:])]
+        return (None, None) + tuple(grads)
 
 
 class _PointTransformer(VisionTransformer):
     _task = 'cls'
+    _variant = '3DViT'
 
     def __init__(self, cfg):
         npoints, nneighbor, n_c, d_points = cfg.num_point, cfg.model.nneighbor, cfg.num_class, cfg.input_dim
@@ -127,20 +160,27 @@ class _PointTransformer(VisionTransformer):
             sd = ckpt['model'] if 'model' in ckpt else ckpt
             own = self.state_dict()
             self.load_state_dict({k: v for k, v in sd.items() if k in own and v.shape == own[k].shape}, strict=False)
-        self.patch_embed = PointEmbed(cfg)
+        vv = VARIANTS[self._variant]
+        c0, keep, chans = level_plan(self._variant, self.embed_dim, npoints)
+        if vv['image']:                       # the variants keep timm's PatchEmbed / pos_embed / head for forward_images and,
+            if self.pretrained:               # with the DeiT checkpoint loaded, freeze head + patch_embed (3DViT_1_layer/model.py:285-289)
+                self.head.weight.requires_grad = False
+                self.head.bias.requires_grad = False
+                for param in self.patch_embed.parameters():
+                    param.requires_grad = False
+            self.use_pos_embed = True
+        else:
+            self.patch_embed = PointEmbed(cfg)
         if getattr(cfg.model, 'head', 'default') == 'AMSoftmax':
-            raise NotImplementedError('AM-softmax head on the point path is not built (config/model/3DViT.yaml uses head: default)')
-        self.head = nn.Linear(self.embed_dim // 4, n_c)
+            raise NotImplementedError('AM-softmax head on the point path is not built (config/model/3DViT*.yaml use head: default)')
+        setattr(self, vv['head'], nn.Linear(c0, n_c))
         self.pos_embed_type = 'default'
         self.transition_downs = nn.ModuleList()
-        for i in range(2):
-            ch = self.embed_dim // 4 * 2 ** (i + 1)
-            self.transition_downs.append(TransitionDown(npoints // 4 ** i, nneighbor, [ch // 2 + 3, ch, ch]))
+        for npoint, ch in zip(keep, chans):
+            self.transition_downs.append(TransitionDown(npoint, nneighbor, [ch // 2 + 3, ch, ch]))
         self.transition_ups = nn.ModuleList()
-        for i in reversed(range(2)):
-            ch = self.embed_dim // 4 * 2 ** i
-            self.transition_ups.append(TransitionUp(ch * 2, ch, ch))
-        c0 = self.embed_dim // 4
+        for ch in reversed(chans):
+            self.transition_ups.append(TransitionUp(ch, ch // 2, ch // 2))
         self.fc1 = nn.Sequential(nn.Linear(d_points, c0), nn.ReLU(), nn.Linear(c0, c0))
         self.fc_pos_embed = nn.Sequential(nn.Linear(3, c0), nn.ReLU(), nn.Linear(c0, c0))
         self._cfg_io = (npoints, d_points)
@@ -152,7 +192,7 @@ class _PointTransformer(VisionTransformer):
         if self._engine is not None and self._engine.device == device:
             return self._engine
         eng = PointEngine(backbone=self.transformer_backbone, n_points=self._cfg_io[0], d_points=self._cfg_io[1],
-                          n_classes=self.n_classes, task=self._task, device=device)
+                          n_classes=self.n_classes, task=self._task, device=device, variant=self._variant)
         own = dict(self.named_parameters())
         sd = {k: own[k].detach() for k in eng.shapes}
         bufs = dict(self.named_buffers())
@@ -164,26 +204,50 @@ class _PointTransformer(VisionTransformer):
         for k, bn in eng.bns.items():                      # module buffers alias the engine's running statistics
             bufs[k + '.running_mean'].data = bn.run_mean
             bufs[k + '.running_var'].data = bn.run_var
+        if eng.images is not None:
+            eng.images.frozen_head = not self.head.weight.requires_grad
+            eng.images.frozen_stem = not self.patch_embed.proj.weight.requires_grad
+            eng.images.frozen_pos = not self.pos_embed.requires_grad
         self._engine = eng
         return eng
 
-    def forward(self, x):
+    def forward(self, x, type='points'):
+        if type != 'points':
+            # the reference's other branch (3DViT_1_layer/model.py:350-352) applies self.head to forward_images' OUTPUT, i.e.
+            # Linear(D, 1000) to a [B, 1000] tensor -- a shape error for every backbone; train_partseg_lwf.py:224 calls
+            # forward_images directly
+            raise RuntimeError("forward(x, type='images') fails in the reference as well (head applied twice); call forward_images(x)")
         if not x.is_cuda:
-            raise RuntimeError(f'{type(self).__name__} runs on the HIP engine: move the model and the batch to the MI355X '
+            raise RuntimeError(f'{self.__class__.__name__} runs on the HIP engine: move the model and the batch to the MI355X '
                                f'(no CPU fallback; the CPU reference lives in oracle/)')
         eng = self.s3d_engine(x.device)
         B, N = x.shape[0], x.shape[1]
         if self.s3d_fps_starts is not None:
             starts = tuple(s.to(x.device) for s in self.s3d_fps_starts)
         else:   # same draws as the reference: torch.randint on the default (CPU) generator, then moved (pointnet_util.py:65)
-            starts = tuple(torch.randint(0, N, (B,), dtype=torch.long).to(x.device) for _ in range(2))
+            starts = tuple(torch.randint(0, n, (B,), dtype=torch.long).to(x.device) for n in eng.Nin)
         own = dict(self.named_parameters())
-        eng.lr = eng.lr
+        for m in self.transition_downs.modules():      # classifier.apply(bn_momentum_adjust) (train_partseg.py:97-99,130)
+            if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                eng.bn_momentum = m.momentum
+                break
         out = _PointForward.apply(self, x, starts, *[own[k] for k in eng.shapes])
         if self.training:
             for k in eng.bns:
                 dict(self.named_buffers())[k + '.num_batches_tracked'].add_(1)
         return out
+
+
+    def forward_images(self, x):
+        """3DViT_1_layer/model.py:323-337 (same in 3DViT_0_layer / 3DViT_LWF): PatchEmbed -> cls + pos_embed -> blocks -> norm -> head."""
+        if not VARIANTS[self._variant]['image']:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'forward_images'")   # models/3DViT/model.py has none
+        if not x.is_cuda:
+            raise RuntimeError(f'{type(self).__name__} runs on the HIP engine: move the model and the images to the MI355X '
+                               f'(no CPU fallback)')
+        eng = self.s3d_engine(x.device)
+        own = dict(self.named_parameters())
+        return _PointImageForward.apply(self, x, *[own[k] for k in eng.shapes])
 
 
 class PointTransformerCls(_PointTransformer):
@@ -192,3 +256,31 @@ class PointTransformerCls(_PointTransformer):
 
 class PointTransformerSeg(_PointTransformer):
     _task = 'seg'
+
+
+class PointTransformerSeg1Layer(_PointTransformer):
+    """models/3DViT_1_layer/model.py: one TransitionDown (N/4 points, D channels) / TransitionUp pair, base width D/2."""
+    _task, _variant = 'seg', '3DViT_1_layer'
+
+
+class PointTransformerSeg0Layer(_PointTransformer):
+    """models/3DViT_0_layer/model.py: every point is a token (fc1 maps straight to D); per-point head on the block output."""
+    _task, _variant = 'seg', '3DViT_0_layer'
+
+
+class PointTransformerSegLWF(_PointTransformer):
+    """models/3DViT_LWF/model.py: two levels keeping N/4 and N/16 points, base width D/4, + forward_images."""
+    _task, _variant = 'seg', '3DViT_LWF'
+
+
+def model_module(name):
+    """Stand-in for importlib.import_module('models.{}.model'.format(name)) (train_partseg.py:74): an object whose
+    PointTransformerSeg (and, for '3DViT', PointTransformerCls) attribute is the drop-in class of that model directory."""
+    import types
+    table = {'3DViT': dict(PointTransformerCls=PointTransformerCls, PointTransformerSeg=PointTransformerSeg),
+             '3DViT_1_layer': dict(PointTransformerSeg=PointTransformerSeg1Layer),
+             '3DViT_0_layer': dict(PointTransformerSeg=PointTransformerSeg0Layer),
+             '3DViT_LWF': dict(PointTransformerSeg=PointTransformerSegLWF)}
+    if name not in table:
+        raise ModuleNotFoundError(f"No module named 'models.{name}'")
+    return types.SimpleNamespace(**table[name])

@@ -18,7 +18,7 @@ if torch.cuda.is_available():
 
 from oracle import point_oracle as po
 from tests._util import check_grads_against_golden
-from tests.test_oracle_points import POINT_CASES, load_point_case
+from tests.test_oracle_points import POINT_CASES, VARIANT_CASES, load_point_case, lwf_images
 
 DEV = 'cuda'
 
@@ -63,7 +63,7 @@ def test_knn16_and_3nn_indices_bit_exact(B, S, N):
     assert rel_err(w3, w) < 1e-5
 
 
-@pytest.mark.parametrize('rows,C,K', [(640, 96, 0), (2048, 192, 16), (4096, 48, 0), (3 * 64 * 16, 96, 16)])
+@pytest.mark.parametrize('rows,C,K', [(640, 96, 0), (2048, 192, 16), (4096, 48, 0), (3 * 64 * 16, 96, 16), (1024, 384, 16), (520, 768, 0)])
 def test_batchnorm_relu_max_fwd_bwd(rows, C, K):
     g = torch.Generator().manual_seed(rows + C)
     x = torch.randn(rows, C, generator=g) * 1.5 + 0.3
@@ -156,6 +156,77 @@ def test_point_engine_matches_reference_golden(name):
     print(f'{name}: logits err {err:.2e}, worst sampled grad err / rms {worst:.3f}')
 
 
+@pytest.mark.parametrize('name', VARIANT_CASES)
+def test_point_engine_variants_match_reference_golden(name):
+    """models/3DViT_1_layer, 3DViT_0_layer, 3DViT_LWF: PointTransformerSeg forward / backward, forward_images on the shared
+    blocks, and (LWF fixture) the gradient of CE(points) + lambda * CE(images) accumulated by the two backward passes."""
+    z, cfg, sd, x, y, starts = load_point_case(name)
+    eng = PointEngine(backbone=cfg['backbone'], n_points=cfg['n_points'], d_points=cfg['d_points'], n_classes=cfg['n_classes'],
+                      task='seg', device=DEV, variant=cfg['variant'])
+    eng.load_state_dict(sd)
+    sts = tuple(s.to(DEV) for s in starts)
+    logits = eng.forward(x.to(DEV), sts).cpu()
+    err = float(np.abs(logits.numpy().reshape(z['logits'].shape) - z['logits']).max())
+    assert err <= 1e-3, f'logits max abs err {err:.3e}'
+    sure = z['top2_gap'] > 2e-3
+    np.testing.assert_array_equal(logits.argmax(-1).numpy().reshape(z['argmax'].shape)[sure], z['argmax'][sure])
+    loss = float(eng.cross_entropy(cfg['batch'], y.to(DEV)))
+    assert abs(loss - float(z['loss_points'] if cfg.get('lwf') else z['loss'])) <= 1e-3
+    for k, bn in eng.bns.items():
+        np.testing.assert_allclose(bn.run_mean.cpu().numpy(), z['stat/' + k + '.running_mean'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(bn.run_var.cpu().numpy(), z['stat/' + k + '.running_var'], rtol=1e-4, atol=1e-5)
+    eng.zero_grad()
+    eng.backward(cfg['batch'])
+    img, yi = lwf_images(cfg)
+    li = eng.images.forward(img.to(DEV)).cpu()
+    ierr = float(np.abs(li.numpy() - z['img_logits']).max())
+    assert ierr <= 1e-3, f'image logits max abs err {ierr:.3e}'
+    sure = z['img_top2_gap'] > 2e-3
+    np.testing.assert_array_equal(li.argmax(1).numpy()[sure], z['img_argmax'][sure])
+    image_only = ('patch_embed.', 'pos_embed', 'head.')
+    if cfg.get('lwf'):
+        loss_i = float(eng.images.cross_entropy(cfg['batch'], yi.to(DEV), grad_scale=cfg['lambda_weight']))
+        assert abs(loss_i - float(z['loss_image'])) <= 1e-3
+        eng.images.backward(cfg['batch'])
+        grads = {k: eng.arena.grad(k) for k in eng.shapes}
+    else:
+        grads = {k: eng.arena.grad(k) for k in eng.shapes if not k.startswith(image_only)}
+        for k in eng.shapes:
+            if k.startswith(image_only):
+                assert float(eng.arena.grad(k).abs().max()) == 0.0, k       # the point backward never touches the 2-D stem / head
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    zero_theory = ('mlp_convs.0.bias', 'mlp_convs.1.bias', 'fc1.0.bias', 'fc2.0.bias', 'norm.bias')
+    zero_theory = tuple(k for k in grads if k.endswith(zero_theory) and (k.startswith('transition_') or k == 'norm.bias'))
+    if eng.levels:               # constant shifts of f are cancelled by the BatchNorms downstream ...
+        zero_theory += ('fc1.2.bias', 'fc_pos_embed.2.bias')
+    if cfg.get('lwf') or not eng.levels:   # ... but 3DViT_0_layer has none, and the image loss reaches norm.bias directly
+        zero_theory = tuple(k for k in zero_theory if k != 'norm.bias')
+    worst = check_grads_against_golden(z, grads, rtol=3e-3, atol=3e-6, skip=zero_theory)
+    print(f'{name}: logits err {err:.2e}, image logits err {ierr:.2e}, worst sampled grad err / rms {worst:.3f}')
+
+
+def test_point_engine_lwf_train_step_and_errors():
+    """PointEngine.lwf_train_step = train_partseg_lwf.py:207-228 (one SGD step on CE(points) + lambda CE(images)) vs the oracle."""
+    z, cfg, sd, x, y, starts = load_point_case('pts_seglwf_tiny_n64_b2')
+    img, yi = lwf_images(cfg)
+    kw = dict(task='seg', backbone=cfg['backbone'], starts=starts, variant=cfg['variant'])
+    _, _, _, grads, _ = po.lwf_loss_and_grads(sd, x, y, img, yi, 0.1, training=True, **kw)
+    eng = PointEngine(backbone=cfg['backbone'], n_points=64, d_points=22, n_classes=50, task='seg', device=DEV, variant='3DViT_LWF')
+    eng.load_state_dict(sd)
+    lp, li = eng.lwf_train_step(x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts), img.to(DEV), yi.to(DEV), 0.1)
+    assert abs(float(lp) - float(z['loss_points'])) <= 1e-3 and abs(float(li) - float(z['loss_image'])) <= 1e-3
+    new = eng.state_dict()
+    for k in ('blocks.3.mlp.fc1.weight', 'pos_embed', 'head.weight', 'new_head.weight', 'transition_downs.1.sa.mlp_convs.1.weight'):
+        want = sd[k] - 0.01 * grads[k]                            # first SGD step: buf = g, p -= lr * g
+        step = float((0.01 * grads[k]).abs().max())
+        assert float((new[k].cpu() - want).abs().max()) <= 0.05 * step + 1e-7, k
+    base = PointEngine(backbone=cfg['backbone'], n_points=64, d_points=22, n_classes=50, task='seg', device=DEV)
+    with pytest.raises(RuntimeError, match='no forward_images'):
+        base.lwf_train_step(x.to(DEV), y.to(DEV), (), img.to(DEV), yi.to(DEV))
+    with pytest.raises(ValueError, match='PointTransformerSeg only'):
+        PointEngine(backbone=cfg['backbone'], n_points=64, d_points=6, n_classes=40, task='cls', device=DEV, variant='3DViT_1_layer')
+
+
 def test_point_engine_sgd_training_reduces_loss():
     cfg = dict(backbone='deit_tiny_patch16_224', n_points=64, d_points=6, n_classes=40)
     sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=40, d_points=6, seed=3)
@@ -209,3 +280,96 @@ def test_drop_in_point_module_matches_reference(name):
         model2(x.to(DEV))
         ev = model2.eval()(x.to(DEV))
     assert float(np.abs(ev.cpu().numpy() - z['logits_eval']).max()) <= 1e-3
+
+
+def _variant_cfg(cfg):
+    import types
+    return types.SimpleNamespace(num_point=cfg['n_points'], num_class=cfg['n_classes'], input_dim=cfg['d_points'],
+                                 model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head='default',
+                                                             transformer_backbone=cfg['backbone'], pretrained=False,
+                                                             name=cfg['variant']))
+
+
+def test_drop_in_variant_module_lwf_step_matches_reference():
+    """train_partseg_lwf.py:207-228 on the drop-in module of models/3DViT_LWF: seg_pred = classifier(points);
+    img_pred = classifier.forward_images(images); loss = CE + lambda * CE; ONE loss.backward(); optimizer.step()."""
+    import simple3d_former_amd as s3d
+    z, cfg, sd, x, y, starts = load_point_case('pts_seglwf_tiny_n64_b2')
+    img, yi = lwf_images(cfg)
+    model = s3d.model_module('3DViT_LWF').PointTransformerSeg(_variant_cfg(cfg))
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all('last_pos_embed' in k for k in missing)
+    model = model.to(DEV).train()
+    model.s3d_fps_starts = starts
+    opt = torch.optim.SGD(model.parameters(), lr=0.01, momentum=0.9)
+    opt.zero_grad()
+    seg_pred = model(x.to(DEV))
+    assert float(np.abs(seg_pred.detach().cpu().numpy() - z['logits']).max()) <= 1e-3
+    loss = F.cross_entropy(seg_pred.contiguous().view(-1, 50), y.to(DEV).view(-1))
+    img_pred = model.forward_images(img.to(DEV))
+    assert float(np.abs(img_pred.detach().cpu().numpy() - z['img_logits']).max()) <= 1e-3
+    loss = loss + cfg['lambda_weight'] * F.cross_entropy(img_pred, yi.to(DEV))
+    assert abs(float(loss) - float(z['loss'])) <= 1e-3
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    zero_theory = tuple(k for k in grads if k.startswith('transition_') and k.endswith(('mlp_convs.0.bias', 'mlp_convs.1.bias',
+                                                                                       'fc1.0.bias', 'fc2.0.bias')))
+    check_grads_against_golden(z, grads, rtol=3e-3, atol=3e-6, skip=zero_theory + ('fc1.2.bias', 'fc_pos_embed.2.bias'))
+    before = model.blocks[2].attn.qkv.weight.detach().clone()
+    opt.step()
+    assert float((model.blocks[2].attn.qkv.weight - before).abs().max()) > 0
+    with pytest.raises(RuntimeError, match='head applied twice'):
+        model(x.to(DEV), type='images')
+
+
+@pytest.mark.parametrize('name', ['pts_seg1_tiny_n64_b2', 'pts_seg0_tiny_n64_b2'])
+def test_drop_in_variant_modules_points_only(name):
+    """classifier(points) alone (train_partseg.py:143-152 with model=3DViT_1_layer / 3DViT_0_layer): the 2-D stem / head stay
+    without gradient, the FPS starts are drawn per level, a frozen (pretrained-style) stem is honoured by forward_images."""
+    import simple3d_former_amd as s3d
+    z, cfg, sd, x, y, starts = load_point_case(name)
+    model = s3d.model_module(cfg['variant']).PointTransformerSeg(_variant_cfg(cfg))
+    model.load_state_dict(sd, strict=False)
+    for p in (model.head.weight, model.head.bias, *model.patch_embed.parameters()):     # what pretrained=True does (model.py:285-289)
+        p.requires_grad = False
+    model = model.to(DEV).train()
+    model.s3d_fps_starts = starts
+    pred = model(x.to(DEV))
+    assert float(np.abs(pred.detach().cpu().numpy() - z['logits']).max()) <= 1e-3
+    F.cross_entropy(pred.reshape(-1, 50), y.to(DEV).reshape(-1)).backward()
+    assert model.pos_embed.grad is None and model.head.weight.grad is None and model.patch_embed.proj.weight.grad is None
+    g = model.new_head.weight.grad
+    ref = float(z['gnorm/new_head.weight'])
+    assert g is not None and abs(float(g.double().norm()) - ref) <= 0.03 * ref
+    model.zero_grad()
+    img, yi = lwf_images(cfg)
+    F.cross_entropy(model.forward_images(img.to(DEV)), yi.to(DEV)).backward()
+    assert model.head.weight.grad is None and model.patch_embed.proj.weight.grad is None       # frozen
+    assert model.pos_embed.grad is not None and float(model.pos_embed.grad.abs().max()) > 0   # pos_embed stays trainable (:287)
+    assert model.new_head.weight.grad is None and model.fc1[0].weight.grad is None            # not in the image graph
+    model.s3d_fps_starts = None                                                               # random starts: one per level, in range
+    with torch.no_grad():
+        out = model.eval()(x.to(DEV))
+    assert tuple(out.shape) == (cfg['batch'], cfg['n_points'], 50) and bool(torch.isfinite(out).all())
+
+
+def test_drop_in_module_honours_bn_momentum_adjust():
+    """train_partseg.py:97-99,130: classifier.apply(bn_momentum_adjust) changes every BatchNorm's momentum per epoch."""
+    import simple3d_former_amd as s3d
+    z, cfg, sd, x, y, starts = load_point_case('pts_seg1_tiny_n64_b2')
+    model = s3d.model_module('3DViT_1_layer').PointTransformerSeg(_variant_cfg(cfg))
+    model.load_state_dict(sd, strict=False)
+    model = model.to(DEV).train()
+    model.s3d_fps_starts = starts
+
+    def bn_momentum_adjust(m, momentum):
+        if isinstance(m, torch.nn.BatchNorm2d) or isinstance(m, torch.nn.BatchNorm1d):
+            m.momentum = momentum
+
+    model = model.apply(lambda m: bn_momentum_adjust(m, 0.5))
+    with torch.no_grad():
+        model(x.to(DEV))
+    k = 'transition_ups.0.fc2.2.running_mean'
+    batch_mean = (z['stat/' + k] - 0.9 * sd[k].numpy()) / 0.1            # the fixture ran with the default momentum 0.1
+    np.testing.assert_allclose(dict(model.named_buffers())[k].cpu().numpy(), 0.5 * sd[k].numpy() + 0.5 * batch_mean, rtol=1e-3, atol=1e-4)

@@ -153,3 +153,36 @@ def test_point_module_state_dict_contract(task):
     cfg.model.transformer_backbone = 'resnet50'
     with pytest.raises(ValueError, match='Unknown transformer backbone name!'):
         s3d.PointTransformerCls(cfg)
+
+
+@pytest.mark.parametrize('name', ['3DViT_1_layer', '3DViT_0_layer', '3DViT_LWF'])
+def test_point_variant_modules_state_dict_contract(name):
+    """model_module(name).PointTransformerSeg(cfg) == the reference's models/<name>/model.py class: state_dict keys + shapes
+    (fixture from the reference), level plan, the engine's parameter set == what the oracle's forward + forward_images touch."""
+    import json
+    from tests._util import GOLDEN
+    from oracle import point_oracle as po
+    ref = json.load(open(f'{GOLDEN}/point_state_dict_keys.json'))[name]
+    cfg = _point_cfg('seg')
+    cfg.model.name = name
+    model = s3d.model_module(name).PointTransformerSeg(cfg)
+    assert {k: list(v.shape) for k, v in model.state_dict().items()} == ref
+    assert not hasattr(s3d.model_module(name), 'PointTransformerCls') and hasattr(s3d.model_module('3DViT'), 'PointTransformerCls')
+    with pytest.raises(ModuleNotFoundError):
+        s3d.model_module('3DViT_2_layer')
+    sd = po.init_state_dict(backbone='deit_tiny_patch16_224', n_classes=50, d_points=22, variant=name)
+    shapes = s3d.point_param_shapes('deit_tiny_patch16_224', 50, 22, name)
+    assert set(shapes) == set(po.used_param_names(sd, name, images=True))
+    assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    from simple3d_former_amd.point_engine import level_plan
+    assert level_plan(name, 192, 2048) == po.level_plan(name, 192, 2048)
+    assert level_plan('3DViT', 192, 2048) == (48, [2048, 512], [96, 192])
+    assert level_plan('3DViT_LWF', 192, 2048) == (48, [512, 128], [96, 192])
+    assert level_plan('3DViT_1_layer', 384, 2048) == (192, [512], [384])
+    assert level_plan('3DViT_0_layer', 192, 2048) == (192, [], [])
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model(torch.zeros(1, 2048, 22))
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        model.forward_images(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(AttributeError):
+        s3d.PointTransformerSeg(_point_cfg('seg')).forward_images(torch.zeros(1, 3, 224, 224))

@@ -10,16 +10,28 @@ from oracle import point_oracle as po
 from tests._util import check_grads_against_golden, GOLDEN
 
 POINT_CASES = ['pts_cls_tiny_n64_b3', 'pts_seg_tiny_n64_b2', 'pts_cls_tiny_n1024_b2', 'pts_seg_tiny_n2048_b1']
+# models/3DViT_1_layer, 3DViT_0_layer, 3DViT_LWF (PointTransformerSeg + forward_images)
+VARIANT_CASES = ['pts_seg1_tiny_n64_b2', 'pts_seg1_small_n256_b2', 'pts_seg0_tiny_n64_b2', 'pts_seglwf_tiny_n64_b2']
 
 
 def load_point_case(name):
     z = np.load(f'{GOLDEN}/{name}.npz')
     cfg = json.loads(str(z['cfg']))
-    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9)
-    x, y, starts = po.synthetic_points(cfg['batch'], cfg['n_points'], cfg['d_points'], cfg['n_classes'], cfg['task'], seed=9)
-    np.testing.assert_array_equal(starts[0].numpy(), z['start0'])
+    variant = cfg.setdefault('variant', '3DViT')
+    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9, variant=variant)
+    x, y, starts = po.synthetic_points(cfg['batch'], cfg['n_points'], cfg['d_points'], cfg['n_classes'], cfg['task'], seed=9,
+                                       variant=variant)
+    for i, st in enumerate(starts):
+        np.testing.assert_array_equal(st.numpy(), z[f'start{i}'])
     np.testing.assert_array_equal(y.numpy(), z['target'])
     return z, cfg, sd, x, y, starts
+
+
+def lwf_images(cfg):
+    """The image batch / teacher labels make_golden_points.py fed to forward_images."""
+    img = (po.vo.portable_uniform((cfg['batch'], 3, 224, 224), 9, 7001) * 2 - 1).float()
+    yi = (po.vo.portable_uniform((cfg['batch'],), 9, 7002) * 1000).long()
+    return img, yi
 
 
 @pytest.mark.parametrize('name', POINT_CASES)
@@ -39,6 +51,36 @@ def test_point_model_matches_reference(name):
     for k, v in stats.items():                                   # BatchNorm running statistics after one train-mode forward
         np.testing.assert_allclose(v.numpy(), z['stat/' + k], rtol=1e-5, atol=1e-6)
     with torch.no_grad():        # the golden eval pass ran after the train-mode pass had updated the running statistics
+        ev = po.forward({**sd, **stats}, x, training=False, **kw)
+    np.testing.assert_allclose(ev.numpy(), z['logits_eval'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', VARIANT_CASES)
+def test_point_variants_match_reference(name):
+    z, cfg, sd, x, y, starts = load_point_case(name)
+    kw = dict(task='seg', backbone=cfg['backbone'], starts=starts, variant=cfg['variant'])
+    img, yi = lwf_images(cfg)
+    np.testing.assert_array_equal(yi.numpy(), z['img_target'])
+    if cfg.get('lwf'):
+        logits, li, loss, grads, stats = po.lwf_loss_and_grads(sd, x, y, img, yi, cfg['lambda_weight'], training=True, **kw)
+        assert abs(float(po.loss_fn(logits, y)) - float(z['loss_points'])) <= 1e-5
+        assert abs(float(torch.nn.functional.cross_entropy(li, yi)) - float(z['loss_image'])) <= 1e-5
+    else:
+        logits, loss, grads, stats = po.loss_and_grads(sd, x, y, training=True, **kw)
+        with torch.no_grad():
+            li = po.forward_images(sd, img, backbone=cfg['backbone'])
+    np.testing.assert_allclose(logits.numpy(), z['logits'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(li.numpy(), z['img_logits'], rtol=0, atol=2e-5)
+    sure = z['img_top2_gap'] > 1e-3
+    np.testing.assert_array_equal(li.argmax(1).numpy()[sure], z['img_argmax'][sure])
+    assert abs(float(loss) - float(z['loss'])) <= 1e-5
+    sure = z['top2_gap'] > 1e-3
+    np.testing.assert_array_equal(logits.argmax(-1).numpy()[sure], z['argmax'][sure])
+    assert set(grads) == set(json.loads(str(z['grad_names'])))
+    check_grads_against_golden(z, grads, rtol=1e-3, atol=2e-6)
+    for k, v in stats.items():
+        np.testing.assert_allclose(v.numpy(), z['stat/' + k], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
         ev = po.forward({**sd, **stats}, x, training=False, **kw)
     np.testing.assert_allclose(ev.numpy(), z['logits_eval'], rtol=0, atol=2e-5)
 
