@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Throughput of the point-cloud training step (forward + CE + backward + SGD) on one MI355X.
-   python tools/point_bench.py cfg4|cfg5 [steps]     cfg4: cls 1024 pts x 6, B=128; cfg5: seg 2048 pts x 22, B=32"""
+   python tools/point_bench.py cfg4|cfg5 [steps]     cfg4: cls 1024 pts x 6, B=128; cfg5: seg 2048 pts x 22, B=32
+   VARIANT=3DViT_1_layer|3DViT_0_layer|3DViT_LWF BACKBONE=deit_small_patch16_224 select the other part-seg model directories
+   (config/model/3DViT_*.yaml) on the cfg5 data shape; LWF=1 adds the image branch of train_partseg_lwf.py (IMG_BATCH images)."""
 import json
 import os
 import sys
@@ -21,21 +23,30 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     c = CFG[name]
     B = int(os.environ.get('BATCH', c['batch']))
-    eng = PointEngine(backbone='deit_tiny_patch16_224', n_points=c['n_points'], d_points=c['d_points'], n_classes=c['n_classes'],
-                      task=c['task'], device='cuda')
-    eng.load_state_dict(po.init_state_dict(backbone='deit_tiny_patch16_224', n_classes=c['n_classes'], d_points=c['d_points'], seed=9))
-    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9)
+    variant = os.environ.get('VARIANT', '3DViT')
+    backbone = os.environ.get('BACKBONE', 'deit_tiny_patch16_224')
+    lwf = os.environ.get('LWF', '0') == '1'
+    eng = PointEngine(backbone=backbone, n_points=c['n_points'], d_points=c['d_points'], n_classes=c['n_classes'],
+                      task=c['task'], device='cuda', variant=variant)
+    eng.load_state_dict(po.init_state_dict(backbone=backbone, n_classes=c['n_classes'], d_points=c['d_points'], seed=9, variant=variant))
+    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9, variant=variant)
     x, y, starts = x.cuda(), y.cuda(), tuple(s.cuda() for s in starts)
+    if lwf:
+        Bi = int(os.environ.get('IMG_BATCH', B))
+        img = (torch.rand(Bi, 3, 224, 224, generator=torch.Generator().manual_seed(9)) * 2 - 1).cuda()
+        yi = torch.randint(0, 1000, (Bi,), generator=torch.Generator().manual_seed(10)).cuda()
+        train = lambda: eng.lwf_train_step(x, y, starts, img, yi, 0.1)[0]
+    else:
+        train = lambda: eng.train_step(x, y, starts)
     for _ in range(3):
-        loss = eng.train_step(x, y, starts)
+        loss = train()
     torch.cuda.synchronize()
-    use_graph = os.environ.get('GRAPH', '1') != '0'
+    use_graph = os.environ.get('GRAPH', '1') != '0' and not lwf
     if use_graph:                                   # the step has no host synchronisation: capture it once, replay it
         graph, loss = eng.capture_train_step(x, y, starts)
         step = graph.replay
     else:
-        def step():
-            return eng.train_step(x, y, starts)
+        step = train
     step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -43,7 +54,7 @@ def main():
         step()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    out = dict(config=name, batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
+    out = dict(config=name, variant=variant, backbone=backbone, lwf=lwf, batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
                points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='hipGraph replay' if use_graph else 'eager')
     print(json.dumps(out))
 
