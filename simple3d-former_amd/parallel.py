@@ -1,5 +1,6 @@
-"""Data-parallel training of the voxel path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on
-ROCm; "gloo" in the CPU tests), replicated parameters, per-step gradient all-reduce.
+"""Data-parallel training of the voxel path (DataParallelTrainer) and of the point path (PointDataParallelTrainer): one
+process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests), replicated
+parameters, per-step gradient all-reduce.
 
 Reference behaviour reproduced (train_cls_voxel.py): DDP constructor broadcast of rank-0 parameters (:155-159), mean
 all-reduce of gradients overlapped with backward (:287), DistributedSampler's index partition without set_epoch
@@ -144,4 +145,105 @@ class DataParallelTrainer:
             self.capture(x.shape[0], weight)
         self._cap['x'].copy_(x, non_blocking=True)
         self._cap['y'].copy_(y, non_blocking=True)
+        return self.step_graph()
+
+
+class PointDataParallelTrainer:
+    """Data-parallel step of the point path (cfg-4 on 4 GPUs, cfg-5 on 8): replicated parameters, each rank
+    trains on its own clouds, gradients are averaged once per step, SGD+momentum on every rank.  The reference's point
+    trainers are single-GPU, so the contract is: per-replica arithmetic == the single-GPU path, BatchNorm statistics stay
+    replica-local (no SyncBN; DDP's constructor broadcast still copies rank 0's parameters AND running statistics once).
+
+    The backward runs in two halves (PointEngine.backward_top / backward_bottom): when the top half returns, the gradient
+    slice [grad_split, numel) -- transformer blocks, TransitionUps, heads: 97 % of the parameters -- is final and its
+    all-reduce is in flight on RCCL's stream while the TransitionDown half computes; the small head slice follows.  The
+    1/world averaging is folded into the fused SGD kernel (grad_scale).  With HIP graphs: [forward, CE, top] | RCCL |
+    [bottom] | RCCL | [SGD], i.e. three replays and two collectives per step."""
+
+    def __init__(self, engine, group=None, use_graphs=True, force_collectives=False):
+        self.eng, self.group = engine, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        broadcast_parameters(engine.arena.p, 0, group)
+        for buf in engine.bn_buffers():
+            broadcast_parameters(buf, 0, group)
+        engine.refresh_weight_planes()
+        split, n = engine.grad_split(), engine.arena.g.numel()
+        self.slices = [(split, n), (0, split)] if 0 < split < n else [(0, n)]
+        self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives)
+        engine.grad_scale = 1.0 / self.world
+        self.use_graphs = use_graphs
+        self._cap = None
+
+    def _halves(self, B, x, y, starts):
+        eng = self.eng
+
+        def top():
+            eng.forward(x, starts)
+            eng.cross_entropy(B, y)
+            eng.backward_top(B)
+
+        return [top, lambda: eng.backward_bottom(B)]
+
+    def step_eager(self, x, y, starts):
+        eng, B = self.eng, x.shape[0]
+        halves = self._halves(B, x, y, starts)
+        for k, fn in enumerate(halves):
+            fn()
+            if k < len(self.slices):
+                self.reducer.launch(k)
+        self.reducer.wait()
+        loss = eng.workspace(B).loss[0]
+        eng.sgd_step()
+        return loss
+
+    def capture(self, x, y, starts):
+        """Captures the three graphs over the given static buffers (copy new batches / FPS starts into them, then step_graph())."""
+        eng, B = self.eng, x.shape[0]
+        state = [eng.arena.p, eng.arena.g, eng.buf, eng.sgd_steps] + eng.bn_buffers()
+        snap = [t.clone() for t in state]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                   # warm-up: kernel attributes, workspaces
+            for fn in self._halves(B, x, y, starts):
+                fn()
+            eng.sgd_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        for t, sv in zip(state, snap):
+            t.copy_(sv)
+        eng.refresh_weight_planes()
+        torch.cuda.synchronize()
+        graphs = []
+        for fn in self._halves(B, x, y, starts):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            graphs.append(g)
+        g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_opt):
+            eng.sgd_step()
+        self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=x, y=y, starts=starts, loss=eng.workspace(B).loss)
+        return self._cap
+
+    def step_graph(self):
+        cap = self._cap
+        for k, g in enumerate(cap['graphs']):
+            g.replay()
+            if k < len(self.slices):
+                self.reducer.launch(k)
+        self.reducer.wait()
+        cap['opt'].replay()
+        return cap['loss'][0]
+
+    def step(self, x, y, starts):
+        if not self.use_graphs:
+            return self.step_eager(x, y, starts)
+        if self._cap is None or self._cap['B'] != x.shape[0]:
+            sx, sy, ss = x.clone(), y.clone(), tuple(s.clone() for s in starts)
+            self.capture(sx, sy, ss)
+        cap = self._cap
+        cap['x'].copy_(x, non_blocking=True)
+        cap['y'].copy_(y, non_blocking=True)
+        for d, s in zip(cap['starts'], starts):
+            d.copy_(s, non_blocking=True)
         return self.step_graph()

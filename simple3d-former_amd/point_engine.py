@@ -279,6 +279,10 @@ class PointEngine:
             sd[k + '.running_mean'] = bn.run_mean.clone(); sd[k + '.running_var'] = bn.run_var.clone()
         return sd
 
+    def bn_buffers(self):
+        """Running statistics of every BatchNorm (what DDP's constructor broadcast copies besides the parameters)."""
+        return [t for bn in self.bns.values() for t in (bn.run_mean, bn.run_var)]
+
     def refresh_weight_planes(self):
         self.arena.refresh_planes()
         for l in self._linears:
@@ -474,6 +478,17 @@ class PointEngine:
 
     # ------------------------------------------------------------------ backward
     def backward(self, B):
+        self.backward_top(B)
+        self.backward_bottom(B)
+
+    def grad_split(self):
+        """Arena offset where the gradients written by backward_top start (cls_token, blocks, norm, TransitionUps, heads):
+        everything at or above it is final when backward_top returns, so a data-parallel trainer can all-reduce that slice
+        while backward_bottom (TransitionDowns + the input MLPs) still runs."""
+        return self.arena.offsets['cls_token']
+
+    def backward_top(self, B):
+        """head -> TransitionUps -> final norm -> 12 blocks -> cls-token gradient."""
         ws = self.workspace(B)
         lib, s, a, C0, D, N = self.lib, L.current_stream(), self.arena, self.C0, self.D, self.N
         BN = B * N
@@ -518,6 +533,12 @@ class PointEngine:
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'cls grad')
         dtok = ws.td[-1].dout if nl else ws.df                   # 3DViT_0_layer: the tokens are f itself
         L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(dtok), ctypes.c_long(B), S1, D, s), 'tokens bwd')
+
+    def backward_bottom(self, B):
+        """TransitionDowns (reverse) -> fc1 / fc_pos_embed."""
+        ws = self.workspace(B)
+        lib, s, C0, N, nl = self.lib, L.current_stream(), self.C0, self.N, self.levels
+        BN = B * N
         # transition downs (reverse): dout of the top level is complete; the lower levels' dout already hold their tu's contribution
         for i in reversed(range(nl)):
             t, lay = ws.td[i], self.td[i]

@@ -373,3 +373,36 @@ def test_drop_in_module_honours_bn_momentum_adjust():
     k = 'transition_ups.0.fc2.2.running_mean'
     batch_mean = (z['stat/' + k] - 0.9 * sd[k].numpy()) / 0.1            # the fixture ran with the default momentum 0.1
     np.testing.assert_allclose(dict(model.named_buffers())[k].cpu().numpy(), 0.5 * sd[k].numpy() + 0.5 * batch_mean, rtol=1e-3, atol=1e-4)
+
+
+def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
+    """PointDataParallelTrainer on one GPU: [forward, CE, backward_top] | RCCL | [backward_bottom] | RCCL | [SGD] captured as three
+    HIP graphs with forced all-reduces, vs the plain eager train_step -- for the two-level model and a variant."""
+    import os
+    import torch.distributed as dist
+    from simple3d_former_amd.parallel import PointDataParallelTrainer
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29519')
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        for variant, task, dp, nc in (('3DViT', 'cls', 6, 40), ('3DViT_1_layer', 'seg', 22, 50)):
+            kw = dict(backbone='deit_tiny_patch16_224', n_points=64, d_points=dp, n_classes=nc)
+            sd = po.init_state_dict(backbone=kw['backbone'], n_classes=nc, d_points=dp, seed=3, variant=variant)
+            x, y, starts = po.synthetic_points(4, 64, dp, nc, task, seed=4, variant=variant)
+            x, y, sts = x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts)
+            ref = PointEngine(task=task, device=DEV, variant=variant, **kw); ref.load_state_dict(sd)
+            eng = PointEngine(task=task, device=DEV, variant=variant, **kw); eng.load_state_dict(sd)
+            tr = PointDataParallelTrainer(eng, use_graphs=True, force_collectives=True)
+            split = eng.arena.offsets['cls_token']
+            assert tr.slices == [(split, eng.arena.g.numel()), (0, split)] and eng.grad_scale == 1.0
+            p0 = ref.arena.p.clone()
+            for step in range(3):
+                l_ref = float(ref.train_step(x, y, sts))
+                l_dp = float(tr.step(x, y, sts))
+                assert abs(l_ref - l_dp) <= 2e-3, f'{variant} step {step}: {l_ref} vs {l_dp}'
+            upd = float((ref.arena.p - p0).abs().max())
+            d = float((eng.arena.p - ref.arena.p).abs().max())
+            assert d <= 0.02 * upd + 1e-6, f'{variant}: replicas differ by {d:.3e} (largest update {upd:.3e})'
+            for a, b in zip(eng.bn_buffers(), ref.bn_buffers()):
+                assert float((a - b).abs().max()) <= 1e-4
+    finally:
+        dist.destroy_process_group()

@@ -10,7 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from simple3d_former_amd.parallel import BucketedGradReducer, DataParallelTrainer, broadcast_parameters, shard_indices
+from simple3d_former_amd.parallel import (BucketedGradReducer, DataParallelTrainer, PointDataParallelTrainer, broadcast_parameters,
+                                          shard_indices)
 
 
 class _Arena:
@@ -122,6 +123,97 @@ def test_two_rank_data_parallel_equals_single_process_full_batch():
     assert torch.equal(res[0][2], torch.full((10,), 3.0))       # 1 + 2 summed over both buckets
     assert res[0][3] == [(5, 3), (2, 1), (0, 0)]                 # backward order, 3 buckets shrinking towards the input
     assert res[0][4] == [(192, 384), (64, 192), (0, 64)]         # contiguous arena slices tiling [0, numel)
+
+
+class FakePointEngine(FakeEngine):
+    """Same stand-in with PointEngine's DP interface: backward in two halves around grad_split, running-stat buffers, SGD."""
+
+    def __init__(self, seed=0):
+        super().__init__(depth=6, width=8, seed=seed)
+        self.stats = torch.full((4,), float(seed))               # "BatchNorm running statistics": replica-local after the broadcast
+        self.buf = torch.zeros_like(self.arena.p)
+        self.sgd_steps = torch.zeros(1, dtype=torch.int32)
+        self.ws = type('WS', (), {})()
+        self.ws.loss = torch.zeros(2)
+
+    def bn_buffers(self): return [self.stats]
+    def grad_split(self): return self.arena.offsets['blocks.2.norm1.weight']     # layers 2..5 = "top", 0..1 = "bottom"
+    def workspace(self, B): return self.ws
+
+    def forward(self, x, starts):
+        self.stats.add_(float(x.sum()))                          # batch-dependent, never all-reduced
+        return FakeEngine.forward(self, x)
+
+    def cross_entropy(self, B, y):
+        self.ws.loss[0] = FakeEngine.cross_entropy(self, B, y)
+        return self.ws.loss[0]
+
+    def backward_top(self, B):
+        self._d = None
+        FakePointEngine.backward(self, B, segments=[(5, 2)])
+
+    def backward(self, B, segments=None, on_segment=None):       # keeps the running upstream gradient between the halves
+        d = self.dout if getattr(self, '_d', None) is None else self._d
+        for first, last in segments:
+            for i in range(first, last - 1, -1):
+                d = d * (1 - self.acts[i + 1] ** 2)
+                self.W(i, self.arena.g).add_(d.t() @ self.acts[i])
+                d = d @ self.W(i)
+        self._d = d
+
+    def backward_bottom(self, B):
+        FakePointEngine.backward(self, B, segments=[(1, 0)])
+
+    def sgd_step(self):
+        self.arena.p.add_(self.arena.g, alpha=-self.lr * self.grad_scale)
+        self.arena.g.zero_()
+
+
+def _point_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100)
+        X = torch.randn(8, 8); Y = torch.randn(8, 8)
+        eng = FakePointEngine(seed=rank + 1)
+        tr = PointDataParallelTrainer(eng, use_graphs=False)
+        stats0 = eng.stats.clone()                               # after the constructor broadcast
+        sl = slice(rank * 4, rank * 4 + 4)
+        losses = [float(tr.step(X[sl], Y[sl], ())) for _ in range(3)]
+        q.put((rank, eng.arena.p.clone(), stats0, eng.stats.clone(), tr.slices, eng.grad_scale, losses))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_point_trainer_two_ranks_equal_single_process_full_batch():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_point_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    ref = FakePointEngine(seed=1)                                # rank 0's initial parameters, full batch, no process group
+    tr = PointDataParallelTrainer(ref, use_graphs=False)
+    assert tr.world == 1 and ref.grad_scale == 1.0
+    for _ in range(3):
+        tr.step(X, Y, ())
+    assert torch.equal(res[0][1], res[1][1]), 'replicas diverged'
+    assert float((res[0][1] - ref.arena.p).abs().max()) < 1e-6, 'DP on two half batches != full batch'
+    assert torch.equal(res[0][2], res[1][2]) and float(res[1][2][0]) == 1.0      # running statistics broadcast from rank 0 once ...
+    assert not torch.equal(res[0][3], res[1][3])                                  # ... and replica-local afterwards (no SyncBN)
+    assert res[0][4] == [(128, 384), (0, 128)] and res[0][5] == 0.5               # top slice first, 1/world folded into SGD
+    plain = FakeEngine(seed=1)                                   # the two halves together == the unsplit backward
+    plain.lr = ref.lr
+    segs, _ = plain.grad_buckets(1)
+    for _ in range(3):
+        plain.forward(X); plain.cross_entropy(8, Y); plain.backward(8, segments=segs); plain.adam_step()
+    assert float((plain.arena.p - ref.arena.p).abs().max()) < 1e-6
 
 
 def test_shard_indices_matches_distributed_sampler():

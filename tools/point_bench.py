@@ -2,7 +2,10 @@
 """Throughput of the point-cloud training step (forward + CE + backward + SGD) on one MI355X.
    python tools/point_bench.py cfg4|cfg5 [steps]     cfg4: cls 1024 pts x 6, B=128; cfg5: seg 2048 pts x 22, B=32
    VARIANT=3DViT_1_layer|3DViT_0_layer|3DViT_LWF BACKBONE=deit_small_patch16_224 select the other part-seg model directories
-   (config/model/3DViT_*.yaml) on the cfg5 data shape; LWF=1 adds the image branch of train_partseg_lwf.py (IMG_BATCH images)."""
+   (config/model/3DViT_*.yaml) on the cfg5 data shape; LWF=1 adds the image branch of train_partseg_lwf.py (IMG_BATCH images).
+   Data parallel (cfg-4 on 4 GPUs, cfg-5 on 8; weak scaling, `batch` clouds per GPU), one process per GPU over RCCL:
+   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/point_bench.py cfg5
+   (rank 0 prints the whole-job rate; FORCE_COLLECTIVES=1 issues the all-reduces at N = 1 too)."""
 import json
 import os
 import sys
@@ -19,6 +22,13 @@ CFG = {'cfg4': dict(task='cls', n_points=1024, d_points=6, n_classes=40, batch=1
 
 
 def main():
+    import torch.distributed as dist
+    rank, world, local = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('WORLD_SIZE', 1), ('LOCAL_RANK', 0)))
+    force = os.environ.get('FORCE_COLLECTIVES', '0') == '1'
+    torch.cuda.set_device(local)
+    if world > 1 or force:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
     name = sys.argv[1] if len(sys.argv) > 1 else 'cfg4'
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     c = CFG[name]
@@ -29,7 +39,7 @@ def main():
     eng = PointEngine(backbone=backbone, n_points=c['n_points'], d_points=c['d_points'], n_classes=c['n_classes'],
                       task=c['task'], device='cuda', variant=variant)
     eng.load_state_dict(po.init_state_dict(backbone=backbone, n_classes=c['n_classes'], d_points=c['d_points'], seed=9, variant=variant))
-    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9, variant=variant)
+    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9 + rank, variant=variant)
     x, y, starts = x.cuda(), y.cuda(), tuple(s.cuda() for s in starts)
     if lwf:
         Bi = int(os.environ.get('IMG_BATCH', B))
@@ -42,21 +52,41 @@ def main():
         loss = train()
     torch.cuda.synchronize()
     use_graph = os.environ.get('GRAPH', '1') != '0' and not lwf
-    if use_graph:                                   # the step has no host synchronisation: capture it once, replay it
+    dp = dist.is_initialized() and not lwf
+    if dp:                                          # graphs [fwd, CE, bwd top] | RCCL | [bwd bottom] | RCCL | [SGD]
+        from simple3d_former_amd.parallel import PointDataParallelTrainer
+        tr = PointDataParallelTrainer(eng, use_graphs=use_graph, force_collectives=force)
+        loss = tr.step(x, y, starts)
+        step = (lambda: tr.step_graph()) if use_graph else (lambda: tr.step_eager(x, y, starts))
+    elif use_graph:                                   # the step has no host synchronisation: capture it once, replay it
         graph, loss = eng.capture_train_step(x, y, starts)
         step = graph.replay
     else:
         step = train
     step()
     torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
     el = time.perf_counter() - t0
-    out = dict(config=name, variant=variant, backbone=backbone, lwf=lwf, batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
+    if dist.is_initialized():
+        t = torch.tensor([el], device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+    B *= world                                      # whole-job figures
+    if rank != 0:
+        dist.destroy_process_group()
+        return
+    out = dict(config=name, variant=variant, backbone=backbone, lwf=lwf, n_gpus=world, scaling='weak', global_batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
                points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='hipGraph replay' if use_graph else 'eager')
     print(json.dumps(out))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
