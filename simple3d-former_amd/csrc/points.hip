@@ -19,72 +19,96 @@ __device__ __forceinline__ float sqdist(float ax, float ay, float az, float bx, 
 }
 
 // ------------------------------------------------------------------------------------------- FPS
-// One workgroup per cloud; the cloud lives in LDS, running min-distances in registers.  npoint sequential iterations of
-// {update min distance to the newest centroid, argmax}; ties resolve to the smallest index (torch.max's first maximum).
-constexpr int FPS_PPT = 8;   // points per thread -> N <= 2048
+// One workgroup (4 waves) per cloud.  npoint strictly sequential iterations of {update the running min distance to the newest
+// centroid, argmax}; ties resolve to the smallest index (torch.max's first maximum).  An iteration is pure latency, so the
+// kernel is built around its critical path: coordinates and running distances live in registers (PPT points per thread), the
+// wave maximum is six DPP max steps (row_shr 1/2/4/8, row_bcast 15/31 -- max is idempotent, so no row / bank masks are needed)
+// read back from lane 63, the winning lane is found by ballot (exact ties, rare, fall back to a scalar loop), and the four
+// wave results meet in a double-buffered LDS slot with ONE barrier per iteration: every thread then reduces the four slots
+// itself and fetches the new centroid with a broadcast LDS read.  (First version: cloud re-read from LDS every iteration, 12
+// ds_bpermute shuffles and three barriers per iteration -- 1.28 us per iteration.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);
+#define S3D_DPP_MAX(ctrl)                                                                  \
+    {                                                                                      \
+        const int t = __builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false);            \
+        x = __float_as_int(fmaxf(__int_as_float(x), __int_as_float(t)));                   \
+    }
+    S3D_DPP_MAX(0x111) S3D_DPP_MAX(0x112) S3D_DPP_MAX(0x114) S3D_DPP_MAX(0x118)           // row_shr:1,2,4,8 -> lane 15 of each row
+    S3D_DPP_MAX(0x142) S3D_DPP_MAX(0x143)                                                 // row_bcast:15, row_bcast:31 -> lane 63
+#undef S3D_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(x, 63));
+}
+__device__ __forceinline__ int wave_min_i32(int x) {
+#define S3D_DPP_MIN(ctrl) x = min(x, __builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false));
+    S3D_DPP_MIN(0x111) S3D_DPP_MIN(0x112) S3D_DPP_MIN(0x114) S3D_DPP_MIN(0x118) S3D_DPP_MIN(0x142) S3D_DPP_MIN(0x143)
+#undef S3D_DPP_MIN
+    return __builtin_amdgcn_readlane(x, 63);
+}
 
+constexpr int FPS_MAX_PPT = 8;   // points per thread -> N <= 2048
+
+template <int PPT>
 __global__ __launch_bounds__(256) void fps_kernel(const float* __restrict__ xyz, long xyz_ld, const long long* __restrict__ start,
                                                   int N, int npoint, int* __restrict__ out_idx, float* __restrict__ new_xyz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* sx = reinterpret_cast<float*>(smem);          // [N][3]
-    float* rv = sx + 3 * N;                              // [4] wave maxima
-    int* ri = reinterpret_cast<int*>(rv + 4);            // [4] wave argmax
-    int* sfar = ri + 4;
+    f32x4* sx = reinterpret_cast<f32x4*>(smem);                         // [N] (x, y, z, -)
+    f32x4* slot = sx + N;                                               // [2][2]: per buffer (v0 i0 v1 i1) (v2 i2 v3 i3)
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = xyz + (long)b * N * xyz_ld;
-    for (int i = tid; i < N; i += 256) {
-        sx[3 * i] = src[(long)i * xyz_ld]; sx[3 * i + 1] = src[(long)i * xyz_ld + 1]; sx[3 * i + 2] = src[(long)i * xyz_ld + 2];
-    }
-    float dist[FPS_PPT];
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
 #pragma unroll
-    for (int j = 0; j < FPS_PPT; ++j) dist[j] = 1e10f;
-    if (tid == 0) *sfar = (int)start[b];
+    for (int j = 0; j < PPT; ++j) {
+        const int i = tid + j * 256;
+        const bool in = i < N;
+        const float* q = src + (long)(in ? i : 0) * xyz_ld;
+        px[j] = q[0]; py[j] = q[1]; pz[j] = q[2];
+        dist[j] = in ? 1e10f : -1.f;                                    // padding lanes can never win (distances are >= 0)
+        if (in) sx[i] = f32x4{px[j], py[j], pz[j], 0.f};
+    }
+    int far = (int)start[b];
     __syncthreads();
     for (int it = 0; it < npoint; ++it) {
-        const int far = *sfar;
-        const float cx = sx[3 * far], cy = sx[3 * far + 1], cz = sx[3 * far + 2];
+        const f32x4 c = sx[far];
         if (tid == 0) {
             out_idx[(long)b * npoint + it] = far;
             float* o = new_xyz + ((long)b * npoint + it) * 3;
-            o[0] = cx; o[1] = cy; o[2] = cz;
+            o[0] = c[0]; o[1] = c[1]; o[2] = c[2];
         }
         float best = -1.f;
         int bi = 0x7fffffff;
 #pragma unroll
-        for (int j = 0; j < FPS_PPT; ++j) {
-            const int pidx = tid + j * 256;
-            if (pidx < N) {
-                const float d = sqdist(sx[3 * pidx], sx[3 * pidx + 1], sx[3 * pidx + 2], cx, cy, cz);
-                dist[j] = fminf(dist[j], d);
-                if (dist[j] > best) { best = dist[j]; bi = pidx; }       // strict >: first (smallest) index wins
-            }
+        for (int j = 0; j < PPT; ++j) {
+            const float d = sqdist(px[j], py[j], pz[j], c[0], c[1], c[2]);
+            dist[j] = fminf(dist[j], d);                                // -1 stays -1 for padding
+            if (dist[j] > best) { best = dist[j]; bi = tid + j * 256; } // strict >: first (smallest) index wins
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-        }
-        __syncthreads();                                  // everyone has read *sfar
-        if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+        const float wmax = wave_max_nonneg(best);
+        const unsigned long long tied = __ballot(best == wmax);
+        int wbi;
+        if ((tied & (tied - 1)) == 0) wbi = __builtin_amdgcn_readlane(bi, __ffsll((long long)tied) - 1);
+        else wbi = wave_min_i32(best == wmax ? bi : 0x7fffffff);       // exact ties across lanes (duplicates, padding): smallest index
+        float* sl = reinterpret_cast<float*>(slot + 2 * (it & 1));
+        if (lane == 0) { sl[2 * wave] = wmax; sl[2 * wave + 1] = __int_as_float(wbi); }
         __syncthreads();
-        if (tid == 0) {
-            float v = rv[0]; int ix = ri[0];
-#pragma unroll
-            for (int w = 1; w < 4; ++w) if (rv[w] > v || (rv[w] == v && ri[w] < ix)) { v = rv[w]; ix = ri[w]; }
-            *sfar = ix;
-        }
-        __syncthreads();
+        const f32x4 a = slot[2 * (it & 1)], e = slot[2 * (it & 1) + 1];
+        float v = a[0]; int ix = __float_as_int(a[1]);
+        { const float ov = a[2]; const int oi = __float_as_int(a[3]); if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; } }
+        { const float ov = e[0]; const int oi = __float_as_int(e[1]); if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; } }
+        { const float ov = e[2]; const int oi = __float_as_int(e[3]); if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; } }
+        far = ix;
     }
 }
 
 // ------------------------------------------------------------------------------------------- kNN
-// One wave per query point: distances to all N reference points in registers (<= 32 per lane), then K rounds of
-// {lane-local min over not-yet-taken, wave argmin}.  Ascending distance; ties -> smaller index.  K == 3 also emits the
-// normalised inverse-distance weights of PointNetFeaturePropagation (data/pointnet_util.py:401-408).
-constexpr int KNN_PPL = 32;  // N <= 2048
+// One wave per query point: distances to all N reference points in registers (PPL <= 32 per lane, templated so that small
+// clouds do not scan dead registers), then K rounds of {lane-local min over not-yet-taken, wave argmin}.  The wave argmin
+// is a DPP min over the distance bits (distances are >= 0, so their bit patterns order like the floats) + a ballot for the
+// owning lane; exact ties fall back to a DPP min over the indices.  Ascending distance; ties -> smaller index.  K == 3 also
+// emits the normalised inverse-distance weights of PointNetFeaturePropagation (data/pointnet_util.py:401-408).
+constexpr int KNN_MAX_PPL = 32;  // N <= 2048
 
-template <int K>
+template <int K, int KNN_PPL>
 __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ query, const float* __restrict__ ref, int S, int N,
                                                   long total, int* __restrict__ out_idx, float* __restrict__ out_w) {
     const int lane = threadIdx.x & 63;
@@ -111,14 +135,11 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ quer
         for (int j = 0; j < KNN_PPL; ++j)
             if (!((taken >> j) & 1u) && d[j] < best) { best = d[j]; bj = j; }
         int bi = (bj < 0) ? 0x7fffffff : lane + bj * 64;
-        float v = best;
-        int ix = bi;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(v, o, 64);
-            const int oi = __shfl_xor(ix, o, 64);
-            if (ov < v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-        }
+        const float v = __int_as_float(wave_min_i32(__float_as_int(best)));
+        const unsigned long long tied = __ballot(best == v);
+        int ix;
+        if ((tied & (tied - 1)) == 0) ix = __builtin_amdgcn_readlane(bi, __ffsll((long long)tied) - 1);
+        else ix = wave_min_i32(best == v ? bi : 0x7fffffff);
         if (ix == bi && bj >= 0) taken |= (1u << bj);
         wi[k] = ix;
         wv[k] = 1.0f / (v + 1e-8f);
@@ -576,19 +597,29 @@ inline unsigned grid_for(long n, int per = 256, long cap = 8192) {
 // ---------------------------------------------------------------------------------------------- launchers
 int s3d_launch_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx,
                    float* new_xyz, hipStream_t s) {
-    S3D_REQUIRE(N <= 256 * FPS_PPT, "fps: N=%d exceeds %d points per cloud", N, 256 * FPS_PPT);
-    const int lds = 3 * N * 4 + 64;
-    hipLaunchKernelGGL(fps_kernel, dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
+    S3D_REQUIRE(N <= 256 * FPS_MAX_PPT, "fps: N=%d exceeds %d points per cloud", N, 256 * FPS_MAX_PPT);
+    const int lds = (N + 4) * 16;
+    if (N <= 256) hipLaunchKernelGGL((fps_kernel<1>), dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
+    else if (N <= 512) hipLaunchKernelGGL((fps_kernel<2>), dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
+    else if (N <= 1024) hipLaunchKernelGGL((fps_kernel<4>), dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
+    else hipLaunchKernelGGL((fps_kernel<8>), dim3(B), dim3(256), lds, s, xyz, xyz_ld, start, N, npoint, out_idx, new_xyz);
     S3D_CHECK_LAUNCH("fps");
     return 0;
 }
 int s3d_launch_knn(const float* query, const float* ref, int B, int S, int N, int K, int* out_idx, float* out_w, hipStream_t s) {
-    S3D_REQUIRE(N <= 64 * KNN_PPL, "knn: N=%d exceeds %d reference points", N, 64 * KNN_PPL);
+    S3D_REQUIRE(N <= 64 * KNN_MAX_PPL, "knn: N=%d exceeds %d reference points", N, 64 * KNN_MAX_PPL);
+    S3D_REQUIRE(K == 16 || K == 3, "knn: K=%d not built (16, 3)", K);
     const long total = (long)B * S;
     dim3 grid((unsigned)((total + 3) / 4));
-    if (K == 16) hipLaunchKernelGGL((knn_kernel<16>), grid, dim3(256), 0, s, query, ref, S, N, total, out_idx, out_w);
-    else if (K == 3) hipLaunchKernelGGL((knn_kernel<3>), grid, dim3(256), 0, s, query, ref, S, N, total, out_idx, out_w);
-    else { s3d_set_error("knn: K=%d not built (16, 3)", K); return 2; }
+#define S3D_KNN(KK, PPL) hipLaunchKernelGGL((knn_kernel<KK, PPL>), grid, dim3(256), 0, s, query, ref, S, N, total, out_idx, out_w)
+#define S3D_KNN_N(KK)                      \
+    if (N <= 256) S3D_KNN(KK, 4);          \
+    else if (N <= 512) S3D_KNN(KK, 8);     \
+    else if (N <= 1024) S3D_KNN(KK, 16);   \
+    else S3D_KNN(KK, 32);
+    if (K == 16) { S3D_KNN_N(16) } else { S3D_KNN_N(3) }
+#undef S3D_KNN_N
+#undef S3D_KNN
     S3D_CHECK_LAUNCH("knn");
     return 0;
 }
