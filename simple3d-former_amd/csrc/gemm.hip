@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
-    const int ntiles = p.K / BK;                                       // K % 64 == 0 (checked by the launcher)
+    const int ntiles = p.K / BK;                                       // K % BK == 0 (checked by the launcher)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     // 16-byte slot swizzle: 128-byte rows as in gemm_body; 64-byte rows (16 banks) repeat every 4 rows -> xor with (r >> 2) & 3
     auto swz = [](int r) { return BK == 64 ? ((r ^ (r >> 3)) & 7) : ((r >> 2) & 3); };
@@ -986,7 +986,8 @@ int launch_tiles(int tile, const GemmArgs& a, int splitk, hipStream_t stream) {
 template <bool SPLIT, int EPI>
 int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
     static const int dma = env_int("S3D_GEMM_DMA");                  // S3D_GEMM_DMA=0: register-staged 128x128 kernel instead
-    if (dma != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
+    // the 128x128 kernel steps k by 32 in split mode (64 in plain bf16): k = 96 / 160 ... (point-path channel widths) qualify too
+    if (dma != 0 && tile == 2 && (a.K & (SPLIT ? 31 : 63)) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
     if constexpr (SPLIT) {
         // small forward tiles on the same DMA pipeline with two k = 64 stages (S3D_GEMM_DMA_SMALL=0: register-staged kernel).
         // cfg-2, us: qkv 12.1 -> 9.7, proj 7.8 -> 6.4, fc1 18.8 -> 16.2, fc2 19.8 -> 14.6; three stages or k = 32 stages were neutral.

@@ -535,12 +535,26 @@ __global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __
 
 // ------------------------------------------------------------------------------------------- misc row ops
 // mean over the N points of each cloud: out[b][c] = mean_n x[b, n, c]   (x.mean(1), models/3DViT/model.py:325)
-__global__ void mean_points_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ out) {
+// One workgroup per cloud: 256 / C row lanes walk the points with coalesced channel-contiguous reads, LDS fold at the end
+// (the first version summed a column per thread with 64 threads per cloud: 245 us for 25 MB).
+__global__ __launch_bounds__(256) void mean_points_kernel(const float* __restrict__ x, int N, int C, float* __restrict__ out) {
+    __shared__ float red[256];
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int per = C <= 256 ? 256 / C : 1;
+    for (int c0 = 0; c0 < C; c0 += 256) {                       // C > 256: one column chunk at a time
+        const int cw = min(C - c0, 256);
+        const int c = threadIdx.x % cw, sub = threadIdx.x / cw;
         float s = 0.f;
-        for (int n = 0; n < N; ++n) s += x[((long)b * N + n) * C + c];
-        out[(long)b * C + c] = s / N;
+        if (sub < per)
+            for (int n = sub; n < N; n += per) s += x[((long)b * N + n) * C + c0 + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < cw) {
+            float t = 0.f;
+            for (int r = 0; r < per; ++r) t += red[r * cw + threadIdx.x];
+            out[(long)b * C + c0 + threadIdx.x] = t / N;
+        }
+        __syncthreads();
     }
 }
 // y[r][c] = scale * x[r / N][c]   (backward of the mean: broadcast dfeat / N)
@@ -721,7 +735,7 @@ int s3d_launch_interp3_bwd(const float* dout, const int* idx, const float* w, in
     return 0;
 }
 int s3d_launch_mean_points(const float* x, int B, int N, int C, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(mean_points_kernel, dim3(B), dim3(64), 0, s, x, N, C, out);
+    hipLaunchKernelGGL(mean_points_kernel, dim3(B), dim3(256), 0, s, x, N, C, out);
     S3D_CHECK_LAUNCH("mean_points");
     return 0;
 }

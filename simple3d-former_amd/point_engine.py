@@ -107,11 +107,12 @@ def bn_buffer_names(backbone, variant='3DViT'):
 class _Linear:
     """y = x @ W^T + b with W [out][in] taken from the arena (padded bf16 planes when `in` or `out` need padding)."""
 
-    def __init__(self, eng, key, out_pad=None):
+    def __init__(self, eng, key, out_pad=None, k_pad=None):
         a = eng.arena
         shp = a.shapes[key + '.weight']
         self.key, self.out, self.inn = key, shp[0], int(np.prod(shp[1:]))
-        self.kpad = _round_up(self.inn, 8)
+        self.kcols = _round_up(self.inn, 8)                     # columns that can be non-zero
+        self.kpad = k_pad or self.kcols                         # row pitch of the input planes / weight rows
         self.opad = out_pad or self.out
         self.padded = (self.kpad != self.inn) or (self.opad != self.out)
         dev = eng.device
@@ -157,7 +158,7 @@ class _Linear:
             if self.opad != self.out:
                 a.grad(self.key + '.bias').add_(self.gbias[:self.out])
         if dx is not None or kw:
-            g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kpad, K=self.opad,
+            g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kcols, K=self.opad,
                        alpha=1.0, **({'C': dx, 'ldc': self.kpad} if dx is not None else {}), **kw)
             L.check(lib.s3d_gemm(0, 1, 0, dx_epi, ctypes.byref(g), 1, s), self.key + ' dgrad')
 
@@ -229,7 +230,7 @@ class PointEngine:
         self.td = []
         for i in range(self.levels):
             p = f'transition_downs.{i}.sa.'
-            self.td.append(dict(c0=_Linear(self, p + 'mlp_convs.0'), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
+            self.td.append(dict(c0=_Linear(self, p + 'mlp_convs.0', k_pad=self._cinp(i)), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
                                 c1=_Linear(self, p + 'mlp_convs.1'), b1=_BatchNorm(self, p + 'mlp_bns.1', self.ch[i])))
         self.tu = []
         for j, i in enumerate(reversed(range(self.levels))):
@@ -291,6 +292,12 @@ class PointEngine:
     def zero_grad(self):
         self.arena.g.zero_()
 
+    def _cinp(self, i):
+        """Row pitch of the gathered [xyz_rel | feats] matrix of td i: k must be a multiple of 32 for the LDS-DMA forward GEMM
+        (51 -> 64, 99 -> 128 columns; the padding columns are zero and cost 14-23 % more bytes on that one operand, the
+        register-staged fallback kernel costs more)."""
+        return _round_up(self.cin[i], 32)
+
     # ------------------------------------------------------------------ workspace
     def workspace(self, B):
         ws = self._ws.get(B)
@@ -311,7 +318,7 @@ class PointEngine:
         xyz_n = N
         cprev = C0
         for i in range(self.levels):
-            S, ch, cinp = self.S[i], self.ch[i], _round_up(self.cin[i], 8)
+            S, ch, cinp = self.S[i], self.ch[i], self._cinp(i)
             R = B * S * KNN
             t = type('TD', (), {})()
             t.S, t.R, t.cinp, t.Nin, t.Cin = S, R, cinp, xyz_n, cprev
