@@ -123,6 +123,11 @@ typedef struct S3dAttnArgs {
     float* delta;
     /* optional dropout on the attention weights, index ((b*H + h)*N + q)*N + key, see S3dGemmArgs */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
+    /* block-diagonal attention: 0 = off; otherwise a query attends only to the keys of its own segment of `seg` consecutive
+     * tokens (needs seg <= N <= 2*seg and N <= 32).  The launchers use it themselves to put TWO short sequences (N <= 16,
+     * contiguous in memory: group_embed pass 1 has N = 15) into one 32-row MFMA tile; lse / delta are then laid out for the
+     * packed problem (Bb/2, 2N), consistently between forward and backward. */
+    int seg;
 } S3dAttnArgs;
 int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
 int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);

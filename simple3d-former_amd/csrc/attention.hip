@@ -33,6 +33,9 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) {
 }
 
 // cooperative (one wave) copy of a [32 rows][HD] bf16 tile into this wave's LDS region (row pitch HD*2 bytes)
+// block-diagonal mask of two packed sequences (S3dAttnArgs::seg): query and key must lie in the same segment
+__device__ __forceinline__ bool seg_ok(const AttnArgs& p, int q, int k) { return p.seg == 0 || ((q >= p.seg) == (k >= p.seg)); }
+
 template <int HD>
 __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld, long row0_off, long st_ld, int t0,
                                            int N, int lane) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         float sv[16], mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool ok = (k0 + acc_row(r, h2)) < p.N;
+            const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok(p, qrow_c, k0 + acc_row(r, h2));
             sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
             mloc = fmaxf(mloc, sv[r]);
         }
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j;
-                const bool ok = (k0 + acc_row(r, h2)) < p.N;
+                const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok(p, qrow_c, k0 + acc_row(r, h2));
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j;
                 const int q = q0 + acc_row(r, h2);
-                const bool ok = kok && (q < p.N);
+                const bool ok = kok && (q < p.N) && seg_ok(p, q, krow_c);
                 const int qc = min(q, p.N - 1);
                 const float lse_r = ldsR[acc_row(r, h2)];
                 const float del_r = ldsR[32 + acc_row(r, h2)];
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j, key = acc_row(r, h2);
-                const float pr = key < p.N ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+                const float pr = (key < p.N && seg_ok(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
                     dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j, q = acc_row(r, h2);
-                const bool ok = tok_ok && (q < p.N);
+                const bool ok = tok_ok && (q < p.N) && seg_ok(p, q, tok);
                 const int qc = min(q, p.N - 1);
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
                 float dm = 1.f;
@@ -1129,13 +1132,31 @@ int check(const AttnArgs& a) {
     S3D_REQUIRE(hd == 48 || hd == 64 || hd == 96 || hd == 192 || hd == 256, "attention: head dim %d not built (48/64/96/192/256)", hd);
     S3D_REQUIRE(a.N > 0 && a.Bb > 0, "attention: empty problem");
     S3D_REQUIRE(a.ld % 8 == 0 && a.ldo % 8 == 0, "attention: leading dims must be multiples of 8");
+    S3D_REQUIRE(a.seg == 0 || (a.seg <= a.N && a.N <= 2 * a.seg && a.N <= 32),
+                "attention: seg=%d needs seg <= N <= 2*seg and N <= 32 (N=%d)", a.seg, a.N);
     return 0;
+}
+
+// Two short sequences per 32-row MFMA tile: with N <= 16 (group_embed pass 1: 15 tokens x 12 544 groups x 3 heads per block)
+// a (batch, head) problem fills a quarter of the 32x32 score tile and every wave pays the full tile's MFMAs, fragment loads and
+// latency.  When consecutive batch entries are contiguous in memory (sb == N * st), the pair (2b, 2b+1) IS a 2N-token
+// sequence; the block-diagonal mask (seg = N) keeps the two apart.  Half the waves, the same bytes.  S3D_ATTN_PACK=0 disables.
+AttnArgs pack_pairs(const AttnArgs& a) {
+    static const int on = getenv("S3D_ATTN_PACK") ? atoi(getenv("S3D_ATTN_PACK")) : 1;
+    if (on == 0 || a.seg != 0 || a.N > 16 || (a.Bb & 1) || a.sb != (long)a.N * a.st || a.drop_thr) return a;
+    AttnArgs b = a;
+    b.Bb = a.Bb / 2;
+    b.seg = a.N;
+    b.N = 2 * a.N;
+    b.sb = 2 * a.sb;
+    return b;
 }
 
 }  // namespace
 
-int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s) {
-    if (int e = check(a)) return e;
+int s3d_launch_attention_fwd(const AttnArgs& a0, bool split, hipStream_t s) {
+    if (int e = check(a0)) return e;
+    const AttnArgs a = pack_pairs(a0);
     if (split) S3D_REQUIRE(a.qkv_lo != nullptr, "attention: split mode needs the lo plane");
     switch (a.D / a.H) {
         case 48: return fwd_hd<48>(a, split, s);
@@ -1146,8 +1167,9 @@ int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s) {
     }
 }
 
-int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s) {
-    if (int e = check(a)) return e;
+int s3d_launch_attention_bwd(const AttnArgs& a0, hipStream_t s) {
+    if (int e = check(a0)) return e;
+    const AttnArgs a = pack_pairs(a0);
     S3D_REQUIRE(a.lddo % 8 == 0 && a.lddq % 8 == 0, "attention: leading dims must be multiples of 8");
     switch (a.D / a.H) {
         case 48: return bwd_hd<48, 1>(a, s);

@@ -182,7 +182,9 @@ def _attn_ref(q, k, v):
 
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(4, 6, 26, 64, False), (3, 3, 15, 256, False), (2, 3, 197, 256, False),
                                                 (5, 4, 100, 192, True), (2, 3, 257, 64, False), (64, 6, 26, 64, False),
-                                                (3, 4, 20, 96, True), (5, 4, 32, 48, False), (3, 2, 7, 64, False), (2, 2, 2, 64, False)])
+                                                (3, 4, 20, 96, True), (5, 4, 32, 48, False), (3, 2, 7, 64, False), (2, 2, 2, 64, False),
+                                                # even batch, N <= 16, contiguous: two sequences share one 32-row tile (pack_pairs)
+                                                (392, 3, 15, 256, False), (6, 6, 10, 64, False), (4, 4, 16, 48, False), (8, 3, 15, 192, False)])
 def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     g = torch.Generator().manual_seed(6)
     D = H * hd
@@ -218,6 +220,36 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     for i, name in enumerate('qkv'):
         e = rms_err(gotd[..., i * D:(i + 1) * D], xb.grad[..., i * D:(i + 1) * D])
         assert e < 2e-2, f'd{name} rms err {e:.3e}'
+
+
+@pytest.mark.parametrize('H,N,hd,seg', [(3, 30, 256, 15), (6, 26, 64, 13), (4, 32, 48, 16), (2, 21, 96, 11)])
+def test_attention_block_diagonal_segments(H, N, hd, seg):
+    """S3dAttnArgs::seg: a query attends to the keys of its own segment only (what the launchers use to pack two short
+    sequences into one tile); here requested explicitly, incl. unequal segments (N < 2*seg)."""
+    g = torch.Generator().manual_seed(16)
+    Bb, D = 3, H * hd
+    qkv = torch.randn(Bb * N, 3 * D, generator=g).to(DEV)
+    hi, lo = ops.split_bf16(qkv)
+    out_hi, out_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, N, 1, split=True, seg=seg)
+    mask = (torch.arange(N)[:, None] >= seg) == (torch.arange(N)[None, :] >= seg)
+
+    def ref_fn(x):
+        q, k, v = [x[..., i * D:(i + 1) * D].reshape(Bb, N, H, hd).transpose(1, 2) for i in range(3)]
+        s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+        return s.masked_fill(~mask.to(s.device), float('-inf')).softmax(-1) @ v
+
+    ref = ref_fn(qkv.double().view(Bb, N, -1))
+    got = (out_hi.float() + out_lo.float()).view(Bb, N, H, hd).transpose(1, 2)
+    assert rel_err(got, ref) < 1e-4
+    dout_bf = torch.randn(Bb * N, D, generator=g).to(DEV).to(torch.bfloat16)
+    dqkv = ops.attention_bwd(hi, out_hi, out_lo, lse, dout_bf, Bb, H, N, D, N, 1, seg=seg)
+    xb = hi.double().view(Bb, N, -1).requires_grad_(True)
+    ref_fn(xb).backward(dout_bf.double().view(Bb, N, H, hd).transpose(1, 2))
+    for i, name in enumerate('qkv'):
+        e = rms_err(dqkv.float().view(Bb, N, -1)[..., i * D:(i + 1) * D], xb.grad[..., i * D:(i + 1) * D])
+        assert e < 2e-2, f'd{name} rms err {e:.3e}'
+    with pytest.raises(RuntimeError, match='seg'):
+        ops.attention_fwd(hi, lo, Bb, H, N, D, N, 1, seg=N // 2 - 1)
 
 
 @pytest.mark.parametrize('kind,V,c,P,D', [('VoxelEmbed', 30, 6, 5, 384), ('VoxelEmbed', 32, 6, 5, 384),
