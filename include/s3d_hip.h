@@ -289,6 +289,9 @@ int s3d_assemble_tokens_bwd(const float* dout, float* dsrc, long B, int n, int D
  *                          weights of PointNetFeaturePropagation (:401-408) for k = 3 (out_w non-NULL)
  *   s3d_group_gather       index_points + [xyz - new_xyz | feats] concat (:126-134) -> split-bf16 GEMM operand rows (b,s,j)
  *   s3d_group_scatter      its backward (scatter-add into d(feats))
+ *   s3d_group_project_*    the first 1x1 convolution of the level WITHOUT the grouped operand: by linearity
+ *                          conv0([xyz_rel | feats[idx]]) = Pf[idx] + xyz_rel . Wx^T + b with Pf = feats . Wf^T computed once per
+ *                          POINT (k = 16 times fewer GEMM rows than sample_and_group's [B,S,k,3+C] tensor, :126-134 + :238-239)
  *   s3d_batchnorm_fwd/bwd  train-mode nn.BatchNorm2d/1d + ReLU (:238-241, models/3DViT/model.py:52-64) over row matrices
  *                          [rows][C]; with K > 0 also the max over the K neighbours (:242) fused in
  *   s3d_interp3(_bwd)      3-NN interpolation + skip add of TransitionUp (models/3DViT/model.py:67-72)
@@ -301,6 +304,24 @@ int s3d_group_gather(const float* xyz, const float* new_xyz, const float* feats,
                      int C, uint16_t* a_hi, uint16_t* a_lo, int lda, s3d_stream_t stream);
 int s3d_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats,
                       s3d_stream_t stream);
+typedef struct S3dGroupProjArgs {
+    const float* xyz; const float* new_xyz; const int* idx;   /* [B,N,3], [B,S,3], neighbours [B,S,K] */
+    int B, N, S, K, C;                    /* C = output channels of the convolution (multiple of 4, <= 1024) */
+    const float* W; int ldw;              /* conv weight [C][ldw]; columns 0..2 multiply xyz_rel (the rest is Wf) */
+    const float* bias;                    /* [C] */
+    const float* Pf; long ldp;            /* fwd in: per-point projection feats . Wf^T, [B*N][ldp] */
+    float* x; long ldx;                   /* fwd out: pre-BatchNorm rows (b, s, j) -> [B*S*K][ldx] */
+    const uint16_t* dx; long lddx;        /* bwd in: gradient wrt x as bf16 [B*S*K][lddx] */
+    const int* inv_off; const int* inv_rows;   /* bwd in: transpose of idx (s3d_neighbor_csr): rows that reference each point */
+    float* dPf;                           /* bwd out: [B*N][ldp] = sum of dx over the rows that reference the point (written, no atomics) */
+    float* dW; float* dbias;              /* bwd out, accumulated: dW[c][0..2] (row pitch ldw) and dbias[c] */
+} S3dGroupProjArgs;
+int s3d_group_project_fwd(const S3dGroupProjArgs* args, s3d_stream_t stream);
+int s3d_group_project_bwd(const S3dGroupProjArgs* args, s3d_stream_t stream);
+/* Transpose of the neighbour lists idx [B][S*K] (values in [0, N)): inv_off [B][N+1] (exclusive prefix of the in-degrees) and
+ * inv_rows [B][S*K] = for every point the ascending list of entries e = s*K + j with idx[b][e] == point.  Lets the backward
+ * GATHER the rows that touch a point (deterministic, no atomics) instead of scatter-adding R x C gradients. */
+int s3d_neighbor_csr(const int* idx, int B, int N, int S, int K, int* inv_off, int* inv_rows, s3d_stream_t stream);
 typedef struct S3dBnArgs {
     const float* x; int ldx;              /* pre-normalisation activations [rows][ldx] */
     long rows; int C; int K;              /* K > 0: rows = groups*K and the max over K is fused (y = [groups][C], arg) */

@@ -267,6 +267,7 @@ size_t s3d_sizeof(const char* n) {
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
+    SZ(S3dGroupProjArgs);
 #undef SZ
     return 0;
 }
@@ -403,6 +404,18 @@ int s3d_group_gather(const float* xyz, const float* new_xyz, const float* feats,
 }
 int s3d_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats, s3d_stream_t s) {
     return s3d_launch_group_scatter(dA, ldd, idx, B, N, S, K, C, dfeats, st(s));
+}
+int s3d_group_project_fwd(const S3dGroupProjArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_group_project_fwd: null args");
+    return s3d_launch_group_project_fwd(*a, st(s));
+}
+int s3d_group_project_bwd(const S3dGroupProjArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_group_project_bwd: null args");
+    return s3d_launch_group_project_bwd(*a, st(s));
+}
+int s3d_neighbor_csr(const int* idx, int B, int N, int S, int K, int* inv_off, int* inv_rows, s3d_stream_t s) {
+    S3D_REQUIRE(idx && inv_off && inv_rows, "s3d_neighbor_csr: null pointer");
+    return s3d_launch_neighbor_csr(idx, B, N, S, K, inv_off, inv_rows, st(s));
 }
 int s3d_batchnorm_fwd(const S3dBnArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_batchnorm_fwd: null args");

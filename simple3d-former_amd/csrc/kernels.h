@@ -48,6 +48,9 @@ int s3d_launch_knn(const float* query, const float* ref, int B, int S, int N, in
 int s3d_launch_group_gather(const float* xyz, const float* new_xyz, const float* feats, const int* idx, int B, int N, int S,
                             int K, int C, bf16_t* a_hi, bf16_t* a_lo, int lda, hipStream_t s);
 int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, int N, int S, int K, int C, float* dfeats, hipStream_t s);
+int s3d_launch_group_project_fwd(const S3dGroupProjArgs& a, hipStream_t s);
+int s3d_launch_group_project_bwd(const S3dGroupProjArgs& a, hipStream_t s);
+int s3d_launch_neighbor_csr(const int* idx, int B, int N, int S, int K, int* inv_off, int* inv_rows, hipStream_t s);
 int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s);
 int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s);
 int s3d_launch_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,

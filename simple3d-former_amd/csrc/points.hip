@@ -533,6 +533,142 @@ __global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __
     }
 }
 
+// ------------------------------------------------------------------------------------------- grouped first convolution
+// sample_and_group builds [B, S, k, 3 + C] rows ([xyz_rel | feats[idx]]) and the level's first 1x1 convolution runs over all
+// B*S*k of them.  The convolution is linear and the feature part of a row is a COPY of a point's features, so
+//     conv0(row (b, s, j)) = Pf[b, idx] + xyz_rel . Wx^T + bias,      Pf = feats . Wf^T  (one GEMM row per point, not per (s, j))
+// k = 16 times fewer GEMM rows, no grouped operand in memory; the 3-column xyz part is done here in fp32 exactly as the
+// reference does it (xyz_rel first, then the products).  Thread layout = the BatchNorm vector kernels' (one channel quad per
+// thread for the whole launch, row lanes stride the rows): Pf rows are gathered with 16-byte loads (the per-cloud Pf block is
+// L2-resident), x rows are written with 16-byte stores.
+// Backward: dPf[b, n] = sum of dx over the rows whose neighbour is n -- gathered through the transposed neighbour lists
+// (neighbor_csr_kernel), not scattered with atomics: a first version with R x C fp32 atomics (quad-per-thread layout, 16-byte
+// strided addresses) took 2.6 ms for cfg-4's first level -- more than the GEMMs it replaced.  dWx / dbias are reduced per
+// workgroup, then one atomic per entry; the per-point GEMMs (dWf = dPf^T feats, dfeats += dPf Wf) follow on the MFMA path.
+__global__ __launch_bounds__(256) void group_proj_fwd_kernel(const S3dGroupProjArgs p, unsigned rows) {
+    const BnLane l = bn_lane(p.C);
+    if (!l.on) return;
+    const int c = 4 * l.q;
+    f32x4 wx, wy, wz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* w = p.W + (long)(c + i) * p.ldw;
+        wx[i] = w[0]; wy[i] = w[1]; wz[i] = w[2];
+    }
+    const f32x4 bb = ld4(p.bias + c);
+    const unsigned SK = (unsigned)p.S * (unsigned)p.K;
+    for (unsigned r = blockIdx.x * l.rpb + l.sub; r < rows; r += gridDim.x * l.rpb) {
+        const unsigned b = r / SK, bs = r / (unsigned)p.K;
+        const long pt = (long)b * p.N + p.idx[r];
+        const float* pp = p.xyz + pt * 3;
+        const float* cc = p.new_xyz + (long)bs * 3;
+        const float rx = pp[0] - cc[0], ry = pp[1] - cc[1], rz = pp[2] - cc[2];
+        f32x4 v = ld4(p.Pf + pt * p.ldp + c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = v[i] + ((rx * wx[i] + ry * wy[i]) + rz * wz[i]) + bb[i];
+        *reinterpret_cast<f32x4*>(p.x + (long)r * p.ldx + c) = v;
+    }
+}
+
+// Transpose of the neighbour graph, one workgroup per cloud: LDS histogram of the in-degrees, block scan, cursor fill, then
+// every point sorts its (short) list so that the backward's summation order is deterministic.
+__global__ __launch_bounds__(256) void neighbor_csr_kernel(const int* __restrict__ idx, int N, int E, int* __restrict__ inv_off,
+                                                           int* __restrict__ inv_rows) {
+    extern __shared__ int csr_lds[];                    // cnt [N + 1] | part [256]
+    int* cnt = csr_lds;
+    int* part = csr_lds + N + 1;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int* id = idx + (long)b * E;
+    int* rows = inv_rows + (long)b * E;
+    for (int i = tid; i <= N; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) atomicAdd(&cnt[id[e]], 1);
+    __syncthreads();
+    const int per = (N + 255) / 256, lo = tid * per, hi = min(lo + per, N);
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {                 // inclusive Hillis-Steele scan of the 256 partial sums
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - sum;                          // exclusive prefix of this thread's first bin
+    for (int i = lo; i < hi; ++i) { const int c = cnt[i]; cnt[i] = run; inv_off[(long)b * (N + 1) + i] = run; run += c; }
+    if (tid == 255) inv_off[(long)b * (N + 1) + N] = E;
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) rows[atomicAdd(&cnt[id[e]], 1)] = e;       // cnt is now the fill cursor
+    __syncthreads();                                    // the lists are complete (and visible) within the workgroup
+    for (int n = tid; n < N; n += 256) {                // cnt[n] = end of list n, start = end of list n - 1
+        const int end = cnt[n], start = n ? cnt[n - 1] : 0;
+        for (int i = start + 1; i < end; ++i) {
+            const int v = rows[i];
+            int j = i - 1;
+            while (j >= start && rows[j] > v) { rows[j + 1] = rows[j]; --j; }
+            rows[j + 1] = v;
+        }
+    }
+}
+
+// Backward, point-centric: C/2 threads per point (a bf16 pair each) walk the rows that reference the point (inv lists), sum their
+// dx in fp32 and write dPf once -- no atomics, fixed order.  dWx / dbias: per-thread partials over its points, folded per workgroup.
+__global__ __launch_bounds__(256) void group_proj_bwd_kernel(const S3dGroupProjArgs p) {
+    __shared__ float red[2048];                         // [point lanes][C][4] : (256 / (C/2)) * C * 4 <= 2048 floats
+    const int c2 = p.C >> 1;                            // threads per point (C <= 512 here; wider: loop below)
+    const int tpp = min(c2, 256), ppb = 256 / tpp;      // threads per point per pass, points per workgroup
+    const int lane = threadIdx.x % tpp, sub = threadIdx.x / tpp;
+    const bool on = sub < ppb;
+    const long npts = (long)p.B * p.N;
+    const int E = p.S * p.K;
+    for (int cbase = 0; cbase < c2; cbase += 256) {     // one pass unless C > 512
+        const int cp = cbase + lane;                    // channel pair
+        const bool con = on && cp < c2;
+        float gw[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, gb[2] = {0.f, 0.f};
+        if (con)
+            for (long pt = (long)blockIdx.x * ppb + sub; pt < npts; pt += (long)gridDim.x * ppb) {
+                const int b = (int)(pt / p.N), n = (int)(pt - (long)b * p.N);
+                const int* off = p.inv_off + (long)b * (p.N + 1) + n;
+                const int start = off[0], end = off[1];
+                const int* rows = p.inv_rows + (long)b * E;
+                const float* pp = p.xyz + pt * 3;
+                const float px = pp[0], py = pp[1], pz = pp[2];
+                float a0 = 0.f, a1 = 0.f;
+                for (int i = start; i < end; ++i) {
+                    const int e = rows[i];
+                    const long r = (long)b * E + e;
+                    const float* cc = p.new_xyz + ((long)b * p.S + e / p.K) * 3;
+                    const unsigned u = *reinterpret_cast<const unsigned*>(p.dx + r * p.lddx + 2 * cp);
+                    const float g0 = __uint_as_float(u << 16), g1 = __uint_as_float(u & 0xffff0000u);
+                    const float rx = px - cc[0], ry = py - cc[1], rz = pz - cc[2];
+                    a0 += g0; a1 += g1;
+                    gw[0][0] += g0 * rx; gw[0][1] += g0 * ry; gw[0][2] += g0 * rz;
+                    gw[1][0] += g1 * rx; gw[1][1] += g1 * ry; gw[1][2] += g1 * rz;
+                }
+                gb[0] += a0; gb[1] += a1;
+                *reinterpret_cast<float2*>(p.dPf + pt * p.ldp + 2 * cp) = make_float2(a0, a1);
+            }
+        const int cw = min(c2 - cbase, 256) * 2;        // channels covered by this pass
+        if (con) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float* o = red + ((long)sub * cw + 2 * lane + i) * 4;
+                o[0] = gw[i][0]; o[1] = gw[i][1]; o[2] = gw[i][2]; o[3] = gb[i];
+            }
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < 4 * cw; j += blockDim.x) {
+            float t = 0.f;
+            for (int r = 0; r < ppb; ++r) t += red[(long)r * cw * 4 + j];
+            const int ch = 2 * cbase + (j >> 2), d = j & 3;
+            if (d < 3) atomic_add_f32(p.dW + (long)ch * p.ldw + d, t);
+            else atomic_add_f32(p.dbias + ch, t);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------- misc row ops
 // mean over the N points of each cloud: out[b][c] = mean_n x[b, n, c]   (x.mean(1), models/3DViT/model.py:325)
 // One workgroup per cloud: 256 / C row lanes walk the points with coalesced channel-contiguous reads, LDS fold at the end
@@ -658,6 +794,39 @@ static bool bn_vec_ok(const S3dBnArgs& a) {
 }
 static bool al(const void* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
 
+static int group_proj_check(const S3dGroupProjArgs& a, const char* what) {
+    S3D_REQUIRE(a.B > 0 && a.N > 0 && a.S > 0 && a.K > 0, "%s: empty problem", what);
+    S3D_REQUIRE(a.C > 0 && a.C % 4 == 0 && a.C <= 1024, "%s: C=%d must be a multiple of 4 up to 1024", what, a.C);
+    S3D_REQUIRE((long)a.B * a.S * a.K < (1L << 31), "%s: more than 2^31 grouped rows", what);
+    S3D_REQUIRE(a.xyz && a.new_xyz && a.idx && a.W && a.ldw >= 3 && a.ldp % 4 == 0, "%s: null geometry / weight pointer or bad pitch", what);
+    return 0;
+}
+int s3d_launch_group_project_fwd(const S3dGroupProjArgs& a, hipStream_t s) {
+    if (int e = group_proj_check(a, "group_project_fwd")) return e;
+    S3D_REQUIRE(a.Pf && a.x && a.bias && a.ldx % 4 == 0 && al(a.Pf, 16) && al(a.x, 16) && al(a.bias, 16),
+                "group_project_fwd: Pf / x / bias must be non-null, 16-byte aligned, pitches multiples of 4");
+    const long rows = (long)a.B * a.S * a.K;
+    hipLaunchKernelGGL(group_proj_fwd_kernel, dim3(grid_for(rows, 256 / (a.C / 4), 8192)), dim3(256), 0, s, a, (unsigned)rows);
+    S3D_CHECK_LAUNCH("group_project_fwd");
+    return 0;
+}
+int s3d_launch_group_project_bwd(const S3dGroupProjArgs& a, hipStream_t s) {
+    if (int e = group_proj_check(a, "group_project_bwd")) return e;
+    S3D_REQUIRE(a.dx && a.dPf && a.dW && a.dbias && a.inv_off && a.inv_rows && a.lddx % 2 == 0 && al(a.dx, 4) && al(a.dPf, 8) && a.ldp % 2 == 0,
+                "group_project_bwd: dx / dPf / dW / dbias / inv_off / inv_rows must be non-null (s3d_neighbor_csr builds the lists)");
+    const long npts = (long)a.B * a.N;
+    const int tpp = a.C / 2 < 256 ? a.C / 2 : 256;
+    hipLaunchKernelGGL(group_proj_bwd_kernel, dim3(grid_for(npts, 256 / tpp, 2048)), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("group_project_bwd");
+    return 0;
+}
+int s3d_launch_neighbor_csr(const int* idx, int B, int N, int S, int K, int* inv_off, int* inv_rows, hipStream_t s) {
+    S3D_REQUIRE(B > 0 && N > 0 && S > 0 && K > 0 && N <= 8192, "neighbor_csr: B=%d N=%d S=%d K=%d (N <= 8192)", B, N, S, K);
+    const size_t lds = (size_t)(N + 1 + 256) * sizeof(int);
+    hipLaunchKernelGGL(neighbor_csr_kernel, dim3(B), dim3(256), lds, s, idx, N, S * K, inv_off, inv_rows);
+    S3D_CHECK_LAUNCH("neighbor_csr");
+    return 0;
+}
 // Channel limits: the scalar statistics kernels map 256 / C rows onto a workgroup (C <= 256); the vector kernels give every
 // lane one channel quad (C <= 1024, 4 | C, aligned rows) -- deit_small / deit_base widths of the 1-level model need those.
 int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {

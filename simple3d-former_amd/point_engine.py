@@ -3,7 +3,9 @@ on one MI355X through the C ABI of libs3d_hip.so.
 
 Pipeline (deit_tiny: D = 192, C0 = D/4 = 48):
   fc1(x) + fc_pos_embed(xyz)                       [B,N,C0]     two 2-layer MLPs              -> MFMA GEMMs
-  TransitionDown 0: FPS(N) -> kNN16 -> gather -> conv1x1+BN+ReLU x2 -> max_k      [B,N,2C0]   s3d_fps/knn/group_gather + GEMMs + batchnorm
+  TransitionDown 0: FPS(N) -> kNN16 -> gather -> conv1x1+BN+ReLU x2 -> max_k      [B,N,2C0]   s3d_fps/knn/group_project + GEMMs + batchnorm
+                    (the first convolution is linear in a COPY of per-point features: Pf = feats . Wf^T once per point, then
+                     Pf[idx] + xyz_rel . Wx^T + b per grouped row -- s3d_group_project_*, 16x fewer GEMM rows, no grouped operand)
   TransitionDown 1: FPS(N/4) -> ...                                               [B,N/4,D]
   cat cls -> 12 timm blocks -> LayerNorm -> drop cls                              s3d_blocks_fwd (shared with the voxel path)
   TransitionUp 0/1: Linear+BN+ReLU on both inputs, 3-NN inverse-distance interpolation, add
@@ -107,12 +109,11 @@ def bn_buffer_names(backbone, variant='3DViT'):
 class _Linear:
     """y = x @ W^T + b with W [out][in] taken from the arena (padded bf16 planes when `in` or `out` need padding)."""
 
-    def __init__(self, eng, key, out_pad=None, k_pad=None):
+    def __init__(self, eng, key, out_pad=None):
         a = eng.arena
         shp = a.shapes[key + '.weight']
         self.key, self.out, self.inn = key, shp[0], int(np.prod(shp[1:]))
-        self.kcols = _round_up(self.inn, 8)                     # columns that can be non-zero
-        self.kpad = k_pad or self.kcols                         # row pitch of the input planes / weight rows
+        self.kpad = _round_up(self.inn, 8)
         self.opad = out_pad or self.out
         self.padded = (self.kpad != self.inn) or (self.opad != self.out)
         dev = eng.device
@@ -158,9 +159,39 @@ class _Linear:
             if self.opad != self.out:
                 a.grad(self.key + '.bias').add_(self.gbias[:self.out])
         if dx is not None or kw:
-            g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kcols, K=self.opad,
+            g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kpad, K=self.opad,
                        alpha=1.0, **({'C': dx, 'ldc': self.kpad} if dx is not None else {}), **kw)
             L.check(lib.s3d_gemm(0, 1, 0, dx_epi, ctypes.byref(g), 1, s), self.key + ' dgrad')
+
+
+class _GroupProj:
+    """First 1x1 convolution of a TransitionDown (mlp_convs.0, weight [ch][3 + C]) in its factored form: the feature columns
+    Wf = W[:, 3:] become a per-point projection (MFMA GEMM over B*N rows), the xyz columns are applied per grouped row by
+    s3d_group_project_fwd.  Holds the split-bf16 planes of Wf."""
+
+    def __init__(self, eng, key, C, ch):
+        self.eng, self.key, self.C, self.ch, self.cin = eng, key, C, ch, C + 3
+        dev = eng.device
+        self.wtmp = torch.empty(ch, C, dtype=torch.float32, device=dev)
+        self.w = torch.zeros(2, ch, C, dtype=torch.bfloat16, device=dev)          # Wf   [ch][C]: forward B operand
+        self.wt_tmp = torch.empty(C, ch, dtype=torch.float32, device=dev)
+        self.wt = torch.zeros(2, C, ch, dtype=torch.bfloat16, device=dev)         # Wf^T [C][ch]: B operand of the split-precision dgrad
+
+    def weight(self):
+        return self.eng.arena.param(self.key + '.weight').view(self.ch, self.cin)
+
+    def refresh(self):
+        self.wtmp.copy_(self.weight()[:, 3:])
+        L.check(self.eng.lib.s3d_split_bf16(L.ptr(self.wtmp), L.ptr(self.w[0]), L.ptr(self.w[1]), ctypes.c_long(self.ch),
+                                            ctypes.c_long(self.C), ctypes.c_long(self.C), L.current_stream()), 'split Wf')
+        self.wt_tmp.copy_(self.wtmp.t())
+        L.check(self.eng.lib.s3d_split_bf16(L.ptr(self.wt_tmp), L.ptr(self.wt[0]), L.ptr(self.wt[1]), ctypes.c_long(self.C),
+                                            ctypes.c_long(self.ch), ctypes.c_long(self.ch), L.current_stream()), 'split Wf^T')
+
+    def args(self, t, xyz_in, B, **kw):
+        a = self.eng.arena
+        return L.fill(L.S3dGroupProjArgs(), xyz=xyz_in, new_xyz=t.new_xyz, idx=t.idx, B=B, N=t.Nin, S=t.S, K=KNN, C=self.ch,
+                      W=a.param(self.key + '.weight'), ldw=self.cin, bias=a.param(self.key + '.bias'), ldp=self.ch, **kw)
 
 
 class _BatchNorm:
@@ -230,7 +261,7 @@ class PointEngine:
         self.td = []
         for i in range(self.levels):
             p = f'transition_downs.{i}.sa.'
-            self.td.append(dict(c0=_Linear(self, p + 'mlp_convs.0', k_pad=self._cinp(i)), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
+            self.td.append(dict(gp=_GroupProj(self, p + 'mlp_convs.0', self.cin[i] - 3, self.ch[i]), b0=_BatchNorm(self, p + 'mlp_bns.0', self.ch[i]),
                                 c1=_Linear(self, p + 'mlp_convs.1'), b1=_BatchNorm(self, p + 'mlp_bns.1', self.ch[i])))
         self.tu = []
         for j, i in enumerate(reversed(range(self.levels))):
@@ -240,7 +271,7 @@ class PointEngine:
                                 l2=_Linear(self, p + 'fc2.0'), b2=_BatchNorm(self, p + 'fc2.2', ch), ch=ch))
         self.head_key = self.vv['head']
         self.head = _Linear(self, self.head_key, out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
-        self._linears = self.fc1 + self.fcp + [t[k] for t in self.td for k in ('c0', 'c1')] + \
+        self._linears = self.fc1 + self.fcp + [t['gp'] for t in self.td] + [t['c1'] for t in self.td] + \
             [t[k] for t in self.tu for k in ('l1', 'l2')] + ([self.head] if self.head else [])
         self.bns = {t[k].key: t[k] for t in self.td for k in ('b0', 'b1')}
         self.bns.update({t[k].key: t[k] for t in self.tu for k in ('b1', 'b2')})
@@ -292,12 +323,6 @@ class PointEngine:
     def zero_grad(self):
         self.arena.g.zero_()
 
-    def _cinp(self, i):
-        """Row pitch of the gathered [xyz_rel | feats] matrix of td i: k must be a multiple of 32 for the LDS-DMA forward GEMM
-        (51 -> 64, 99 -> 128 columns; the padding columns are zero and cost 14-23 % more bytes on that one operand, the
-        register-staged fallback kernel costs more)."""
-        return _round_up(self.cin[i], 32)
-
     # ------------------------------------------------------------------ workspace
     def workspace(self, B):
         ws = self._ws.get(B)
@@ -318,19 +343,21 @@ class PointEngine:
         xyz_n = N
         cprev = C0
         for i in range(self.levels):
-            S, ch, cinp = self.S[i], self.ch[i], self._cinp(i)
+            S, ch = self.S[i], self.ch[i]
             R = B * S * KNN
             t = type('TD', (), {})()
-            t.S, t.R, t.cinp, t.Nin, t.Cin = S, R, cinp, xyz_n, cprev
+            t.S, t.R, t.Nin, t.Cin = S, R, xyz_n, cprev
             t.fps_idx = torch.empty(B, S, **i32); t.new_xyz = torch.empty(B, S, 3, **f32)
             t.idx = torch.empty(B, S, KNN, **i32)
-            t.A = torch.empty(2, R, cinp, **b16)
+            t.inv_off = torch.empty(B, xyz_n + 1, **i32); t.inv_rows = torch.empty(B, S * KNN, **i32)   # transposed neighbour lists
+            t.fp = torch.empty(2, B * xyz_n, cprev, **b16)       # planes of the level's input features
+            t.Pf = torch.empty(B * xyz_n, ch, **f32)              # feats . Wf^T per point
+            t.dPf = torch.empty(B * xyz_n, ch, **f32); t.dPfp = torch.empty(2, B * xyz_n, ch, **b16)
             t.x1 = torch.empty(R, ch, **f32); t.y1 = torch.empty(2, R, ch, **b16)
             t.x2 = torch.empty(R, ch, **f32); t.out = torch.empty(B * S, ch, **f32)
             t.arg = torch.empty(B * S, ch, dtype=torch.uint8, device=dev)
             t.dx = torch.empty(R, ch, **b16)                  # bf16 gradient scratch (dx2 then dx1)
             t.dy1 = torch.empty(R, ch, **f32)
-            t.dA = torch.empty(R, cinp, **f32)
             t.dout = torch.empty(B * S, ch, **f32)            # gradient wrt this level's output features
             ws.td.append(t)
             xyz_n, cprev = S, ch
@@ -411,10 +438,14 @@ class PointEngine:
             t, lay = ws.td[i], self.td[i]
             L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
             L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
-            L.check(lib.s3d_group_gather(L.ptr(xyz_in), L.ptr(t.new_xyz), L.ptr(feats), L.ptr(t.idx), B, t.Nin, t.S, KNN, cin_feats,
-                                         L.ptr(t.A[0]), L.ptr(t.A[1]), t.cinp, s), 'group_gather')
-            ch = self.ch[i]
-            lay['c0'].fwd(t.A[0], t.A[1], t.R, 4, C=t.x1, ldc=ch)
+            ch, gp = self.ch[i], lay['gp']
+            t.xyz_in = xyz_in
+            L.check(lib.s3d_neighbor_csr(L.ptr(t.idx), B, t.Nin, t.S, KNN, L.ptr(t.inv_off), L.ptr(t.inv_rows), s), 'neighbor_csr')
+            self._pack(feats, cin_feats, cin_feats, B * t.Nin, t.fp)
+            g = L.fill(L.S3dGemmArgs(), A_hi=t.fp[0], A_lo=t.fp[1], lda=cin_feats, B_hi=gp.w[0], B_lo=gp.w[1], ldb=cin_feats,
+                       M=B * t.Nin, N=ch, K=cin_feats, C=t.Pf, ldc=ch, alpha=1.0)
+            L.check(lib.s3d_gemm(0, 0, 1 if self.split else 0, 4, ctypes.byref(g), 1, s), 'per-point projection')
+            L.check(lib.s3d_group_project_fwd(ctypes.byref(gp.args(t, xyz_in, B, Pf=t.Pf, x=t.x1, ldx=ch)), s), 'group_project_fwd')
             lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch)
             lay['c1'].fwd(t.y1[0], t.y1[1], t.R, 4, C=t.x2, ldc=ch)
             lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
@@ -553,9 +584,22 @@ class PointEngine:
             lay['b1'].bwd(t.x2, t.R, t.dout, t.dx, K=KNN, arg=t.arg)
             lay['c1'].bwd(t.dx, t.y1[0], t.R, dx=t.dy1, dx_epi=4)
             lay['b0'].bwd(t.x1, t.R, t.dy1, t.dx)
-            lay['c0'].bwd(t.dx, t.A[0], t.R, dx=t.dA, dx_epi=4)
-            dprev = ws.td[i - 1].dout if i >= 1 else ws.df
-            L.check(lib.s3d_group_scatter(L.ptr(t.dA), t.cinp, L.ptr(t.idx), B, t.Nin, t.S, KNN, t.Cin, L.ptr(dprev), s), 'group_scatter')
+            gp, a = lay['gp'], self.arena
+            L.check(lib.s3d_group_project_bwd(ctypes.byref(gp.args(t, t.xyz_in, B, dx=t.dx, lddx=ch, dPf=t.dPf, inv_off=t.inv_off,
+                                                                   inv_rows=t.inv_rows,
+                                                                   dW=a.grad(gp.key + '.weight'), dbias=a.grad(gp.key + '.bias'))), s),
+                    'group_project_bwd')
+            rows = B * t.Nin
+            self._pack(t.dPf, ch, ch, rows, t.dPfp)
+            gwf = a.grad(gp.key + '.weight').view(ch, gp.cin)[:, 3:]          # d(Wf) lives inside the conv weight's gradient
+            g = L.fill(L.S3dGemmArgs(), A_hi=t.dPfp[0], lda=ch, B_hi=t.fp[0], ldb=t.Cin, M=ch, N=t.Cin, K=rows, C=gwf, ldc=gp.cin, alpha=1.0)
+            L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), 'Wf wgrad')
+            dprev = ws.td[i - 1].dout if i >= 1 else ws.df                     # already holds the TransitionUp's contribution
+            # dfeats += dPf . Wf in split precision (dPf is a SUM of ~16 bf16 rows; rounding it to one bf16 plane put the sampled
+            # gradients of the input MLPs at the edge of the parity bar), as an NT product against Wf^T
+            g = L.fill(L.S3dGemmArgs(), A_hi=t.dPfp[0], A_lo=t.dPfp[1], lda=ch, B_hi=gp.wt[0], B_lo=gp.wt[1], ldb=ch, M=rows, N=t.Cin,
+                       K=ch, C=dprev, ldc=t.Cin, R=dprev, ldr=t.Cin, alpha=1.0)
+            L.check(lib.s3d_gemm(0, 0, 1, 2, ctypes.byref(g), 1, s), 'per-point dgrad')
         # the two input MLPs: f = fc1(x) + fc_pos_embed(xyz)
         self._pack_bf(ws.df, C0, BN, ws.dfb)
         self.fc1[1].bwd(ws.dfb, ws.h1[0], BN, dx_epi=8, O_hi=ws.dh, ldo=C0, aux=ws.h1pre, ldaux=C0)

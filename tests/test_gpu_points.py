@@ -406,3 +406,49 @@ def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
                 assert float((a - b).abs().max()) <= 1e-4
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B,N,S,C,ch', [(2, 40, 10, 8, 16), (3, 64, 64, 48, 96), (2, 256, 64, 96, 192), (1, 128, 32, 192, 384)])
+def test_group_project_fwd_bwd(B, N, S, C, ch):
+    """s3d_group_project_*: conv0([xyz_rel | feats[idx]]) = Pf[idx] + xyz_rel . Wx^T + b vs the reference formulation (grouped
+    rows through a [ch][3 + C] weight, sample_and_group + the first Conv2d of PointNetSetAbstraction) in fp64."""
+    g = torch.Generator().manual_seed(B * N + C)
+    K = 16
+    xyz = torch.rand(B, N, 3, generator=g); feats = torch.randn(B, N, C, generator=g)
+    new_xyz = xyz[:, torch.randperm(N, generator=g)[:S]].contiguous()
+    idx = po.knn_indices(new_xyz, xyz, K)
+    W = torch.randn(ch, 3 + C, generator=g) / (3 + C) ** 0.5; bias = torch.randn(ch, generator=g)
+    Wd, fd = W.double().requires_grad_(True), feats.double().requires_grad_(True)
+    bd = bias.double().requires_grad_(True)
+    grouped = torch.cat([po.index_points(xyz.double(), idx) - new_xyz.double()[:, :, None], po.index_points(fd, idx)], dim=-1)
+    ref = grouped.reshape(B * S * K, -1) @ Wd.t() + bd
+    Pf = (feats.double().reshape(B * N, C) @ W.double()[:, 3:].t()).float()
+    dev = lambda t: t.to(DEV)
+    xyz_d, nx_d, idx_d, W_d, b_d, Pf_d = dev(xyz), dev(new_xyz), dev(idx.to(torch.int32)), dev(W), dev(bias), dev(Pf)
+    x = torch.empty(B * S * K, ch, device=DEV)
+    a = L.fill(L.S3dGroupProjArgs(), xyz=xyz_d, new_xyz=nx_d, idx=idx_d, B=B, N=N, S=S, K=K, C=ch, W=W_d, ldw=3 + C, bias=b_d,
+               Pf=Pf_d, ldp=ch, x=x, ldx=ch)
+    L.check(L.lib().s3d_group_project_fwd(ctypes.byref(a), L.current_stream()), 'gp fwd')
+    assert rel_err(x, ref.detach()) < 2e-6
+    dx = torch.randn(B * S * K, ch, generator=g).to(torch.bfloat16)
+    ref.backward(dx.double())
+    dx_d = dev(dx)
+    # transposed neighbour lists: for every point the ascending entries e = s*K + j that reference it
+    inv_off = torch.empty(B, N + 1, dtype=torch.int32, device=DEV); inv_rows = torch.empty(B, S * K, dtype=torch.int32, device=DEV)
+    L.check(L.lib().s3d_neighbor_csr(L.ptr(idx_d), B, N, S, K, L.ptr(inv_off), L.ptr(inv_rows), L.current_stream()), 'csr')
+    flat = idx.reshape(B, S * K)
+    for b in range(B):
+        order = torch.sort(flat[b], stable=True).indices                 # ascending point, ties in entry order
+        assert torch.equal(inv_rows[b].cpu().long(), order)
+        assert torch.equal(inv_off[b].cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), torch.bincount(flat[b], minlength=N).cumsum(0)]))
+    dPf = torch.full((B * N, ch), float('nan'), device=DEV)              # written, not accumulated
+    dW = torch.zeros(ch, 3 + C, device=DEV); db = torch.zeros(ch, device=DEV)
+    L.fill(a, dx=dx_d, lddx=ch, dPf=dPf, dW=dW, dbias=db, inv_off=inv_off, inv_rows=inv_rows)
+    L.check(L.lib().s3d_group_project_bwd(ctypes.byref(a), L.current_stream()), 'gp bwd')
+    assert rel_err(dW[:, :3], Wd.grad[:, :3]) < 1e-4 and float(dW[:, 3:].abs().max()) == 0.0
+    assert rel_err(db, bd.grad) < 1e-4
+    # dPf: d(loss)/d(Pf) -> the per-point GEMMs' inputs; check through the chain rule: dfeats = dPf Wf, dWf = dPf^T feats
+    assert rel_err(dPf.double().cpu() @ W.double()[:, 3:], fd.grad.reshape(B * N, C)) < 1e-4
+    assert rel_err(dPf.double().cpu().t() @ feats.double().reshape(B * N, C), Wd.grad[:, 3:]) < 1e-4
+    with pytest.raises(RuntimeError, match='multiple of 4'):
+        L.check(L.lib().s3d_group_project_fwd(ctypes.byref(L.fill(a, C=ch - 1)), L.current_stream()), 'gp fwd')
