@@ -311,6 +311,8 @@ typedef struct S3dGroupProjArgs {
     const float* bias;                    /* [C] */
     const float* Pf; long ldp;            /* fwd in: per-point projection feats . Wf^T, [B*N][ldp] */
     float* x; long ldx;                   /* fwd out: pre-BatchNorm rows (b, s, j) -> [B*S*K][ldx] */
+    double* sums;                         /* fwd, optional: [2*C] column sums and sums of squares of x, ACCUMULATED (zero it first):
+                                           * the statistics pass of the BatchNorm that follows (S3dBnArgs::have_sums) */
     const uint16_t* dx; long lddx;        /* bwd in: gradient wrt x as bf16 [B*S*K][lddx] */
     const int* inv_off; const int* inv_rows;   /* bwd in: transpose of idx (s3d_neighbor_csr): rows that reference each point */
     float* dPf;                           /* bwd out: [B*N][ldp] = sum of dx over the rows that reference the point (written, no atomics) */
@@ -336,6 +338,8 @@ typedef struct S3dBnArgs {
     uint16_t* dx; int lddx;               /* bwd: gradient wrt x as bf16 [rows][lddx] */
     float* dgamma; float* dbeta;
     int eval_mode;                        /* fwd: normalise with the running statistics (model.eval()), no update */
+    int have_sums;                        /* fwd: `sums` already holds the column sums / sums of squares of x (the producer of x
+                                           * accumulated them, e.g. s3d_group_project_fwd): skip the statistics pass */
 } S3dBnArgs;
 int s3d_batchnorm_fwd(const S3dBnArgs* args, s3d_stream_t stream);
 int s3d_batchnorm_bwd(const S3dBnArgs* args, s3d_stream_t stream);

@@ -547,8 +547,8 @@ __global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __
 // workgroup, then one atomic per entry; the per-point GEMMs (dWf = dPf^T feats, dfeats += dPf Wf) follow on the MFMA path.
 __global__ __launch_bounds__(256) void group_proj_fwd_kernel(const S3dGroupProjArgs p, unsigned rows) {
     const BnLane l = bn_lane(p.C);
-    if (!l.on) return;
     const int c = 4 * l.q;
+    double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};          // BatchNorm statistics of the rows this thread writes
     f32x4 wx, wy, wz;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -557,17 +557,23 @@ __global__ __launch_bounds__(256) void group_proj_fwd_kernel(const S3dGroupProjA
     }
     const f32x4 bb = ld4(p.bias + c);
     const unsigned SK = (unsigned)p.S * (unsigned)p.K;
-    for (unsigned r = blockIdx.x * l.rpb + l.sub; r < rows; r += gridDim.x * l.rpb) {
-        const unsigned b = r / SK, bs = r / (unsigned)p.K;
-        const long pt = (long)b * p.N + p.idx[r];
-        const float* pp = p.xyz + pt * 3;
-        const float* cc = p.new_xyz + (long)bs * 3;
-        const float rx = pp[0] - cc[0], ry = pp[1] - cc[1], rz = pp[2] - cc[2];
-        f32x4 v = ld4(p.Pf + pt * p.ldp + c);
+    if (l.on)
+        for (unsigned r = blockIdx.x * l.rpb + l.sub; r < rows; r += gridDim.x * l.rpb) {
+            const unsigned b = r / SK, bs = r / (unsigned)p.K;
+            const long pt = (long)b * p.N + p.idx[r];
+            const float* pp = p.xyz + pt * 3;
+            const float* cc = p.new_xyz + (long)bs * 3;
+            const float rx = pp[0] - cc[0], ry = pp[1] - cc[1], rz = pp[2] - cc[2];
+            f32x4 v = ld4(p.Pf + pt * p.ldp + c);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = v[i] + ((rx * wx[i] + ry * wy[i]) + rz * wz[i]) + bb[i];
-        *reinterpret_cast<f32x4*>(p.x + (long)r * p.ldx + c) = v;
-    }
+            for (int i = 0; i < 4; ++i) {
+                v[i] = v[i] + ((rx * wx[i] + ry * wy[i]) + rz * wz[i]) + bb[i];
+                const double d = v[i];
+                sm[i] += d; sq[i] += d * d;
+            }
+            *reinterpret_cast<f32x4*>(p.x + (long)r * p.ldx + c) = v;
+        }
+    if (p.sums) bn_fold_sums(l, p.C, sm, sq, p.sums);              // uniform branch; every thread reaches the barrier inside
 }
 
 // Transpose of the neighbour graph, one workgroup per cloud: LDS histogram of the in-degrees, block scan, cursor fill, then
@@ -836,6 +842,9 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
     if (a.eval_mode) {
         S3D_REQUIRE(a.run_mean && a.run_var, "batchnorm(eval): running statistics required");
         hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cblocks), dim3(256), 0, s, a.run_mean, a.run_var, a.C, a.eps, a.mean, a.rstd);
+    } else if (a.have_sums) {
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
+                           a.run_mean, a.run_var);
     } else {
         (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
         const int per = a.C <= 256 ? 256 / a.C : 1;

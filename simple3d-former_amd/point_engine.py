@@ -445,8 +445,12 @@ class PointEngine:
             g = L.fill(L.S3dGemmArgs(), A_hi=t.fp[0], A_lo=t.fp[1], lda=cin_feats, B_hi=gp.w[0], B_lo=gp.w[1], ldb=cin_feats,
                        M=B * t.Nin, N=ch, K=cin_feats, C=t.Pf, ldc=ch, alpha=1.0)
             L.check(lib.s3d_gemm(0, 0, 1 if self.split else 0, 4, ctypes.byref(g), 1, s), 'per-point projection')
-            L.check(lib.s3d_group_project_fwd(ctypes.byref(gp.args(t, xyz_in, B, Pf=t.Pf, x=t.x1, ldx=ch)), s), 'group_project_fwd')
-            lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch)
+            fused = self.training                    # the gather kernel also accumulates the BatchNorm statistics of x1
+            if fused:
+                lay['b0'].sums.zero_()
+            L.check(lib.s3d_group_project_fwd(ctypes.byref(gp.args(t, xyz_in, B, Pf=t.Pf, x=t.x1, ldx=ch,
+                                                                   sums=lay['b0'].sums if fused else None)), s), 'group_project_fwd')
+            lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch, have_sums=1 if fused else 0)
             lay['c1'].fwd(t.y1[0], t.y1[1], t.R, 4, C=t.x2, ldc=ch)
             lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
             xyz_in, feats, cin_feats = t.new_xyz, t.out, ch

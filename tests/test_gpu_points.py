@@ -428,8 +428,11 @@ def test_group_project_fwd_bwd(B, N, S, C, ch):
     x = torch.empty(B * S * K, ch, device=DEV)
     a = L.fill(L.S3dGroupProjArgs(), xyz=xyz_d, new_xyz=nx_d, idx=idx_d, B=B, N=N, S=S, K=K, C=ch, W=W_d, ldw=3 + C, bias=b_d,
                Pf=Pf_d, ldp=ch, x=x, ldx=ch)
+    sums = torch.zeros(2 * ch, dtype=torch.float64, device=DEV)         # optional: BatchNorm statistics of x, accumulated on the fly
+    L.fill(a, sums=sums)
     L.check(L.lib().s3d_group_project_fwd(ctypes.byref(a), L.current_stream()), 'gp fwd')
     assert rel_err(x, ref.detach()) < 2e-6
+    assert rel_err(sums[:ch], x.double().sum(0)) < 1e-9 and rel_err(sums[ch:], (x.double() ** 2).sum(0)) < 1e-9
     dx = torch.randn(B * S * K, ch, generator=g).to(torch.bfloat16)
     ref.backward(dx.double())
     dx_d = dev(dx)
