@@ -37,16 +37,26 @@ union U128 {
     uint32_t w[4];
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions, result in every lane.  Within a row of 16 lanes: four DPP steps (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror -- each is an exchange between halves that already agree, i.e. a butterfly); the four row results are then read
+// with v_readlane and combined as scalars.  ~11 cheap instructions instead of six ds_bpermute round trips through the LDS
+// crossbar (the __shfl_xor butterfly), which matters for the few-microsecond LayerNorm / softmax / loss kernels whose
+// critical path is two or three of these.
+template <typename F>
+__device__ __forceinline__ float wave_reduce(float v, F op) {
+    int x = __float_as_int(v);
+#define S3D_DPP_STEP(ctrl) x = __float_as_int(op(__int_as_float(x), __int_as_float(__builtin_amdgcn_update_dpp(x, x, ctrl, 0xf, 0xf, false))));
+    S3D_DPP_STEP(0xB1)   // quad_perm:[1,0,3,2]
+    S3D_DPP_STEP(0x4E)   // quad_perm:[2,3,0,1]
+    S3D_DPP_STEP(0x141)  // row_half_mirror
+    S3D_DPP_STEP(0x140)  // row_mirror
+#undef S3D_DPP_STEP
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(x, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(x, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
+    return op(op(r0, r1), op(r2, r3));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
+__device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, one exp + 5 FMAs): ~3x fewer VALU instructions than erff in
 // the GELU epilogues, with an error far below the bf16/1e-3 budgets of this path.
