@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
             mloc = fmaxf(mloc, sv[r]);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = half_max(mloc);
         const float mnew = fmaxf(m_i, mloc);                      // finite: every key tile holds >= 1 valid key
         const float alpha = fast_exp(m_i - mnew);                     // exp(-inf) = 0 on the first tile
         float lsum = 0.f;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             sv[r] = fast_exp(sv[r] - mnew);                           // invalid keys: exp(-inf) = 0
             lsum += sv[r];
         }
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = half_sum(lsum);
         l_i = l_i * alpha + lsum;
         m_i = mnew;
         if (p.drop_thr) {                                         // dropout on the attention weights (normaliser undropped)
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
         }
-        delta += __shfl_xor(delta, 32, 64);
+        delta = half_sum(delta);
     }
     const float lse_q = p.lse[(long)bh * p.N + qrow_c];
     if (active && qok && h2 == 0) p.delta[(long)bh * p.N + qrow] = delta;
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
             sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
             mloc = fmaxf(mloc, sv[r]);
         }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        mloc = half_max(mloc);
         const float mnew = fmaxf(m_i, mloc);
         const float alpha = fast_exp(m_i - mnew);
         float lsum = 0.f;
@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
             sv[r] = fast_exp(sv[r] - mnew);
             lsum += sv[r];
         }
-        lsum += __shfl_xor(lsum, 32, 64);
+        lsum = half_sum(lsum);
         l_i = l_i * alpha + lsum;
         m_i = mnew;
         if (p.drop_thr) {
@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p)
 #pragma unroll
             for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
         }
-        delta += __shfl_xor(delta, 32, 64);
+        delta = half_sum(delta);
     }
     const float lse_q = p.lse[(long)bh * p.N + qrow_c];
     if (active && qok && h2 == 0) p.delta[(long)bh * p.N + qrow] = delta;
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
         }
-        delta += __shfl_xor(delta, 32, 64);
+        delta = half_sum(delta);
     }
     const float lse_q = p.lse[(long)bh * p.N + tok];
     if (h2 == 0) { ldsR[l31] = delta; ldsR[32 + l31] = lse_q; }

@@ -55,6 +55,17 @@ __device__ __forceinline__ float wave_reduce(float v, F op) {
     const float r2 = __int_as_float(__builtin_amdgcn_readlane(x, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(x, 48));
     return op(op(r0, r1), op(r2, r3));
 }
+// Reduction across the two 32-lane halves (the 32x32 MFMA layouts keep a row's values in lanes l and l + 32): gfx950's
+// v_permlane32_swap hands every lane the lower-half and the upper-half value (tools/probes/permlane_probe.hip) -- one VALU
+// instruction instead of the ds_bpermute behind __shfl_xor(v, 32).
+__device__ __forceinline__ float half_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return __int_as_float(r[0]) + __int_as_float(r[1]);
+}
+__device__ __forceinline__ float half_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return fmaxf(__int_as_float(r[0]), __int_as_float(r[1]));
+}
 __device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](float a, float b) { return a + b; }); }
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
