@@ -628,6 +628,7 @@ __global__ __launch_bounds__(256) void group_proj_bwd_kernel(const S3dGroupProjA
     const bool on = sub < ppb;
     const long npts = (long)p.B * p.N;
     const int E = p.S * p.K;
+    const int kshift = (p.K & (p.K - 1)) == 0 ? __builtin_ctz(p.K) : -1;       // entry -> centroid: e / K
     for (int cbase = 0; cbase < c2; cbase += 256) {     // one pass unless C > 512
         const int cp = cbase + lane;                    // channel pair
         const bool con = on && cp < c2;
@@ -641,17 +642,22 @@ __global__ __launch_bounds__(256) void group_proj_bwd_kernel(const S3dGroupProjA
                 const float* pp = p.xyz + pt * 3;
                 const float px = pp[0], py = pp[1], pz = pp[2];
                 float a0 = 0.f, a1 = 0.f;
-                for (int i = start; i < end; ++i) {
-                    const int e = rows[i];
-                    const long r = (long)b * E + e;
-                    const float* cc = p.new_xyz + ((long)b * p.S + e / p.K) * 3;
-                    const unsigned u = *reinterpret_cast<const unsigned*>(p.dx + r * p.lddx + 2 * cp);
+                auto take = [&](int e, unsigned u) {
+                    const float* cc = p.new_xyz + ((long)b * p.S + (kshift >= 0 ? e >> kshift : e / p.K)) * 3;
                     const float g0 = __uint_as_float(u << 16), g1 = __uint_as_float(u & 0xffff0000u);
                     const float rx = px - cc[0], ry = py - cc[1], rz = pz - cc[2];
                     a0 += g0; a1 += g1;
                     gw[0][0] += g0 * rx; gw[0][1] += g0 * ry; gw[0][2] += g0 * rz;
                     gw[1][0] += g1 * rx; gw[1][1] += g1 * ry; gw[1][2] += g1 * rz;
+                };
+                auto dxw = [&](int e) { return *reinterpret_cast<const unsigned*>(p.dx + ((long)b * E + e) * p.lddx + 2 * cp); };
+                int i = start;
+                for (; i + 4 <= end; i += 4) {                 // four independent index -> row loads in flight
+                    const int e0 = rows[i], e1 = rows[i + 1], e2 = rows[i + 2], e3 = rows[i + 3];
+                    const unsigned u0 = dxw(e0), u1 = dxw(e1), u2 = dxw(e2), u3 = dxw(e3);
+                    take(e0, u0); take(e1, u1); take(e2, u2); take(e3, u3);
                 }
+                for (; i < end; ++i) { const int e = rows[i]; take(e, dxw(e)); }
                 gb[0] += a0; gb[1] += a1;
                 *reinterpret_cast<float2*>(p.dPf + pt * p.ldp + 2 * cp) = make_float2(a0, a1);
             }
