@@ -33,8 +33,13 @@ __device__ __forceinline__ bf16x8 ld_frag(const bf16_t* p) {
 }
 
 // cooperative (one wave) copy of a [32 rows][HD] bf16 tile into this wave's LDS region (row pitch HD*2 bytes)
-// block-diagonal mask of two packed sequences (S3dAttnArgs::seg): query and key must lie in the same segment
-__device__ __forceinline__ bool seg_ok(const AttnArgs& p, int q, int k) { return p.seg == 0 || ((q >= p.seg) == (k >= p.seg)); }
+// block-diagonal mask of two packed sequences (S3dAttnArgs::seg): query and key must lie in the same segment.  A template
+// flag, not a run-time test: the mask costs the few-microsecond cfg-2 kernels 0.7 % of the step when it is compiled in.
+template <bool SEG>
+__device__ __forceinline__ bool seg_ok(const AttnArgs& p, int q, int k) {
+    if constexpr (!SEG) return true;
+    return (q >= p.seg) == (k >= p.seg);
+}
 
 template <int HD>
 __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld, long row0_off, long st_ld, int t0,
@@ -75,7 +80,7 @@ __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2,
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------- forward
-template <int HD, bool SPLIT>
+template <int HD, bool SPLIT, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         float sv[16], mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok(p, qrow_c, k0 + acc_row(r, h2));
+            const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok<SEG>(p, qrow_c, k0 + acc_row(r, h2));
             sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
             mloc = fmaxf(mloc, sv[r]);
         }
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------- backward: dQ (+ delta)
-template <int HD>
+template <int HD, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j;
-                const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok(p, qrow_c, k0 + acc_row(r, h2));
+                const bool ok = (k0 + acc_row(r, h2)) < p.N && seg_ok<SEG>(p, qrow_c, k0 + acc_row(r, h2));
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
 
 // ------------------------------------------------------------------------------------------- backward: dK, dV
 // DSPLIT > 1 splits the output d-range of dK/dV over blockIdx.y (register budget at hd = 256).
-template <int HD, int DSPLIT>
+template <int HD, int DSPLIT, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT;
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j;
                 const int q = q0 + acc_row(r, h2);
-                const bool ok = kok && (q < p.N) && seg_ok(p, q, krow_c);
+                const bool ok = kok && (q < p.N) && seg_ok<SEG>(p, q, krow_c);
                 const int qc = min(q, p.N - 1);
                 const float lse_r = ldsR[acc_row(r, h2)];
                 const float del_r = ldsR[32 + acc_row(r, h2)];
@@ -870,7 +875,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p)
 // microseconds of launch ramp and memory latency around a handful of MFMAs.  Here one wave does both for its (batch, head):
 // phase A = the dQ kernel's body (lane = query; also yields delta), phase B = the dK/dV kernel's body (lane = key), with
 // delta / lse handed over through LDS instead of a global round trip.
-template <int HD>
+template <int HD, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j, key = acc_row(r, h2);
-                const float pr = (key < p.N && seg_ok(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+                const float pr = (key < p.N && seg_ok<SEG>(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
                     dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
@@ -990,7 +995,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int r = 8 * s2 + j, q = acc_row(r, h2);
-                const bool ok = tok_ok && (q < p.N) && seg_ok(p, q, tok);
+                const bool ok = tok_ok && (q < p.N) && seg_ok<SEG>(p, q, tok);
                 const int qc = min(q, p.N - 1);
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
                 float dm = 1.f;
@@ -1072,11 +1077,15 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     if (split) {
         const int lds = wpb * 2 * 32 * HD * 2;
         set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * HD * 2);
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
+        set_lds(attn_fwd_kernel<HD, true, true>, 4 * 2 * 32 * HD * 2);
+        if (a.seg) hipLaunchKernelGGL((attn_fwd_kernel<HD, true, true>), grid, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_fwd_kernel<HD, false>, 4 * 32 * HD * 2);
-        hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(64 * wpb), lds, s, a);
+        set_lds(attn_fwd_kernel<HD, false, true>, 4 * 32 * HD * 2);
+        if (a.seg) hipLaunchKernelGGL((attn_fwd_kernel<HD, false, true>), grid, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(64 * wpb), lds, s, a);
     }
     S3D_CHECK_LAUNCH("attention_fwd");
     return 0;
@@ -1092,7 +1101,9 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
         if (a.N <= 32 && !no_small) {
             const int lds = wpb * (3 * 32 * HD * 2 + 256);
             set_lds(attn_bwd_small_kernel<HD>, 4 * (3 * 32 * HD * 2 + 256));
-            hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
+            set_lds(attn_bwd_small_kernel<HD, true>, 4 * (3 * 32 * HD * 2 + 256));
+            if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
+            else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
             S3D_CHECK_LAUNCH("attention_bwd_small");
             return 0;
         }
@@ -1107,7 +1118,9 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
+        set_lds(attn_bwd_dq_kernel<HD, true>, 4 * 32 * HD * 2);
+        if (a.seg) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dq");
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
@@ -1119,8 +1132,10 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     } else {
         const int lds = wpb * (2 * 32 * HD * 2 + 256);
         set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * (2 * 32 * HD * 2 + 256));
+        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT, true>, 4 * (2 * 32 * HD * 2 + 256));
         dim3 g2(grid.x, DSPLIT);
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(64 * wpb), lds, s, a);
+        if (a.seg) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT, true>), g2, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dkv");
     }
     return 0;
