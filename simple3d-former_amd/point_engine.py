@@ -18,8 +18,10 @@ train_partseg.py:74 / train_partseg_lwf.py): the same layers around the same tra
 TransitionUp pairs (VARIANTS below).  The three variants are part-segmentation only, keep timm's 2-D stem / `head` for
 forward_images (models/3DViT_1_layer/model.py:323-337 -> ImageBranch on the shared blocks) and name the point head
 `new_head`; `lwf_train_step` is the train_partseg_lwf.py:207-228 step."""
+import contextlib
 import ctypes
 import math
+import os
 
 import numpy as np
 import torch
@@ -29,6 +31,7 @@ from .engine import BACKBONES, LN_EPS, ParamArena, _BlockScratch, _BlockWorkspac
 
 KNN = 16
 BN_EPS = 1e-5
+GEOM_STREAM = os.environ.get('S3D_POINT_GEOM_STREAM', '1') != '0'    # geometry chain on a side stream (see PointEngine._geometry)
 
 # levels: TransitionDown/Up pairs; first_div: td 0 keeps N / first_div points (models/3DViT/model.py:242 `npoints // 4 ** i`,
 # the variants `npoints // 4 ** (i + 1)`, 3DViT_1_layer/model.py:231); head: key of the point head; image: forward_images exists.
@@ -413,6 +416,49 @@ class PointEngine:
         L.check(self.lib.s3d_pack_rows(L.ptr(x), C, C, ctypes.c_long(rows), L.ptr(out), None, C, L.current_stream()), 'pack_rows')
 
     # ------------------------------------------------------------------ forward
+    def _geometry(self, ws, B, starts):
+        """Everything that depends on the coordinates only: per level FPS -> kNN(16) -> transposed neighbour lists, then the 3-NN
+        tables of the TransitionUps.  FPS is `npoint` strictly sequential iterations on ONE workgroup per cloud (32 - 128
+        workgroups on 256 CUs) and the kNN kernels are short, so the chain runs on a side stream next to the feature path (the
+        input MLPs, then level i's GEMMs / BatchNorms while level i+1's geometry is computed); the feature path waits on one
+        event per level.  Works the same under HIP-graph capture (fork = wait_stream, join = the last wait_event).
+        Returns [event per level..., event after the 3-NN tables] (None when the side stream is off, S3D_POINT_GEOM_STREAM=0)."""
+        lib, nl = self.lib, self.levels
+        if nl == 0:
+            return [None]
+        side = None
+        if GEOM_STREAM:
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            side.wait_stream(torch.cuda.current_stream())
+        events = []
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            s = L.current_stream()
+            xyz_in = ws.xyz
+            for i in range(nl):
+                t = ws.td[i]
+                L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
+                L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
+                L.check(lib.s3d_neighbor_csr(L.ptr(t.idx), B, t.Nin, t.S, KNN, L.ptr(t.inv_off), L.ptr(t.inv_rows), s), 'neighbor_csr')
+                t.xyz_in = xyz_in
+                xyz_in = t.new_xyz
+                events.append(self._mark(side))
+            res_xyz = [ws.xyz] + [t.new_xyz for t in ws.td]      # per resolution, fine -> coarse
+            for j in range(nl):                                  # tu j interpolates resolution nl-j onto resolution nl-j-1
+                u = ws.tu[j]
+                L.check(lib.s3d_knn(L.ptr(res_xyz[nl - j - 1]), L.ptr(res_xyz[nl - j]), B, u.Sf, u.Sc, 3, L.ptr(u.idx), L.ptr(u.w), s), 'knn3')
+            events.append(self._mark(side))
+        return events
+
+    @staticmethod
+    def _mark(side):
+        if side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(side)
+        return ev
+
     def forward(self, x, starts, training=True):
         """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = one int64 [B] tensor per TransitionDown.
         training=False normalises with the BatchNorm running statistics (model.eval()); backward needs training=True."""
@@ -424,6 +470,8 @@ class PointEngine:
         lib, s, a, C0, D = self.lib, L.current_stream(), self.arena, self.C0, self.D
         BN = B * N
         ws.xyz = x[..., :3].contiguous()
+        assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
+        geom = self._geometry(ws, B, starts)
         # fc1(x) + fc_pos_embed(xyz)
         self._pack(x, dp, dp, BN, ws.xp)
         self._pack(x, 3, dp, BN, ws.xyzp)
@@ -432,15 +480,12 @@ class PointEngine:
         self.fcp[0].fwd(ws.xyzp[0], ws.xyzp[1], BN, 7, O_hi=ws.h2[0], O_lo=ws.h2[1], ldo=C0, aux=ws.h2pre, ldaux=C0)
         self.fcp[1].fwd(ws.h2[0], ws.h2[1], BN, 2, C=ws.f, ldc=C0, R=ws.f, ldr=C0)
         # transition downs
-        assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
-        xyz_in, feats, cin_feats = ws.xyz, ws.f, C0
+        feats, cin_feats = ws.f, C0
         for i in range(self.levels):
             t, lay = ws.td[i], self.td[i]
-            L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
-            L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
-            ch, gp = self.ch[i], lay['gp']
-            t.xyz_in = xyz_in
-            L.check(lib.s3d_neighbor_csr(L.ptr(t.idx), B, t.Nin, t.S, KNN, L.ptr(t.inv_off), L.ptr(t.inv_rows), s), 'neighbor_csr')
+            if geom[i] is not None:
+                torch.cuda.current_stream().wait_event(geom[i])          # this level's FPS / kNN / transposed lists are ready
+            ch, gp, xyz_in = self.ch[i], lay['gp'], t.xyz_in
             self._pack(feats, cin_feats, cin_feats, B * t.Nin, t.fp)
             g = L.fill(L.S3dGemmArgs(), A_hi=t.fp[0], A_lo=t.fp[1], lda=cin_feats, B_hi=gp.w[0], B_lo=gp.w[1], ldb=cin_feats,
                        M=B * t.Nin, N=ch, K=cin_feats, C=t.Pf, ldc=ch, alpha=1.0)
@@ -453,7 +498,7 @@ class PointEngine:
             lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch, have_sums=1 if fused else 0)
             lay['c1'].fwd(t.y1[0], t.y1[1], t.R, 4, C=t.x2, ldc=ch)
             lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
-            xyz_in, feats, cin_feats = t.new_xyz, t.out, ch
+            feats, cin_feats = t.out, ch
         # tokens -> blocks -> norm -> drop cls
         S1 = ws.S1
         L.check(lib.s3d_assemble_tokens(L.ptr(feats), L.ptr(a.param('cls_token')), L.ptr(ws.zero_pos), L.ptr(ws.blocks.x[0]),
@@ -468,11 +513,10 @@ class PointEngine:
         # transition ups
         coarse_planes = ws.tp
         nl = self.levels
-        res_xyz = [ws.xyz] + [t.new_xyz for t in ws.td]          # per resolution, fine -> coarse
         res_feats = [ws.f] + [t.out for t in ws.td]
-        coarse_xyz = [res_xyz[nl - j] for j in range(nl)]
-        fine_xyz = [res_xyz[nl - j - 1] for j in range(nl)]
         fine_feats = [res_feats[nl - j - 1] for j in range(nl)]
+        if nl and geom[nl] is not None:
+            torch.cuda.current_stream().wait_event(geom[nl])             # 3-NN tables (and the join of the side stream)
         for j in range(nl):
             u, lay = ws.tu[j], self.tu[j]
             ch = u.ch
@@ -481,7 +525,6 @@ class PointEngine:
             self._pack(fine_feats[j], ch, ch, B * u.Sf, u.inp2)
             lay['l2'].fwd(u.inp2[0], u.inp2[1], B * u.Sf, 4, C=u.u2, ldc=ch)
             lay['b2'].fwd(u.u2, B * u.Sf, y=u.f2, ldo=ch)
-            L.check(lib.s3d_knn(L.ptr(fine_xyz[j]), L.ptr(coarse_xyz[j]), B, u.Sf, u.Sc, 3, L.ptr(u.idx), L.ptr(u.w), s), 'knn3')
             L.check(lib.s3d_interp3(L.ptr(u.f1), u.Sc, L.ptr(u.f2), L.ptr(u.idx), L.ptr(u.w), B, u.Sf, ch, L.ptr(u.out), s), 'interp3')
             if j + 1 < nl:
                 self._pack(u.out, ch, ch, B * u.Sf, ws.tu[j + 1].inp1)
