@@ -350,9 +350,6 @@ class PointEngine:
             R = B * S * KNN
             t = type('TD', (), {})()
             t.S, t.R, t.Nin, t.Cin = S, R, xyz_n, cprev
-            t.fps_idx = torch.empty(B, S, **i32); t.new_xyz = torch.empty(B, S, 3, **f32)
-            t.idx = torch.empty(B, S, KNN, **i32)
-            t.inv_off = torch.empty(B, xyz_n + 1, **i32); t.inv_rows = torch.empty(B, S * KNN, **i32)   # transposed neighbour lists
             t.fp = torch.empty(2, B * xyz_n, cprev, **b16)       # planes of the level's input features
             t.Pf = torch.empty(B * xyz_n, ch, **f32)              # feats . Wf^T per point
             t.dPf = torch.empty(B * xyz_n, ch, **f32); t.dPfp = torch.empty(2, B * xyz_n, ch, **b16)
@@ -384,7 +381,6 @@ class PointEngine:
             u.Sc, u.Sf, u.ch = Sc, Sf, ch
             u.u1 = torch.empty(B * Sc, ch, **f32); u.f1 = torch.empty(B * Sc, ch, **f32)
             u.u2 = torch.empty(B * Sf, ch, **f32); u.f2 = torch.empty(B * Sf, ch, **f32)
-            u.idx = torch.empty(B, Sf, 3, **i32); u.w = torch.empty(B, Sf, 3, **f32)
             u.out = torch.empty(B * Sf, ch, **f32)
             u.inp2 = torch.empty(2, B * Sf, ch, **b16)         # planes of the fine-level input (p0 / f)
             u.inp1 = torch.empty(2, B * Sc, 2 * ch, **b16) if j >= 1 else None     # planes of the coarse input (tu j-1's output)
@@ -392,6 +388,8 @@ class PointEngine:
             u.dxb1 = torch.empty(B * Sc, ch, **b16); u.dxb2 = torch.empty(B * Sf, ch, **b16)
             u.din1 = torch.empty(B * Sc, 2 * ch, **f32)        # gradient wrt the coarse input
             ws.tu.append(u)
+        ws.geo = [self._new_geometry(ws, B), None]              # geometry sets: [in use, prefetched for the next batch (lazily)]
+        self._activate(ws, ws.geo[0])
         ws.dv1 = torch.empty(BN, C0, **f32)
         ws.df = torch.empty(BN, C0, **f32); ws.dfb = torch.empty(BN, C0, **b16)
         ws.dh = torch.empty(BN, C0, **b16)
@@ -415,17 +413,45 @@ class PointEngine:
     def _pack_bf(self, x, C, rows, out):
         L.check(self.lib.s3d_pack_rows(L.ptr(x), C, C, ctypes.c_long(rows), L.ptr(out), None, C, L.current_stream()), 'pack_rows')
 
-    # ------------------------------------------------------------------ forward
-    def _geometry(self, ws, B, starts):
+    # ------------------------------------------------------------------ geometry
+    def _new_geometry(self, ws, B):
+        """Buffers for everything derived from the coordinates of ONE batch (the outputs of _geometry)."""
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev); i32 = dict(dtype=torch.int32, device=dev)
+        g = type('Geometry', (), {})()
+        g.xyz = torch.empty(B, self.N, 3, **f32)
+        g.td, g.tu, g.events = [], [], [None] * (self.levels + 1)
+        for t in ws.td:
+            g.td.append(dict(fps_idx=torch.empty(B, t.S, **i32), new_xyz=torch.empty(B, t.S, 3, **f32), idx=torch.empty(B, t.S, KNN, **i32),
+                             inv_off=torch.empty(B, t.Nin + 1, **i32), inv_rows=torch.empty(B, t.S * KNN, **i32)))   # transposed neighbour lists
+        for u in ws.tu:
+            g.tu.append(dict(idx=torch.empty(B, u.Sf, 3, **i32), w=torch.empty(B, u.Sf, 3, **f32)))
+        return g
+
+    @staticmethod
+    def _activate(ws, g):
+        """Points the workspace's geometry fields at set g (plain attribute rebinding: kernels read the pointers at launch)."""
+        ws.xyz = g.xyz
+        xyz_in = g.xyz
+        for t, d in zip(ws.td, g.td):
+            t.fps_idx, t.new_xyz, t.idx, t.inv_off, t.inv_rows = d['fps_idx'], d['new_xyz'], d['idx'], d['inv_off'], d['inv_rows']
+            t.xyz_in = xyz_in
+            xyz_in = t.new_xyz
+        for u, d in zip(ws.tu, g.tu):
+            u.idx, u.w = d['idx'], d['w']
+
+    def _geometry(self, ws, B, x, starts, g):
         """Everything that depends on the coordinates only: per level FPS -> kNN(16) -> transposed neighbour lists, then the 3-NN
         tables of the TransitionUps.  FPS is `npoint` strictly sequential iterations on ONE workgroup per cloud (32 - 128
         workgroups on 256 CUs) and the kNN kernels are short, so the chain runs on a side stream next to the feature path (the
         input MLPs, then level i's GEMMs / BatchNorms while level i+1's geometry is computed); the feature path waits on one
         event per level.  Works the same under HIP-graph capture (fork = wait_stream, join = the last wait_event).
-        Returns [event per level..., event after the 3-NN tables] (None when the side stream is off, S3D_POINT_GEOM_STREAM=0)."""
+        Fills geometry set g; g.events = [event per level..., event after the 3-NN tables] (None when the side stream is off,
+        S3D_POINT_GEOM_STREAM=0)."""
         lib, nl = self.lib, self.levels
         if nl == 0:
-            return [None]
+            g.xyz.copy_(x[..., :3])
+            return
         side = None
         if GEOM_STREAM:
             if getattr(self, '_side', None) is None:
@@ -435,21 +461,21 @@ class PointEngine:
         events = []
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             s = L.current_stream()
-            xyz_in = ws.xyz
+            g.xyz.copy_(x[..., :3])
+            xyz_in = g.xyz
             for i in range(nl):
-                t = ws.td[i]
-                L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(t.fps_idx), L.ptr(t.new_xyz), s), 'fps')
-                L.check(lib.s3d_knn(L.ptr(t.new_xyz), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(t.idx), None, s), 'knn')
-                L.check(lib.s3d_neighbor_csr(L.ptr(t.idx), B, t.Nin, t.S, KNN, L.ptr(t.inv_off), L.ptr(t.inv_rows), s), 'neighbor_csr')
-                t.xyz_in = xyz_in
-                xyz_in = t.new_xyz
+                t, d = ws.td[i], g.td[i]
+                L.check(lib.s3d_fps(L.ptr(xyz_in), ctypes.c_long(3), L.ptr(starts[i]), B, t.Nin, t.S, L.ptr(d['fps_idx']), L.ptr(d['new_xyz']), s), 'fps')
+                L.check(lib.s3d_knn(L.ptr(d['new_xyz']), L.ptr(xyz_in), B, t.S, t.Nin, KNN, L.ptr(d['idx']), None, s), 'knn')
+                L.check(lib.s3d_neighbor_csr(L.ptr(d['idx']), B, t.Nin, t.S, KNN, L.ptr(d['inv_off']), L.ptr(d['inv_rows']), s), 'neighbor_csr')
+                xyz_in = d['new_xyz']
                 events.append(self._mark(side))
-            res_xyz = [ws.xyz] + [t.new_xyz for t in ws.td]      # per resolution, fine -> coarse
+            res_xyz = [g.xyz] + [d['new_xyz'] for d in g.td]     # per resolution, fine -> coarse
             for j in range(nl):                                  # tu j interpolates resolution nl-j onto resolution nl-j-1
-                u = ws.tu[j]
-                L.check(lib.s3d_knn(L.ptr(res_xyz[nl - j - 1]), L.ptr(res_xyz[nl - j]), B, u.Sf, u.Sc, 3, L.ptr(u.idx), L.ptr(u.w), s), 'knn3')
+                u, d = ws.tu[j], g.tu[j]
+                L.check(lib.s3d_knn(L.ptr(res_xyz[nl - j - 1]), L.ptr(res_xyz[nl - j]), B, u.Sf, u.Sc, 3, L.ptr(d['idx']), L.ptr(d['w']), s), 'knn3')
             events.append(self._mark(side))
-        return events
+        g.events = events
 
     @staticmethod
     def _mark(side):
@@ -459,9 +485,11 @@ class PointEngine:
         ev.record(side)
         return ev
 
-    def forward(self, x, starts, training=True):
+    def forward(self, x, starts, training=True, geometry=None):
         """x [B,N,d_points] fp32 device tensor (xyz in the first 3 columns); starts = one int64 [B] tensor per TransitionDown.
-        training=False normalises with the BatchNorm running statistics (model.eval()); backward needs training=True."""
+        training=False normalises with the BatchNorm running statistics (model.eval()); backward needs training=True.
+        geometry: a set prepared earlier for THIS batch (prepare_geometry / train_step_pipelined), already joined into the
+        current stream -- the forward then skips FPS / kNN and waits for nothing."""
         self.training = bool(training)
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
         B, N, dp = x.shape
@@ -469,9 +497,14 @@ class PointEngine:
         ws = self.workspace(B)
         lib, s, a, C0, D = self.lib, L.current_stream(), self.arena, self.C0, self.D
         BN = B * N
-        ws.xyz = x[..., :3].contiguous()
-        assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
-        geom = self._geometry(ws, B, starts)
+        if geometry is None:
+            assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
+            geometry = ws.geo[0]
+            self._geometry(ws, B, x, starts, geometry)
+            geom = geometry.events
+        else:
+            geom = [None] * (self.levels + 1)
+        self._activate(ws, geometry)
         # fc1(x) + fc_pos_embed(xyz)
         self._pack(x, dp, dp, BN, ws.xp)
         self._pack(x, 3, dp, BN, ws.xyzp)
@@ -671,6 +704,61 @@ class PointEngine:
         self.backward(B)
         self.sgd_step()
         return loss
+
+    def prepare_geometry(self, x, starts, slot=0):
+        """FPS / kNN / transposed lists / 3-NN tables of batch x into geometry set `slot`, joined into the current stream."""
+        ws = self.workspace(x.shape[0])
+        if ws.geo[slot] is None:
+            ws.geo[slot] = self._new_geometry(ws, x.shape[0])
+        g = ws.geo[slot]
+        self._geometry(ws, x.shape[0], x, starts, g)
+        if g.events[-1] is not None:
+            torch.cuda.current_stream().wait_event(g.events[-1])
+        return g
+
+    def train_step_pipelined(self, x, target, starts, next_x, next_starts, slot):
+        """One training step on batch x, whose geometry was prepared into set `slot` by the previous call (or prepare_geometry),
+        while the side stream prepares the geometry of the NEXT batch into the other set.  The geometry of a batch depends on
+        its coordinates (and the FPS start draws) only, and FPS in particular is a long chain of sequential iterations on one
+        workgroup per cloud: computed inside the step it is 1.5 ms of mostly idle GPU before the first TransitionDown can
+        start (cfg-5); computed one step ahead it hides behind the GEMMs of the current step.  Every step still does one
+        geometry pass and one forward / backward / update; the two only belong to consecutive batches."""
+        B = x.shape[0]
+        ws = self.workspace(B)
+        cur = ws.geo[slot]
+        assert cur is not None, 'prepare_geometry(x, starts, slot) must run before the first pipelined step'
+        if ws.geo[1 - slot] is None:
+            ws.geo[1 - slot] = self._new_geometry(ws, B)
+        nxt = ws.geo[1 - slot]
+        self._geometry(ws, B, next_x, next_starts, nxt)          # side stream (forks from here)
+        self.forward(x, starts, geometry=cur)
+        loss = self.cross_entropy(B, target)
+        self.backward(B)
+        self.sgd_step()
+        if nxt.events[-1] is not None:
+            torch.cuda.current_stream().wait_event(nxt.events[-1])    # join: the next step finds its geometry complete
+        return loss
+
+    def capture_train_step_pipelined(self, xs, ys, starts):
+        """Two HIP graphs over static buffers xs[p], ys[p], starts[p] (p = 0, 1): graph p trains on batch p with geometry set p and
+        prepares set 1-p from batch 1-p.  Protocol: fill buffers 0, prepare_geometry(xs[0], starts[0], 0); then for every step
+        write the NEXT batch into buffers 1-p, graphs[p].replay(), p ^= 1.  Returns (graphs, loss scalar tensor)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                # warm-up: kernel attributes, workspaces, both geometry sets
+            self.prepare_geometry(xs[0], starts[0], 0)
+            for p in (0, 1):
+                self.train_step_pipelined(xs[p], ys[p], starts[p], xs[1 - p], starts[1 - p], p)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs = []
+        for p in (0, 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self.train_step_pipelined(xs[p], ys[p], starts[p], xs[1 - p], starts[1 - p], p)
+            graphs.append(g)
+        self.prepare_geometry(xs[0], starts[0], 0)
+        return graphs, loss
 
     def lwf_train_step(self, x, target, starts, img, img_target, lambda_weight=0.1):
         """train_partseg_lwf.py:207-228: loss = CE(seg_pred, target) + lambda * CE(forward_images(images), label_teacher); one

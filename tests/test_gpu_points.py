@@ -455,3 +455,40 @@ def test_group_project_fwd_bwd(B, N, S, C, ch):
     assert rel_err(dPf.double().cpu().t() @ feats.double().reshape(B * N, C), Wd.grad[:, 3:]) < 1e-4
     with pytest.raises(RuntimeError, match='multiple of 4'):
         L.check(L.lib().s3d_group_project_fwd(ctypes.byref(L.fill(a, C=ch - 1)), L.current_stream()), 'gp fwd')
+
+
+def test_pipelined_steps_equal_plain_steps():
+    """train_step_pipelined (geometry of the next batch prepared on the side stream during the current step, two geometry sets)
+    == the plain train_step sequence on alternating batches, eagerly and through the two captured graphs."""
+    kw = dict(backbone='deit_tiny_patch16_224', n_points=64, d_points=22, n_classes=50)
+    sd = po.init_state_dict(backbone=kw['backbone'], n_classes=50, d_points=22, seed=3)
+    batches = []
+    for seed in (4, 5):
+        x, y, starts = po.synthetic_points(3, 64, 22, 50, 'seg', seed=seed)
+        batches.append((x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts)))
+    ref = PointEngine(task='seg', device=DEV, **kw); ref.load_state_dict(sd)
+    want = [float(ref.train_step(*batches[i % 2])) for i in range(4)]
+    eng = PointEngine(task='seg', device=DEV, **kw); eng.load_state_dict(sd)
+    eng.prepare_geometry(batches[0][0], batches[0][2], 0)
+    got = []
+    for i in range(4):
+        (x, y, st), (nx, _, nst) = batches[i % 2], batches[(i + 1) % 2]
+        got.append(float(eng.train_step_pipelined(x, y, st, nx, nst, i % 2)))
+    assert max(abs(a - b) for a, b in zip(want, got)) <= 2e-3, (want, got)
+    assert float((eng.arena.p - ref.arena.p).abs().max()) <= 2e-3
+    # captured: two graphs over static buffers, alternating
+    eng2 = PointEngine(task='seg', device=DEV, **kw); eng2.load_state_dict(sd)
+    xs = [batches[0][0].clone(), batches[1][0].clone()]; ys = [batches[0][1].clone(), batches[1][1].clone()]
+    sts = [tuple(t.clone() for t in batches[0][2]), tuple(t.clone() for t in batches[1][2])]
+    snap = (eng2.arena.p.clone(), eng2.buf.clone(), eng2.sgd_steps.clone(), [b.clone() for b in eng2.bn_buffers()])
+    graphs, loss = eng2.capture_train_step_pipelined(xs, ys, sts)
+    eng2.arena.p.copy_(snap[0]); eng2.buf.copy_(snap[1]); eng2.sgd_steps.copy_(snap[2]); eng2.arena.g.zero_()
+    for b, v in zip(eng2.bn_buffers(), snap[3]):
+        b.copy_(v)
+    eng2.refresh_weight_planes()
+    eng2.prepare_geometry(xs[0], sts[0], 0)
+    got2 = []
+    for i in range(4):
+        graphs[i % 2].replay()
+        got2.append(float(loss))
+    assert max(abs(a - b) for a, b in zip(want, got2)) <= 2e-3, (want, got2)

@@ -5,7 +5,8 @@
    (config/model/3DViT_*.yaml) on the cfg5 data shape; LWF=1 adds the image branch of train_partseg_lwf.py (IMG_BATCH images).
    Data parallel (cfg-4 on 4 GPUs, cfg-5 on 8; weak scaling, `batch` clouds per GPU), one process per GPU over RCCL:
    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P tools/point_bench.py cfg5
-   (rank 0 prints the whole-job rate; FORCE_COLLECTIVES=1 issues the all-reduces at N = 1 too)."""
+   (rank 0 prints the whole-job rate; FORCE_COLLECTIVES=1 issues the all-reduces at N = 1 too).
+   PIPELINE=1: train_step_pipelined -- the geometry (FPS / kNN) of batch i+1 is computed on the side stream during step i."""
 import json
 import os
 import sys
@@ -58,6 +59,22 @@ def main():
         tr = PointDataParallelTrainer(eng, use_graphs=use_graph, force_collectives=force)
         loss = tr.step(x, y, starts)
         step = (lambda: tr.step_graph()) if use_graph else (lambda: tr.step_eager(x, y, starts))
+    elif os.environ.get('PIPELINE', '0') == '1' and not lwf:
+        xs, ys, sts = [x, x.clone()], [y, y.clone()], [starts, tuple(t.clone() for t in starts)]
+        state = {'p': 0}
+        if use_graph:
+            graphs, loss = eng.capture_train_step_pipelined(xs, ys, sts)
+
+            def step():
+                graphs[state['p']].replay()
+                state['p'] ^= 1
+        else:
+            eng.prepare_geometry(xs[0], sts[0], 0)
+
+            def step():
+                p = state['p']
+                eng.train_step_pipelined(xs[p], ys[p], sts[p], xs[1 - p], sts[1 - p], p)
+                state['p'] ^= 1
     elif use_graph:                                   # the step has no host synchronisation: capture it once, replay it
         graph, loss = eng.capture_train_step(x, y, starts)
         step = graph.replay
@@ -83,7 +100,7 @@ def main():
         dist.destroy_process_group()
         return
     out = dict(config=name, variant=variant, backbone=backbone, lwf=lwf, n_gpus=world, scaling='weak', global_batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
-               points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch='hipGraph replay' if use_graph else 'eager')
+               points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch=('hipGraph replay' if use_graph else 'eager') + (', geometry one step ahead' if os.environ.get('PIPELINE', '0') == '1' and not lwf and not dp else ''))
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
