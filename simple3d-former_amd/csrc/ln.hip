@@ -6,16 +6,20 @@
 namespace {
 
 constexpr int MAXC = 4;   // float4 chunks per lane -> D <= 1024
+// The kernels are templated on the chunk count MC actually needed (D <= 256 / 512 / 1024): with MC = 4 a D = 192 row (deit_tiny,
+// 33 k - 188 k rows per launch on the point and group_embed paths) still issued four clamped loads per array and held 176 VGPRs
+// = two waves per SIMD, i.e. half the HBM rate the same kernel reaches at D = 768.
 
+template <int MC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.rows) return;
     const float* x = p.x + row * p.ldx;
-    float4 v[MAXC];
+    float4 v[MC];
     float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MC; ++c) {
         const int col = c * 256 + lane * 4;
         const float4 t = *reinterpret_cast<const float4*>(x + min(col, p.D - 4));      // unconditional, clamped
         const float keep = (col < p.D) ? 1.f : 0.f;
@@ -25,7 +29,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
     const float mean = wave_sum(s) / p.D;
     float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < p.D) {
             const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
         if (p.rstd) p.rstd[row] = rstd;
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < p.D) {
             const float4 g = *reinterpret_cast<const float4*>(p.gamma + col);
@@ -63,19 +67,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
 // block count is kept at rows/16).
 constexpr int MAX_RPW = 4;
 
-template <int RPW>
+template <int RPW, int MC>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* red = reinterpret_cast<float*>(smem);          // [2][4 waves][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long nw = (long)gridDim.x * 4;
-    float4 dg[MAXC], db[MAXC];
+    float4 dg[MC], db[MC];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nchunk = (p.D + 255) / 256;                 // float4 chunks per lane actually used (<= MAXC)
+    for (int c = 0; c < MC; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nchunk = (p.D + 255) / 256;                 // float4 chunks per lane actually used (<= MC)
 
     for (long row0 = (long)blockIdx.x * 4 + wave; row0 < p.rows; row0 += nw * RPW) {
-        float4 X[RPW][MAXC], DY[RPW][MAXC], R[RPW][MAXC];
+        float4 X[RPW][MC], DY[RPW][MC], R[RPW][MC];
         float mean[RPW], rstd[RPW];
         // phase 1: every load of every row of this batch
 #pragma unroll
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
             mean[i] = p.mean[row];
             rstd[i] = p.rstd[row];
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 const int col = min(c * 256 + lane * 4, p.D - 4);
                 if (c < nchunk) {
                     X[i][c] = *reinterpret_cast<const float4*>(p.x + row * p.ldx + col);
@@ -98,10 +102,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
         for (int i = 0; i < RPW; ++i) {
             const long row = row0 + (long)i * nw;
             const bool live = row < p.rows;
-            float4 xh[MAXC], g[MAXC];
+            float4 xh[MC], g[MC];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 const int col = c * 256 + lane * 4;
                 if (c < nchunk && col < p.D) {
                     const float4 w = *reinterpret_cast<const float4*>(p.gamma + col);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
             s2 = wave_sum(s2) / p.D;
             if (!live) continue;                          // wave-uniform
 #pragma unroll
-            for (int c = 0; c < MAXC; ++c) {
+            for (int c = 0; c < MC; ++c) {
                 const int col = c * 256 + lane * 4;
                 if (c < nchunk && col < p.D) {
                     const float4 r = R[i][c];
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
     }
     if (p.dgamma == nullptr && p.partial == nullptr) return;   // uniform
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
+    for (int c = 0; c < MC; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < p.D) {
             *reinterpret_cast<float4*>(red + (0 * 4 + wave) * p.D + col) = dg[c];
@@ -199,7 +203,10 @@ __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const LnReduceArgs 
 int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024 && a.ldx % 4 == 0, "layernorm: D=%d must be a multiple of 4 and <= 1024", a.D);
     if (a.rows <= 0) return 0;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((a.rows + 3) / 4)), dim3(256), 0, s, a);
+    const dim3 grid((unsigned)((a.rows + 3) / 4));
+    if (a.D <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, a);
+    else if (a.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a);
     S3D_CHECK_LAUNCH("ln_fwd");
     return 0;
 }
@@ -218,9 +225,16 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     // rows each wave handles per trip: as many as the grid leaves it (clamped duplicate rows would only add loads)
     const long per_wave = (a.rows + blocks * 4 - 1) / (blocks * 4);
     const size_t lds = 2 * 4 * a.D * sizeof(float);
-    if (per_wave >= 3) hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else if (per_wave == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), lds, s, a);
+#define S3D_LN_BWD(RPW)                                                                                          \
+    do {                                                                                                         \
+        if (a.D <= 256) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 1>), dim3((unsigned)blocks), dim3(256), lds, s, a);      \
+        else if (a.D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<RPW, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a);                 \
+    } while (0)
+    if (per_wave >= 3) S3D_LN_BWD(4);
+    else if (per_wave == 2) S3D_LN_BWD(2);
+    else S3D_LN_BWD(1);
+#undef S3D_LN_BWD
     S3D_CHECK_LAUNCH("ln_bwd");
     return 0;
 }
