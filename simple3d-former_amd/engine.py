@@ -168,14 +168,17 @@ class _BlockScratch:
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
         self.dxn = torch.empty(M, D, **f32)
-        self.dx_a = torch.empty(M, D, **f32)
+        # dx_a and its bf16 copy share one allocation: the backward starts from "zero except the cls rows", one fill instead of two
+        self._dxa_raw = torch.empty(M * D * 6, dtype=torch.uint8, device=device)
+        self.dx_a = self._dxa_raw[:M * D * 4].view(torch.float32).view(M, D)
+        self.dx_a_bf = self._dxa_raw[M * D * 4:].view(torch.bfloat16).view(M, D)
         self.dx_b = torch.empty(M, D, **f32)
-        self.dx_a_bf = torch.empty(M, D, **b16)
         self.dx_b_bf = torch.empty(M, D, **b16)
         self.dh = torch.empty(M, hidden, **b16)
         self.dqkv = torch.empty(M, 3 * D, **b16)
         self.datt = torch.empty(M, D, **b16)
         self.delta = torch.empty(BHN, **f32)
+        self.zero_dx_a = self._dxa_raw.zero_
         self.c = L.S3dBlockScratch()
         L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
                dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
@@ -447,8 +450,7 @@ class VoxelEngine:
             ws.dlogits.copy_(dlogits)
         L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
         sc = ws.scratch
-        sc.dx_a.zero_()
-        sc.dx_a_bf.zero_()
+        sc.zero_dx_a()
         nt = ws.ntok_last
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.last.x[self.depth], ldx=nt * D,
                     mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=nt * D,
@@ -482,8 +484,7 @@ class VoxelEngine:
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'pass-2 token grads')
         L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.dgfeat), ctypes.c_long(ws.B), self.P * self.P, D, s),
                 'assemble bwd')
-        sc.dx_a.zero_()
-        sc.dx_a_bf.zero_()
+        sc.zero_dx_a()
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dgfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
                     mean=ws.gstats[0], rstd=ws.gstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
                     dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),

@@ -118,8 +118,7 @@ class ImageBranch:
             ws.dlogits.copy_(dlogits)
         L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd (images)')
         sc = ws.scratch
-        sc.dx_a.zero_()
-        sc.dx_a_bf.zero_()
+        sc.zero_dx_a()
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.blocks.x[e.depth], ldx=self.ntok * D, mean=ws.fstats[0],
                     rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D, dx_bf=sc.dx_a_bf,
                     lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'), rows=B, D=D)
