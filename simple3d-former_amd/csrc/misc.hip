@@ -316,59 +316,20 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
     if (lane == 0 && acc != 0.f) atomic_add_f32(p.loss, acc / den);
 }
 
-// one wave-per-row block for small batches (rows <= 256: every voxel / point classification batch): denominator, loss and
-// dlogits in ONE launch, no atomics, fixed summation order (the two-kernel path below costs a second ~5 us launch)
-__global__ __launch_bounds__(256) void ce_small_kernel(const CeArgs p) {
-    __shared__ float part[256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float s = 0.f;
-    if (p.weight) for (long r = threadIdx.x; r < p.rows; r += 256) s += p.weight[p.target[r]];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
-    const float den = p.weight ? part[0] : (float)p.rows;
-    __syncthreads();
-    float acc = 0.f;
-    const int ld = p.ld > 0 ? p.ld : p.C;
-    for (long row = wave; row < p.rows; row += 4) {
-        const float* l = p.logits + row * ld;
-        float m = -INFINITY;
-        for (int c = lane; c < p.C; c += 64) m = fmaxf(m, l[c]);
-        m = wave_max(m);
-        float e = 0.f;
-        for (int c = lane; c < p.C; c += 64) e += expf(l[c] - m);
-        e = wave_sum(e);
-        const long t = p.target[row];
-        const float w = p.weight ? p.weight[t] : 1.f;
-        const float lse = m + logf(e);
-        acc += w * (lse - l[t]);
-        if (p.dlogits)
-            for (int c = lane; c < ld; c += 64)
-                p.dlogits[row * ld + c] = (c < p.C) ? p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den : 0.f;
-    }
-    if (lane == 0) part[wave] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) { p.loss[0] = ((part[0] + part[1]) + (part[2] + part[3])) / den; p.loss[1] = den; }
-}
-
 // ------------------------------------------------------------------------------------------- Adam
-// The step counter and the bias corrections live on the device (the step is replayed as a graph).  Thread 0 of every workgroup
-// derives the corrections for step + 1 (double precision, as torch does) and shares them through LDS; the LAST workgroup to
-// finish (ticket in AdamState::pad) publishes step + 1 -- by then every workgroup has read the old value.  (A separate
-// one-thread prelude kernel did this before: one more ~5 us launch per step.)
+__global__ void adam_prelude_kernel(AdamState* st) {
+    st->step += 1;
+    const double b1 = st->beta1, b2 = st->beta2;
+    const double bc1 = 1.0 - pow(b1, (double)st->step);
+    const double bc2 = 1.0 - pow(b2, (double)st->step);
+    st->step_size = (float)((double)st->lr / bc1);
+    st->bc2_sqrt = (float)sqrt(bc2);
+}
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ hi,
-                                                   bf16_t* __restrict__ lo, long n4, AdamState* st, int zero_grad) {
-    __shared__ float corr[2];
-    const int step = st->step + 1;
-    if (threadIdx.x == 0) {
-        const double bc1 = 1.0 - pow((double)st->beta1, (double)step), bc2 = 1.0 - pow((double)st->beta2, (double)step);
-        corr[0] = (float)((double)st->lr / bc1);
-        corr[1] = (float)sqrt(bc2);
-    }
-    __syncthreads();
+                                                   bf16_t* __restrict__ lo, long n4, const AdamState* st, int zero_grad) {
     const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
-    const float step_size = corr[0], bc2s = corr[1];
+    const float step_size = st->step_size, bc2s = st->bc2_sqrt;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
@@ -389,18 +350,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hi) reinterpret_cast<uint2*>(hi)[i] = H.u;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = L.u;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // relaxed device-scope ticket, NO __threadfence(): a device-scope release on gfx950 writes the XCD's L2 back, and 2048 of
-        // them in the middle of a 0.8 GB streaming kernel cost 130 us.  Nothing needs ordering here: this workgroup consumed
-        // st->step long ago, and the new value only has to be visible to the NEXT kernel.
-        if (__hip_atomic_fetch_add(&st->pad, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
-            st->step = step;
-            st->step_size = step_size;
-            st->bc2_sqrt = bc2s;
-            st->pad = 0;
-        }
     }
 }
 
@@ -490,11 +439,6 @@ int s3d_launch_head_bwd(const HeadArgs& a, hipStream_t s) {
 }
 
 int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
-    if (a.rows <= 256) {
-        hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(256), 0, s, a);
-        S3D_CHECK_LAUNCH("cross_entropy");
-        return 0;
-    }
     hipLaunchKernelGGL(ce_den_kernel, dim3(1), dim3(256), 0, s, a);
     long blocks = (a.rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
@@ -506,6 +450,7 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
                     int zero_grad, hipStream_t s) {
     S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
+    hipLaunchKernelGGL(adam_prelude_kernel, dim3(1), dim3(1), 0, s, st);
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad);
