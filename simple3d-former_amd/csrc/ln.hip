@@ -3,6 +3,8 @@
 // residual-gradient add, a bf16 copy of dx (operand of the next wgrad/dgrad GEMM) and the gamma/beta gradients.
 #include "kernels.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int MAXC = 4;   // float4 chunks per lane -> D <= 1024
@@ -231,8 +233,10 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
         else if (a.D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a); \
         else hipLaunchKernelGGL((ln_bwd_kernel<RPW, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a);                 \
     } while (0)
-    if (per_wave >= 3) S3D_LN_BWD(4);
-    else if (per_wave == 2) S3D_LN_BWD(2);
+    static const int forced_rpw = getenv("S3D_LN_RPW") ? atoi(getenv("S3D_LN_RPW")) : 0;      // tuning override
+    const int rpw = forced_rpw ? forced_rpw : (per_wave >= 3 ? 4 : per_wave == 2 ? 2 : 1);
+    if (rpw >= 4) S3D_LN_BWD(4);
+    else if (rpw == 2) S3D_LN_BWD(2);
     else S3D_LN_BWD(1);
 #undef S3D_LN_BWD
     S3D_CHECK_LAUNCH("ln_bwd");
