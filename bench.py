@@ -159,12 +159,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # S3D_BENCH_DEVICE / S3D_BENCH_BACKEND: dry run of the multi-rank code path on a box with fewer GPUs than ranks (all ranks on
+    # one device, gloo collectives -- RCCL refuses two ranks per device); the numbers of such a run mean nothing
+    dev_index = int(os.environ.get('S3D_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1 or args.force_collectives:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29541')
-        dist.init_process_group(backend='nccl', init_method='env://', world_size=world, rank=rank)
+        dist.init_process_group(backend=os.environ.get('S3D_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
 
     # model + optimizer state (reference init, seed 9), per-rank synthetic shard of the global batch
     eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, pos_embedding=conf['pos_embedding'], **CFG)
@@ -306,10 +309,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(x_cpu, y_cpu)
 
+    # RCCL writes a version banner to the C stdout of every rank, block-buffered until the process exits -- i.e. AFTER a JSON line
+    # printed from Python.  Push it out on every rank first, so that the JSON line is the last thing on stdout.
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        barrier()                     # rank 0 ran the instrumented pass; every rank's banner is out
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        barrier()                     # rank 0 ran the instrumented pass; leave together
+    if world > 1 or args.force_collectives:
+        if world > 1:
+            barrier()
         dist.destroy_process_group()
 
 

@@ -101,7 +101,9 @@ def main():
         return
     out = dict(config=name, variant=variant, backbone=backbone, lwf=lwf, n_gpus=world, scaling='weak', global_batch=B, ms_per_step=round(el / steps * 1e3, 3), clouds_per_sec=round(B * steps / el, 1),
                points_per_sec=round(B * c['n_points'] * steps / el, 0), loss=round(float(loss), 5), launch=('hipGraph replay' if use_graph else 'eager') + (', geometry one step ahead' if os.environ.get('PIPELINE', '0') == '1' and not lwf and not dp else ''))
-    print(json.dumps(out))
+    import ctypes
+    ctypes.CDLL(None).fflush(None)                  # RCCL's version banner sits in the C stdout buffer: out before the JSON line
+    print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 
