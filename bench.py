@@ -139,6 +139,9 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-collectives', action='store_true',
                     help='diagnostic: run the segmented multi-GPU step (RCCL calls between graph segments) even at N=1')
+    ap.add_argument('--graph-collectives', action='store_true',
+                    help='experimental: one HIP graph per step with the RCCL all-reduces captured inside (default: one graph per '
+                         'backward segment, collectives launched from the host in between)')
     ap.add_argument('--buckets', type=int, default=4)
     ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
@@ -176,7 +179,7 @@ def main():
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
     x, y = x_cpu.to(dev), y_cpu.to(dev)
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
-                                  force_collectives=args.force_collectives)
+                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
 
     def barrier():
@@ -223,7 +226,9 @@ def main():
         'config': {'workload': conf['workload'], 'batch_per_gpu': BATCH_PER_GPU,
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
-                   'grad_buckets': len(trainer.slices)},
+                   'grad_buckets': len(trainer.slices),
+                   'collectives': ('none' if not (world > 1 or args.force_collectives) else 'captured in the step graph'
+                                   if args.graph_collectives else 'host-launched between graph segments')},
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
         'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         'loss_first_step': round(first_loss, 5) if first_loss is not None else None, 'loss_last_step': round(final_loss, 5),

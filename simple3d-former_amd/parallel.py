@@ -59,7 +59,12 @@ def broadcast_parameters(flat_param, src=0, group=None):
 class DataParallelTrainer:
     """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
 
-    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False):
+    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False, graph_collectives=False):
+        """graph_collectives: capture the WHOLE step -- backward segments, the all-reduce of every bucket (RCCL calls are
+        capturable: tools/probes/rccl_graph_probe.py), Adam -- into ONE HIP graph instead of one graph per segment with the
+        collectives launched from the host in between.  Removes the per-step launch overhead of the segmented mode (measured at
+        one rank); opt-in until it has run on a multi-GPU node."""
+        self.graph_collectives = bool(graph_collectives)
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -116,6 +121,19 @@ class DataParallelTrainer:
             t.copy_(sv)
         eng.refresh_weight_planes()
         torch.cuda.synchronize()
+        if self.graph_collectives:
+            self.reducer.launch(0); self.reducer.wait()                # communicator set-up outside the capture
+            eng.arena.g.zero_()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for k in range(len(self.segments)):
+                    self._phase(k, B, sx, sy, weight)
+                    self.reducer.launch(k)                              # a side branch of the graph: overlaps the next segment
+                self.reducer.wait()
+                eng.adam_step(zero_grad=True)
+            self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss)
+            return self._cap
         graphs = []
         for k in range(len(self.segments)):
             g = torch.cuda.CUDAGraph()
@@ -131,6 +149,9 @@ class DataParallelTrainer:
     def step_graph(self):
         """Replays the captured step on the static buffers (cap['x'], cap['y'] must already hold the batch)."""
         cap = self._cap
+        if 'whole' in cap:
+            cap['whole'].replay()
+            return cap['loss'][0]
         for k, g in enumerate(cap['graphs']):
             g.replay()
             self.reducer.launch(k)          # RCCL all-reduce of bucket k overlaps the next segment's replay
