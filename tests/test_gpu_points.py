@@ -410,7 +410,8 @@ def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('B,N,S,C,ch', [(2, 40, 10, 8, 16), (3, 64, 64, 48, 96), (2, 256, 64, 96, 192), (1, 128, 32, 192, 384)])
+@pytest.mark.parametrize('B,N,S,C,ch', [(2, 40, 10, 8, 16), (3, 64, 64, 48, 96), (2, 256, 64, 96, 192), (1, 128, 32, 192, 384),
+                                          (1, 64, 16, 384, 768)])     # ch > 512: two channel passes in the backward kernel
 def test_group_project_fwd_bwd(B, N, S, C, ch):
     """s3d_group_project_*: conv0([xyz_rel | feats[idx]]) = Pf[idx] + xyz_rel . Wx^T + b vs the reference formulation (grouped
     rows through a [ch][3 + C] weight, sample_and_group + the first Conv2d of PointNetSetAbstraction) in fp64."""
