@@ -140,7 +140,7 @@ def test_gemm_epilogues_gelu_resid_token_dgelu():
     assert rms_err(o.float(), (dyh.double() @ w2h.double()) * gp) < 1e-2
 
 
-@pytest.mark.parametrize('rows,D', [(7, 192), (1664, 384), (333, 768)])
+@pytest.mark.parametrize('rows,D', [(7, 192), (1664, 384), (333, 768), (40000, 192), (9, 256), (64, 1024), (5000, 512)])
 def test_layernorm_fwd_bwd(rows, D):
     g = torch.Generator().manual_seed(5)
     x = (torch.randn(rows, D, generator=g) * 2 + 0.5).to(DEV)

@@ -495,3 +495,18 @@ def test_pipelined_steps_equal_plain_steps():
         graphs[i % 2].replay()
         got2.append(float(loss))
     assert max(abs(a - b) for a, b in zip(want, got2)) <= 2e-3, (want, got2)
+
+
+@pytest.mark.parametrize('B,N,C', [(3, 64, 48), (128, 1024, 48), (2, 100, 192), (2, 50, 320)])
+def test_mean_points_and_broadcast(B, N, C):
+    """x.mean(1) (models/3DViT/model.py:325) and its backward (broadcast / N); C > 256 walks the column chunks."""
+    g = torch.Generator().manual_seed(B + N + C)
+    x = torch.randn(B, N, C, generator=g)
+    xd = x.to(DEV)
+    out = torch.empty(B, C, device=DEV)
+    L.check(L.lib().s3d_mean_points(L.ptr(xd), B, N, C, L.ptr(out), L.current_stream()), 'mean_points')
+    assert rel_err(out, x.double().mean(1)) < 1e-5
+    d = torch.randn(B, C, generator=g).to(DEV)
+    y = torch.empty(B * N, C, device=DEV)
+    L.check(L.lib().s3d_bcast_rows(L.ptr(d), N, C, ctypes.c_long(B * N), ctypes.c_float(1.0 / N), L.ptr(y), L.current_stream()), 'bcast')
+    assert rel_err(y.view(B, N, C), (d.cpu() / N)[:, None, :].expand(B, N, C)) < 1e-6
