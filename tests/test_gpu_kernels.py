@@ -44,7 +44,9 @@ def test_split_bf16_reconstructs_fp32():
     assert torch.equal(hi, x.to(torch.bfloat16))                                        # hi = RNE(x), same as torch
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 40, 384), (100, 384, 216), (1664, 1152, 384), (1664, 384, 1536), (4096, 3072, 768)])
+@pytest.mark.parametrize('M,N,K', [(64, 40, 384), (100, 384, 216), (1664, 1152, 384), (1664, 384, 1536), (4096, 3072, 768),
+                                   # point-path shapes: many rows, narrow n, k = 96 / 64 / 192 (k % 32 on the 128x128 LDS-DMA kernel), ragged M
+                                   (70000, 96, 96), (65537, 96, 64), (33000, 192, 192), (66000, 48, 48)])
 @pytest.mark.parametrize('split', [True, False])
 def test_gemm_forward_nt(M, N, K, split):
     g = torch.Generator().manual_seed(1)
