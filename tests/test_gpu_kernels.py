@@ -68,7 +68,8 @@ def test_gemm_catches_transposes():
     assert rel_err(got, w.t()) < 1e-5
 
 
-@pytest.mark.parametrize('M,N,K', [(78, 192, 576), (1664, 1536, 384), (1664, 384, 1152), (4096, 768, 3072)])
+@pytest.mark.parametrize('M,N,K', [(78, 192, 576), (1664, 1536, 384), (1664, 384, 1152), (4096, 768, 3072),
+                                   (70000, 96, 96), (66000, 192, 192), (33001, 48, 96), (131072, 56, 96)])      # point path: k = 96 stays register-staged
 def test_gemm_dgrad_nn(M, N, K):
     """dx[m][i] = sum_o dy[m][o] W[o][i]: W is stored [K=o][N=i] (k-major B operand)."""
     g = torch.Generator().manual_seed(2)
@@ -83,7 +84,8 @@ def test_gemm_dgrad_nn(M, N, K):
     assert rms_err(out, dy.double() @ w.double()) < 1e-2
 
 
-@pytest.mark.parametrize('rows,O,I', [(30, 64, 192), (78, 576, 192), (1664, 1536, 384), (1664, 384, 1536), (1664, 384, 216)])
+@pytest.mark.parametrize('rows,O,I', [(30, 64, 192), (78, 576, 192), (1664, 1536, 384), (1664, 384, 1536), (1664, 384, 216),
+                                      (70016, 96, 96), (131072, 96, 48), (188160, 768, 768), (33000, 192, 96)])   # long reductions
 def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     """dW[o][i] += sum_m dy[m][o] x[m][i]; db[o] += sum_m dy[m][o] (split-K fp32 atomics)."""
     g = torch.Generator().manual_seed(3)
@@ -99,6 +101,17 @@ def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     # accumulation semantics: a second call adds
     ops.gemm(1, 1, 0, 'ATOMIC', splitk=0, A_hi=dyh, lda=O, B_hi=xh, ldb=I, M=O, N=I, K=rows, C=dW, ldc=I, bias_grad=db)
     assert rel_err(dW, 2 * (dyh.double().t() @ xh.double())) < 2e-5
+
+
+def test_gemm_wgrad_into_a_sub_matrix():
+    """The factored set-abstraction convolution accumulates d(Wf) INSIDE the conv weight's gradient: C = dW + 3 columns, ldc = 3 + I."""
+    g = torch.Generator().manual_seed(13)
+    rows, O, I = 8192, 96, 48
+    dy = torch.randn(rows, O, generator=g).to(DEV); x = torch.randn(rows, I, generator=g).to(DEV)
+    dyh, _ = ops.split_bf16(dy); xh, _ = ops.split_bf16(x)
+    dW = torch.zeros(O, 3 + I, dtype=torch.float32, device=DEV)
+    ops.gemm(1, 1, 0, 'ATOMIC', splitk=0, A_hi=dyh, lda=O, B_hi=xh, ldb=I, M=O, N=I, K=rows, C=dW[:, 3:], ldc=3 + I)
+    assert rel_err(dW[:, 3:], dyh.double().t() @ xh.double()) < 2e-5 and float(dW[:, :3].abs().max()) == 0.0
 
 
 def test_gemm_epilogues_gelu_resid_token_dgelu():
