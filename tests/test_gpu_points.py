@@ -510,3 +510,25 @@ def test_mean_points_and_broadcast(B, N, C):
     y = torch.empty(B * N, C, device=DEV)
     L.check(L.lib().s3d_bcast_rows(L.ptr(d), N, C, ctypes.c_long(B * N), ctypes.c_float(1.0 / N), L.ptr(y), L.current_stream()), 'bcast')
     assert rel_err(y.view(B, N, C), (d.cpu() / N)[:, None, :].expand(B, N, C)) < 1e-6
+
+
+def test_geometry_on_the_main_stream_gives_the_same_result(monkeypatch):
+    """S3D_POINT_GEOM_STREAM=0 (FPS / kNN inline on the current stream) and the side-stream default must agree bit for bit: the
+    same kernels on the same inputs, only their placement differs."""
+    from simple3d_former_amd import point_engine as pe_mod
+    z, cfg, sd, x, y, starts = load_point_case('pts_seg_tiny_n64_b2')
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(pe_mod, 'GEOM_STREAM', on)
+        eng = PointEngine(backbone=cfg['backbone'], n_points=64, d_points=22, n_classes=50, task='seg', device=DEV)
+        eng.load_state_dict(sd)
+        sts = tuple(s.to(DEV) for s in starts)
+        logits = eng.forward(x.to(DEV), sts).clone()
+        eng.cross_entropy(cfg['batch'], y.to(DEV)); eng.zero_grad(); eng.backward(cfg['batch'])
+        outs.append((logits, [eng.workspace(cfg['batch']).td[i].idx.clone() for i in range(2)], eng.arena.grad('fc1.0.weight').clone()))
+        assert (eng._side is not None) == on if hasattr(eng, '_side') else not on
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+    # the backward is not bit-reproducible run to run (fp32 atomics in the split-K wgrads; a flipped bf16 rounding downstream): same bar
+    # as between two data-parallel replicas
+    assert float((outs[0][2] - outs[1][2]).abs().max()) <= 2e-2 * float(outs[0][2].abs().max())
