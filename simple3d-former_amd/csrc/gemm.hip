@@ -491,6 +491,36 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// ---- in-kernel timeline (debug builds only: make TL=1 -> libs3d_hip_tl.so; tools/timeline_probe.py) -------------------------
+// wave 0 / lane 0 of every workgroup stamps s_memtime (shader clock) at the phase boundaries of the DMA forward kernel and
+// s_memrealtime (100 MHz, chip-wide) at entry / exit: where a 10-20 us launch of ~600 workgroups spends its time.
+#ifdef S3D_TIMELINE
+__device__ unsigned long long* g_tl_buf = nullptr;      // [workgroup][TL_SLOTS]
+constexpr int TL_SLOTS = 40;
+#define TL_STAMP(i)                                                                                     \
+    do {                                                                                                \
+        if (g_tl_buf && threadIdx.x == 0 && (i) < TL_SLOTS)                                             \
+            g_tl_buf[(long)(blockIdx.y * gridDim.x + blockIdx.x) * TL_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define TL_REAL(i)                                                                                      \
+    do {                                                                                                \
+        if (g_tl_buf && threadIdx.x == 0)                                                               \
+            g_tl_buf[(long)(blockIdx.y * gridDim.x + blockIdx.x) * TL_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define TL_HWID(i)                                                                                      \
+    do {                                                                                                \
+        if (g_tl_buf && threadIdx.x == 0) {                                                             \
+            unsigned xcc__, hw__;                                                                       \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc__), "=s"(hw__)); \
+            g_tl_buf[(long)(blockIdx.y * gridDim.x + blockIdx.x) * TL_SLOTS + (i)] = ((unsigned long long)xcc__ << 32) | hw__; \
+        }                                                                                               \
+    } while (0)
+#else
+#define TL_STAMP(i) do {} while (0)
+#define TL_REAL(i) do {} while (0)
+#define TL_HWID(i) do {} while (0)
+#endif
+
 template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -548,14 +578,17 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    TL_REAL(0); TL_HWID(1); TL_STAMP(2);
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < ntiles) issue(u);
+    TL_STAMP(3);
     for (int t = 0; t < ntiles; ++t) {
         // stage t is complete once at most the younger stages' pieces of this wave are outstanding
         if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // everyone's pieces landed; buffer (t-1) % NS is free
+        TL_STAMP(8 + t);                                               // tile t landed for the whole workgroup
         if (t + NS - 1 < ntiles) issue(t + NS - 1);
         const unsigned char* sA = smem + (t % NS) * STAGE;
         const unsigned char* sB = sA + NPL * A_BYTES;
@@ -591,6 +624,7 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
     constexpr int LDC = BN + 4, CPR = BN / 8;
     float* ct = reinterpret_cast<float*>(smem);
     __syncthreads();
+    TL_STAMP(4);                                                       // mainloop done
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -604,7 +638,19 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
         ld_f32<8>(v, ct + row * LDC + col);
         epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
     }
+#ifdef S3D_TIMELINE
+    TL_STAMP(5);                                                       // epilogue stores issued (this wave)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(6); TL_REAL(7);                                           // ... and acknowledged
+#endif
 }
+
+#ifdef S3D_TIMELINE
+extern "C" int s3d_debug_timeline_set(void* buf) {
+    unsigned long long* b = reinterpret_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Large backward GEMMs with k-major operands (NN dgrad: B = W [K][N]; TN wgrad: A = dy [K][M] and B = x [K][N]) on the same
