@@ -194,6 +194,12 @@ typedef struct S3dAdamState {
 } S3dAdamState;
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t stream);
+/* Data-parallel gradient wire format (replaces DDP's fp32 bucket all-reduce, train_cls_voxel.py:155-159,287, by half the bytes
+ * on xGMI): s3d_pack_bf16 rounds a finished gradient bucket to bf16 (rne; n % 8 == 0), the bf16 buffer is sum-all-reduced, and
+ * s3d_adam_step_wire takes the gradient from it (g is only zeroed).  The averaging stays in S3dAdamState::grad_scale. */
+int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t stream);
+int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                       S3dAdamState* state, int zero_grad, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ timm Block
  * One pre-norm transformer block: x += attn(norm1(x)); x += mlp(norm2(x))  (timm==0.3.2 Block.forward, invoked by
@@ -340,6 +346,8 @@ typedef struct S3dBnArgs {
     int eval_mode;                        /* fwd: normalise with the running statistics (model.eval()), no update */
     int have_sums;                        /* fwd: `sums` already holds the column sums / sums of squares of x (the producer of x
                                            * accumulated them, e.g. s3d_group_project_fwd): skip the statistics pass */
+    const float* momentum_dev;            /* optional: device-resident momentum (overrides `momentum`), so that a captured HIP graph
+                                           * follows the reference's per-epoch BN-momentum decay (train_partseg.py:126-130) */
 } S3dBnArgs;
 int s3d_batchnorm_fwd(const S3dBnArgs* args, s3d_stream_t stream);
 int s3d_batchnorm_bwd(const S3dBnArgs* args, s3d_stream_t stream);
@@ -353,6 +361,10 @@ int s3d_pack_rows(const float* x, int C, int ldx, long rows, uint16_t* hi, uint1
 int s3d_add_inplace(float* a, const float* b, long n, s3d_stream_t stream);
 int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, float lr, float momentum,
                  float grad_scale, int* step_counter, s3d_stream_t stream);
+/* the same step with {lr, momentum, grad_scale} read from device memory at run time: a captured HIP graph follows the
+ * reference's per-epoch learning-rate decay (train_partseg.py:121-125) without re-capture */
+int s3d_sgd_step_dev(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, const float* hyper,
+                     int* step_counter, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ evaluation + input format
  *   s3d_cls_eval       pred = logits.max(1)[1]; counts[0] += correct, counts[1+c] += correct of class c, counts[1+C+c] += seen of

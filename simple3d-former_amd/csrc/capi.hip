@@ -344,8 +344,14 @@ int s3d_image_patchify(const float* img, uint16_t* a_hi, uint16_t* a_lo, long ld
 }
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t s) {
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, st(s));
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, nullptr, st(s));
 }
+int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                       S3dAdamState* state, int zero_grad, s3d_stream_t s) {
+    S3D_REQUIRE(g_wire != nullptr, "s3d_adam_step_wire: the bf16 gradient buffer is required");
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, st(s));
+}
+int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
 
 int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_block_fwd: null args");
@@ -441,7 +447,12 @@ int s3d_pack_rows(const float* x, int C, int ldx, long rows, uint16_t* hi, uint1
 int s3d_add_inplace(float* a, const float* b, long n, s3d_stream_t s) { return s3d_launch_add_inplace(a, b, n, st(s)); }
 int s3d_sgd_step(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, float lr, float momentum, float grad_scale,
                  int* step_counter, s3d_stream_t s) {
-    return s3d_launch_sgd(p, g, buf, hi, lo, n, lr, momentum, grad_scale, step_counter, st(s));
+    return s3d_launch_sgd(p, g, buf, hi, lo, n, lr, momentum, grad_scale, step_counter, nullptr, st(s));
+}
+int s3d_sgd_step_dev(float* p, float* g, float* buf, uint16_t* hi, uint16_t* lo, long n, const float* hyper, int* step_counter,
+                     s3d_stream_t s) {
+    S3D_REQUIRE(hyper != nullptr, "s3d_sgd_step_dev: hyper = device float[3] {lr, momentum, grad_scale} required");
+    return s3d_launch_sgd(p, g, buf, hi, lo, n, 0.f, 0.f, 1.f, step_counter, hyper, st(s));
 }
 
 int s3d_cls_eval(const float* logits, int ld, const long long* target, long rows, int C, int* pred, long long* counts, s3d_stream_t s) {

@@ -1041,7 +1041,12 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         if (dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0) {
             if (tile == 1) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 2>(a, s);
             if (tile == 0) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2>(a, s);
-            if (tile == 3) return launch_nt_dma_small<SPLIT, EPI, 32, 32, 2>(a, s);
+            if (tile == 3) {
+                static const int ns32 = env_int("S3D_DMA_NS32");            // ring depth of the 32x32 tiles (experiment)
+                if (ns32 == 3) return launch_nt_dma_small<SPLIT, EPI, 32, 32, 3>(a, s);
+                if (ns32 == 4) return launch_nt_dma_small<SPLIT, EPI, 32, 32, 4>(a, s);
+                return launch_nt_dma_small<SPLIT, EPI, 32, 32, 2>(a, s);
+            }
         }
     }
     return launch_tiles<false, false, SPLIT, EPI>(tile, a, 1, s);

@@ -39,7 +39,8 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s);
 // ---- fused Adam over a flat fp32 arena (+ split-bf16 shadow planes) ----
 typedef S3dAdamState AdamState;
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
-                    int zero_grad, hipStream_t s);
+                    int zero_grad, const bf16_t* g_wire, hipStream_t s);
+int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
 
 // ---- point-cloud operators (points.hip) ----
 int s3d_launch_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx,
@@ -61,7 +62,7 @@ int s3d_launch_bcast_rows(const float* x, int N, int C, long rows, float scale, 
 int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, bf16_t* lo, int ldo, hipStream_t s);
 int s3d_launch_add_inplace(float* a, const float* b, long n, hipStream_t s);
 int s3d_launch_sgd(float* p, float* g, float* buf, bf16_t* hi, bf16_t* lo, long n, float lr, float momentum, float grad_scale,
-                   int* step_counter, hipStream_t s);
+                   int* step_counter, const float* hyper, hipStream_t s);
 
 // ---- evaluation metrics + bit-packed voxel input (metrics.hip) ----
 int s3d_launch_cls_eval(const float* logits, int ld, const long long* target, long rows, int C, int* pred, long long* counts, hipStream_t s);

@@ -327,11 +327,19 @@ __global__ void adam_prelude_kernel(AdamState* st) {
 }
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ hi,
-                                                   bf16_t* __restrict__ lo, long n4, const AdamState* st, int zero_grad) {
+                                                   bf16_t* __restrict__ lo, long n4, const AdamState* st, int zero_grad,
+                                                   const bf16_t* __restrict__ gw) {
     const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
     const float step_size = st->step_size, bc2s = st->bc2_sqrt;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<float4*>(g)[i];
+        float4 P = reinterpret_cast<float4*>(p)[i], G;
+        if (gw) {                                       // bf16 wire format: the all-reduced gradient arrives as bf16 (uniform branch)
+            union { uint2 u; bf16_t h[4]; } W;
+            W.u = reinterpret_cast<const uint2*>(gw)[i];
+            G = make_float4(bf2f(W.h[0]), bf2f(W.h[1]), bf2f(W.h[2]), bf2f(W.h[3]));
+        } else {
+            G = reinterpret_cast<float4*>(g)[i];
+        }
         float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gs, G.y * gs, G.z * gs, G.w * gs};
         float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
@@ -448,12 +456,33 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
 }
 
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
-                    int zero_grad, hipStream_t s) {
+                    int zero_grad, const bf16_t* g_wire, hipStream_t s) {
     S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
     hipLaunchKernelGGL(adam_prelude_kernel, dim3(1), dim3(1), 0, s, st);
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire);
     S3D_CHECK_LAUNCH("adam");
+    return 0;
+}
+
+// fp32 -> bf16 (rne), 8 elements per thread: the gradient wire format of the data-parallel trainer
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        U128 o;
+        o.h[0] = f2bf(a[0]); o.h[1] = f2bf(a[1]); o.h[2] = f2bf(a[2]); o.h[3] = f2bf(a[3]);
+        o.h[4] = f2bf(b[0]); o.h[5] = f2bf(b[1]); o.h[6] = f2bf(b[2]); o.h[7] = f2bf(b[3]);
+        reinterpret_cast<u32x4*>(dst)[i] = o.u;
+    }
+}
+int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
+    S3D_REQUIRE(n % 8 == 0 && ((uintptr_t)src & 31) == 0 && ((uintptr_t)dst & 15) == 0,
+                "pack_bf16: n=%ld must be a multiple of 8 and the buffers 32 / 16-byte aligned", n);
+    if (n == 0) return 0;
+    long blocks = (n / 8 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, n / 8);
+    S3D_CHECK_LAUNCH("pack_bf16");
     return 0;
 }

@@ -206,9 +206,10 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 // mean / rstd + running statistics (momentum m, unbiased running variance), nn.BatchNorm semantics
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, long rows, int C, float eps, float momentum,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ run_mean,
-                                   float* __restrict__ run_var) {
+                                   float* __restrict__ run_var, const float* __restrict__ momentum_dev) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (momentum_dev) momentum = *momentum_dev;        // device-resident hyper-parameter: HIP-graph replays see updates
     const double m = sums[c] / rows;
     double var = sums[C + c] / rows - m * m;
     if (var < 0) var = 0;
@@ -730,8 +731,10 @@ __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restric
 }
 // SGD with momentum over a flat arena (+ split-plane refresh, gradient zeroing): torch.optim.SGD(lr, momentum)
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, bf16_t* __restrict__ hi,
-                           bf16_t* __restrict__ lo, long n, float lr, float momentum, float grad_scale, const int* __restrict__ first) {
+                           bf16_t* __restrict__ lo, long n, float lr, float momentum, float grad_scale, const int* __restrict__ first,
+                           const float* __restrict__ hyper) {
     const bool is_first = (*first == 0);
+    if (hyper) { lr = hyper[0]; momentum = hyper[1]; grad_scale = hyper[2]; }      // device-resident (graph-replay safe)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gg = g[i] * grad_scale;
         const float bb = is_first ? gg : momentum * buf[i] + gg;
@@ -850,7 +853,7 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(cblocks), dim3(256), 0, s, a.run_mean, a.run_var, a.C, a.eps, a.mean, a.rstd);
     } else if (a.have_sums) {
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
-                           a.run_mean, a.run_var);
+                           a.run_mean, a.run_var, a.momentum_dev);
     } else {
         (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
         const int per = a.C <= 256 ? 256 / a.C : 1;
@@ -859,7 +862,7 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
-                           a.run_mean, a.run_var);
+                           a.run_mean, a.run_var, a.momentum_dev);
     }
     if (a.K > 0) {
         S3D_REQUIRE(a.rows % a.K == 0 && a.ldx == a.C, "batchnorm(max): rows must be groups*K and x compact");
@@ -939,9 +942,9 @@ int s3d_launch_add_inplace(float* a, const float* b, long n, hipStream_t s) {
     return 0;
 }
 int s3d_launch_sgd(float* p, float* g, float* buf, bf16_t* hi, bf16_t* lo, long n, float lr, float momentum, float grad_scale,
-                   int* step_counter, hipStream_t s) {
+                   int* step_counter, const float* hyper, hipStream_t s) {
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, buf, hi, lo, n, lr, momentum, grad_scale,
-                       step_counter);
+                       step_counter, hyper);
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, s, step_counter);
     S3D_CHECK_LAUNCH("sgd");
     return 0;

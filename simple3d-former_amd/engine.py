@@ -242,6 +242,7 @@ class VoxelEngine:
         self.set_optimizer(lr=lr, betas=betas, eps=eps)
         self._ws = {}
         self._graphs = {}
+        self.capture_epoch = 0              # bumped whenever something baked into captured graphs changes (set_dropout)
         self.world_size = 1
         # group_embed encoder-layer dropout: 0 = eval mode; set_dropout(0.1) = the reference's training mode (hash-based masks)
         self.dropout_p = 0.0
@@ -302,9 +303,26 @@ class VoxelEngine:
             L.check(self.lib.s3d_split_bf16(L.ptr(w), L.ptr(self.conv_hi), L.ptr(self.conv_lo), ctypes.c_long(self.D),
                                             ctypes.c_long(self.Kc), ctypes.c_long(self.Kpad), L.current_stream()), 'split conv')
 
-    def set_optimizer(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, step=None):
-        """torch.optim.Adam hyper-parameters (train_cls_voxel.py:195); lives on the device so graph replays see it."""
-        cur_step = int(self.adam_state[7].item()) if step is None else int(step)
+    def optimizer_state(self):
+        """-> dict(lr, betas, eps, grad_scale, step) currently on the device."""
+        raw = self.adam_state.cpu().numpy()
+        f = raw[:5].view(np.float32)
+        return dict(lr=float(f[0]), betas=(float(f[1]), float(f[2])), eps=float(f[3]), grad_scale=float(f[4]), step=int(raw[7]))
+
+    def set_optimizer(self, lr=None, betas=None, eps=None, grad_scale=None, step=None):
+        """torch.optim.Adam hyper-parameters (train_cls_voxel.py:195); lives on the device so graph replays see it.  Arguments left
+        at None keep their current value -- in particular a data-parallel trainer's grad_scale = 1/world survives a later
+        set_optimizer(lr=...) (gradients stay the MEAN over ranks)."""
+        if getattr(self, '_adam_init', False):
+            cur = self.optimizer_state()
+        else:
+            cur = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0, step=0)
+            self._adam_init = True
+        lr = cur['lr'] if lr is None else lr
+        betas = cur['betas'] if betas is None else betas
+        eps = cur['eps'] if eps is None else eps
+        grad_scale = cur['grad_scale'] if grad_scale is None else grad_scale
+        cur_step = cur['step'] if step is None else int(step)
         st = np.zeros(9, dtype=np.int32)
         st[:7] = np.array([lr, betas[0], betas[1], eps, grad_scale, 0.0, 0.0], dtype=np.float32).view(np.int32)
         st[7] = cur_step
@@ -312,13 +330,25 @@ class VoxelEngine:
 
     def set_dropout(self, p, seed=None):
         """Dropout of nn.TransformerEncoderLayer inside group_embed (vit_3d_2d_pretrain.py:381; p = 0.1 when model.train()).
-        The seed lives on the device and is advanced once per train_step."""
-        self.dropout_p = float(p)
+        The seed lives on the device and is advanced once per training step (advance_dropout_seed).  The probability is a
+        launch argument, i.e. baked into captured graphs: changing it drops this engine's graphs and bumps capture_epoch so that
+        trainers holding their own captures re-capture."""
+        p = float(p)
+        if p != self.dropout_p:
+            self._graphs.clear()
+            self.capture_epoch += 1
+        self.dropout_p = p
         if seed is not None:
             self.dropout_seed.fill_(int(seed))
         for ws in self._ws.values():
             if self.group:
                 ws.enc.shape.dropout_p = self.dropout_p
+
+    def advance_dropout_seed(self):
+        """Fresh dropout masks for the next forward: one device-side increment (graph-replay safe).  Every path that trains calls
+        it once per step -- train_step, the data-parallel trainer's eager step and its captured phase 0."""
+        if self.group and self.dropout_p > 0:
+            self.dropout_seed.add_(1)
 
     def set_lr(self, lr):
         self.adam_state[0:1].copy_(torch.tensor([lr], dtype=torch.float32).view(torch.int32))
@@ -548,12 +578,26 @@ class VoxelEngine:
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'token grads')
 
     # ------------------------------------------------------------------ optimizer
-    def adam_step(self, zero_grad=True):
+    def adam_step(self, zero_grad=True, wire=None):
+        """wire: bf16 tensor of the arena's layout holding the (all-reduced) gradient -- the data-parallel wire format; the
+        fp32 gradient arena is then only zeroed."""
         a = self.arena
-        L.check(self.lib.s3d_adam_step(L.ptr(a.p), L.ptr(a.g), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
-                                       ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
-                                       L.current_stream()), 'adam')
+        if wire is None:
+            L.check(self.lib.s3d_adam_step(L.ptr(a.p), L.ptr(a.g), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
+                                           ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                           L.current_stream()), 'adam')
+        else:
+            assert wire.dtype == torch.bfloat16 and wire.numel() == a.numel and wire.is_cuda
+            L.check(self.lib.s3d_adam_step_wire(L.ptr(a.p), L.ptr(a.g), L.ptr(wire), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
+                                                ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                                L.current_stream()), 'adam (bf16 wire)')
         self._refresh_conv_planes()
+
+    def pack_grads(self, start, end, wire):
+        """gradient arena [start, end) -> bf16 wire buffer [start, end) (round to nearest even), on the current stream."""
+        a = self.arena
+        L.check(self.lib.s3d_pack_bf16(ctypes.c_void_p(a.g.data_ptr() + 4 * start), ctypes.c_void_p(wire.data_ptr() + 2 * start),
+                                       ctypes.c_long(end - start), L.current_stream()), 'pack_bf16')
 
     def zero_grad(self):
         self.arena.g.zero_()
@@ -563,8 +607,7 @@ class VoxelEngine:
         """zero_grad -> model(voxel) -> F.cross_entropy -> backward -> Adam  (train_cls_voxel.py:277-288), all on the
         HIP path.  Gradients are zeroed by the previous step's Adam kernel.  Returns the loss as a device scalar."""
         B = x.shape[0]
-        if self.group and self.dropout_p > 0:
-            self.dropout_seed.add_(1)                     # fresh masks every step (device-side, graph-replay safe)
+        self.advance_dropout_seed()                       # fresh masks every step (device-side, graph-replay safe)
         self.forward(x)
         loss = self.cross_entropy(B, target, weight)
         self.backward(B)

@@ -28,11 +28,14 @@ def shard_indices(n_samples, world_size, rank, seed=0, shuffle=True):
 
 
 class BucketedGradReducer:
-    """Sum-all-reduce of contiguous slices of one flat gradient tensor, launched asynchronously bucket by bucket."""
+    """Sum-all-reduce of contiguous slices of one flat gradient tensor, launched asynchronously bucket by bucket.
+    prepare(start, end), if given, runs on the current stream right before bucket [start, end) is handed to the collective (the
+    bf16 wire format packs the finished fp32 slice into the flat bf16 tensor there)."""
 
-    def __init__(self, flat_grad, slices, group=None, force=False):
+    def __init__(self, flat_grad, slices, group=None, force=False, prepare=None):
         self.flat, self.slices, self.group = flat_grad, list(slices), group
         self.force = force                   # issue the collective even at world size 1 (exercises the RCCL path)
+        self.prepare = prepare
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._works = []
         covered = sorted(self.slices)
@@ -40,9 +43,11 @@ class BucketedGradReducer:
             all(a[1] == b[0] for a, b in zip(covered, covered[1:])), 'buckets must tile the arena exactly'
 
     def launch(self, i):
+        s, e = self.slices[i]
+        if self.prepare is not None:
+            self.prepare(s, e)
         if self.world == 1 and not self.force:
             return
-        s, e = self.slices[i]
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
@@ -59,8 +64,12 @@ def broadcast_parameters(flat_param, src=0, group=None):
 class DataParallelTrainer:
     """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
 
-    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False, graph_collectives=False):
-        """graph_collectives: capture the WHOLE step -- backward segments, the all-reduce of every bucket (RCCL calls are
+    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False, graph_collectives=False,
+                 wire='fp32'):
+        """wire: 'fp32' all-reduces the gradient arena itself (DDP's arithmetic); 'bf16' rounds every finished bucket to bf16
+        (s3d_pack_bf16, on the compute stream right after its backward segment), all-reduces HALF the bytes over xGMI and lets the
+        Adam kernel read the bf16 sum (s3d_adam_step_wire) -- gradient compression as in DDP's bf16_compress_hook.
+        graph_collectives: capture the WHOLE step -- backward segments, the all-reduce of every bucket (RCCL calls are
         capturable: tools/probes/rccl_graph_probe.py), Adam -- into ONE HIP graph instead of one graph per segment with the
         collectives launched from the host in between.  Removes the per-step launch overhead of the segmented mode (measured at
         one rank); opt-in until it has run on a multi-GPU node."""
@@ -71,30 +80,42 @@ class DataParallelTrainer:
         broadcast_parameters(engine.arena.p, 0, group)                 # DDP-constructor broadcast (C2)
         engine.refresh_weight_planes()
         self.segments, self.slices = engine.grad_buckets(n_buckets if (self.world > 1 or force_collectives) else 1)
-        self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives)
-        self._hp = dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
-        engine.set_optimizer(grad_scale=1.0 / self.world, **self._hp)
+        if wire not in ('fp32', 'bf16'):
+            raise ValueError(f"wire must be 'fp32' or 'bf16', not {wire!r}")
+        self.wire = None
+        if wire == 'bf16':
+            self.wire = torch.zeros(engine.arena.g.numel(), dtype=torch.bfloat16, device=engine.arena.g.device)
+            self.reducer = BucketedGradReducer(self.wire, self.slices, group, force=force_collectives,
+                                               prepare=lambda s, e: engine.pack_grads(s, e, self.wire))
+        else:
+            self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives)
+        # keep the lr / betas / eps the engine was built with (the reference's default lr is 0.05, train_cls_voxel.py:373); only the
+        # 1/world averaging is this trainer's business
+        engine.set_optimizer(grad_scale=1.0 / self.world)
+        if self.world > 1:                   # DDP ranks draw different dropout masks (independent RNG streams per process)
+            engine.dropout_seed.add_(1000003 * dist.get_rank(group))
         self.use_graphs = use_graphs
         self._cap = None
 
-    def set_optimizer(self, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        self._hp = dict(lr=lr, betas=betas, eps=eps)
-        self.eng.set_optimizer(grad_scale=1.0 / self.world, **self._hp)
+    def set_optimizer(self, lr=None, betas=None, eps=None):
+        self.eng.set_optimizer(lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.world)
 
     # ---- eager step -------------------------------------------------------------------------------------------
     def step_eager(self, x, y, weight=None):
         eng, B = self.eng, x.shape[0]
+        eng.advance_dropout_seed()
         eng.forward(x)
         loss = eng.cross_entropy(B, y, weight)
         eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
         self.reducer.wait()
-        eng.adam_step(zero_grad=True)
+        eng.adam_step(zero_grad=True, wire=self.wire)
         return loss
 
     # ---- HIP-graph step ---------------------------------------------------------------------------------------
     def _phase(self, k, B, sx, sy, weight):
         eng = self.eng
         if k == 0:
+            eng.advance_dropout_seed()                                  # captured: every replay draws fresh masks
             eng.forward(sx)
             eng.cross_entropy(B, sy, weight)
             ws = eng.backward_begin(B)
@@ -107,14 +128,14 @@ class DataParallelTrainer:
         eng = self.eng
         sx = torch.zeros(B, 1, eng.V, eng.V, eng.V, dtype=torch.float32, device=eng.device)
         sy = torch.zeros(B, dtype=torch.int64, device=eng.device)
-        state = (eng.arena.p, eng.arena.m, eng.arena.v, eng.arena.g, eng.adam_state)
+        state = (eng.arena.p, eng.arena.m, eng.arena.v, eng.arena.g, eng.adam_state, eng.dropout_seed)
         snap = [t.clone() for t in state]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                                   # warm-up: kernel attributes, workspaces
             for k in range(len(self.segments)):
                 self._phase(k, B, sx, sy, weight)
-            eng.adam_step(zero_grad=True)
+            eng.adam_step(zero_grad=True, wire=self.wire)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for t, sv in zip(state, snap):
@@ -131,8 +152,8 @@ class DataParallelTrainer:
                     self._phase(k, B, sx, sy, weight)
                     self.reducer.launch(k)                              # a side branch of the graph: overlaps the next segment
                 self.reducer.wait()
-                eng.adam_step(zero_grad=True)
-            self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss)
+                eng.adam_step(zero_grad=True, wire=self.wire)
+            self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
             return self._cap
         graphs = []
         for k in range(len(self.segments)):
@@ -142,13 +163,15 @@ class DataParallelTrainer:
             graphs.append(g)
         g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_opt):
-            eng.adam_step(zero_grad=True)
-        self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss)
+            eng.adam_step(zero_grad=True, wire=self.wire)
+        self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
         return self._cap
 
     def step_graph(self):
         """Replays the captured step on the static buffers (cap['x'], cap['y'] must already hold the batch)."""
         cap = self._cap
+        if cap['epoch'] != self.eng.capture_epoch:
+            raise RuntimeError('the captured step is stale (set_dropout changed a value baked into the graphs): capture() again')
         if 'whole' in cap:
             cap['whole'].replay()
             return cap['loss'][0]
@@ -162,7 +185,7 @@ class DataParallelTrainer:
     def step(self, x, y, weight=None):
         if not self.use_graphs:
             return self.step_eager(x, y, weight)
-        if self._cap is None or self._cap['B'] != x.shape[0]:
+        if self._cap is None or self._cap['B'] != x.shape[0] or self._cap['epoch'] != self.eng.capture_epoch:
             self.capture(x.shape[0], weight)
         self._cap['x'].copy_(x, non_blocking=True)
         self._cap['y'].copy_(y, non_blocking=True)
@@ -220,20 +243,14 @@ class PointDataParallelTrainer:
     def capture(self, x, y, starts):
         """Captures the three graphs over the given static buffers (copy new batches / FPS starts into them, then step_graph())."""
         eng, B = self.eng, x.shape[0]
-        state = [eng.arena.p, eng.arena.g, eng.buf, eng.sgd_steps] + eng.bn_buffers()
-        snap = [t.clone() for t in state]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                                   # warm-up: kernel attributes, workspaces
-            for fn in self._halves(B, x, y, starts):
-                fn()
-            eng.sgd_step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        for t, sv in zip(state, snap):
-            t.copy_(sv)
-        eng.refresh_weight_planes()
-        torch.cuda.synchronize()
+        with eng._preserved_state():                                    # parameters, momentum, step flag, BN statistics restored
+            with torch.cuda.stream(side):                               # warm-up: kernel attributes, workspaces
+                for fn in self._halves(B, x, y, starts):
+                    fn()
+                eng.sgd_step()
+            torch.cuda.current_stream().wait_stream(side)
         graphs = []
         for fn in self._halves(B, x, y, starts):
             g = torch.cuda.CUDAGraph()

@@ -208,6 +208,7 @@ class _BatchNorm:
     def _args(self, x, rows, K=0, **kw):
         a = self.eng.arena
         return L.fill(L.S3dBnArgs(), x=x, ldx=self.C, rows=rows, C=self.C, K=K, eps=BN_EPS, momentum=self.eng.bn_momentum,
+                      momentum_dev=self.eng.hyper[3:4],
                       gamma=a.param(self.key + '.weight'), beta=a.param(self.key + '.bias'), mean=self.mean, rstd=self.rstd,
                       run_mean=self.run_mean, run_var=self.run_var, sums=self.sums, eval_mode=0 if self.eng.training else 1, **kw)
 
@@ -248,15 +249,18 @@ class PointEngine:
         self.Nin = ([n_points] + self.S)[:self.levels]          # points entering td i
         assert all(n >= KNN for n in self.Nin), f'every TransitionDown needs >= {KNN} input points'
         self.cin = [c // 2 + 3 for c in self.ch]
-        self.split, self.bn_momentum = bool(split), bn_momentum
-        self.lr, self.momentum = lr, momentum
+        self.split = bool(split)
+        # {lr, momentum, grad_scale, BatchNorm momentum} live on the DEVICE and the kernels read them at run time, so a captured HIP
+        # graph follows the reference's per-epoch schedules (lr decay train_partseg.py:121-125, bn_momentum_adjust :126-130) and a
+        # data-parallel trainer's 1/world without re-capture.  The attributes below are views of that block.
+        self._hyper_host = [float(lr), float(momentum), 1.0, float(bn_momentum)]
+        self.hyper = torch.tensor(self._hyper_host, dtype=torch.float32, device=self.device)
         self.training = True                # BatchNorm mode: batch statistics (model.train()) vs running statistics
         self.shapes = point_param_shapes(backbone, n_classes, d_points, variant)
         self.arena = ParamArena(self.shapes, self.device)
         self.buf = torch.zeros_like(self.arena.p)                   # SGD momentum buffer
         self.sgd_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.world_size = 1
-        self.grad_scale = 1.0
         a = self.arena
         # layers
         self.fc1 = [_Linear(self, 'fc1.0'), _Linear(self, 'fc1.2')]
@@ -300,7 +304,47 @@ class PointEngine:
             from .image_branch import ImageBranch
             self.images = ImageBranch(self)
 
+    # ------------------------------------------------------------------ hyper-parameters (device-resident)
+    def _set_hyper(self, i, v):
+        v = float(v)
+        if self._hyper_host[i] != v:
+            self._hyper_host[i] = v
+            self.hyper[i:i + 1].fill_(v)                 # stream-ordered: later launches AND graph replays see it
+
+    lr = property(lambda self: self._hyper_host[0], lambda self, v: self._set_hyper(0, v))
+    momentum = property(lambda self: self._hyper_host[1], lambda self, v: self._set_hyper(1, v))
+    grad_scale = property(lambda self: self._hyper_host[2], lambda self, v: self._set_hyper(2, v))
+    bn_momentum = property(lambda self: self._hyper_host[3], lambda self, v: self._set_hyper(3, v))
+
+    def set_lr(self, lr):
+        """Per-epoch learning-rate decay of the point trainers (train_partseg.py:121-125); takes effect on captured graphs too."""
+        self.lr = lr
+
+    def set_bn_momentum(self, m):
+        """classifier.apply(bn_momentum_adjust) (train_partseg.py:126-130); takes effect on captured graphs too."""
+        self.bn_momentum = m
+
     # ------------------------------------------------------------------ parameters / buffers
+    def train_state(self):
+        """Every tensor a training step mutates (parameters, gradients, momentum buffer, step flag, BatchNorm running statistics):
+        what a capture warm-up has to snapshot and restore."""
+        return [self.arena.p, self.arena.g, self.buf, self.sgd_steps] + self.bn_buffers()
+
+    @contextlib.contextmanager
+    def _preserved_state(self):
+        """Warm-up steps of a graph capture run on whatever the static buffers hold: restore the training state afterwards so that
+        capturing mid-training applies no spurious update (as VoxelEngine.capture_train_step does)."""
+        state = self.train_state()
+        snap = [t.clone() for t in state]
+        try:
+            yield
+        finally:
+            torch.cuda.synchronize()
+            for t, sv in zip(state, snap):
+                t.copy_(sv)
+            self.refresh_weight_planes()
+            torch.cuda.synchronize()
+
     def load_state_dict(self, sd):
         self.arena.load(sd)
         for k, bn in self.bns.items():
@@ -691,9 +735,8 @@ class PointEngine:
     def sgd_step(self):
         """torch.optim.SGD(lr=0.01, momentum=0.9) (train_cls.py:91) + weight-plane refresh + gradient zeroing."""
         a = self.arena
-        L.check(self.lib.s3d_sgd_step(L.ptr(a.p), L.ptr(a.g), L.ptr(self.buf), L.ptr(a.hi), L.ptr(a.lo), ctypes.c_long(a.numel),
-                                      ctypes.c_float(self.lr), ctypes.c_float(self.momentum), ctypes.c_float(self.grad_scale),
-                                      L.ptr(self.sgd_steps), L.current_stream()), 'sgd')
+        L.check(self.lib.s3d_sgd_step_dev(L.ptr(a.p), L.ptr(a.g), L.ptr(self.buf), L.ptr(a.hi), L.ptr(a.lo), ctypes.c_long(a.numel),
+                                          L.ptr(self.hyper), L.ptr(self.sgd_steps), L.current_stream()), 'sgd')
         for l in self._linears:
             l.refresh()
 
@@ -745,12 +788,12 @@ class PointEngine:
         write the NEXT batch into buffers 1-p, graphs[p].replay(), p ^= 1.  Returns (graphs, loss scalar tensor)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                # warm-up: kernel attributes, workspaces, both geometry sets
-            self.prepare_geometry(xs[0], starts[0], 0)
-            for p in (0, 1):
-                self.train_step_pipelined(xs[p], ys[p], starts[p], xs[1 - p], starts[1 - p], p)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        with self._preserved_state():
+            with torch.cuda.stream(side):            # warm-up: kernel attributes, workspaces, both geometry sets
+                self.prepare_geometry(xs[0], starts[0], 0)
+                for p in (0, 1):
+                    self.train_step_pipelined(xs[p], ys[p], starts[p], xs[1 - p], starts[1 - p], p)
+            torch.cuda.current_stream().wait_stream(side)
         graphs = []
         for p in (0, 1):
             g = torch.cuda.CUDAGraph()
@@ -783,10 +826,10 @@ class PointEngine:
         into x / target / starts, then graph.replay().  Returns (graph, loss scalar tensor)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                # warm-up on a side stream: kernel attributes, workspaces
-            self.train_step(x, target, starts)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        with self._preserved_state():
+            with torch.cuda.stream(side):            # warm-up on a side stream: kernel attributes, workspaces
+                self.train_step(x, target, starts)
+            torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = self.train_step(x, target, starts)

@@ -101,8 +101,11 @@ class _PointForward(torch.autograd.Function):
             ws.dlogits.zero_()
             ws.dlogits.view(ctx.batch, eng.N, -1)[..., :eng.ncls].copy_(dlogits)
         eng.backward(ctx.batch)
-        two = eng.images is not None      # a second node (forward_images) reuses the arena before autograd has accumulated -> copy
-        grads = [None if not need or (two and k.startswith(_IMAGE_ONLY)) else (eng.arena.grad(k).clone() if two else eng.arena.grad(k))
+        # always COPIES of the arena slices: autograd keeps ("steals") the returned tensors as param.grad, and a view of the arena
+        # would be wiped by the next backward's eng.zero_grad() under gradient accumulation / zero_grad(set_to_none=False), or
+        # added to itself by AccumulateGrad; a second node (forward_images) also reuses the arena before autograd has accumulated
+        two = eng.images is not None
+        grads = [None if not need or (two and k.startswith(_IMAGE_ONLY)) else eng.arena.grad(k).clone()
                  for k, need in zip(eng.shapes, ctx.needs_input_grad[3:])]
         return (None, None, None) + tuple(grads)
 

@@ -133,6 +133,9 @@ _IMAGE_ONLY = ('patch_embed.', 'pos_embed', 'head.')                            
 _VOXEL_ONLY = ('voxel_embed.', 'voxel_pos_embed', 'voxel_head.', 'group_')            # not in the graph of forward_images
 
 
+GROUP_EMBED_DROPOUT = 0.1        # nn.TransformerEncoderLayer's default, which vit_3d_2d_pretrain.py:381 does not override
+
+
 class _VoxelForward(torch.autograd.Function):
     """model(voxel) as one autograd node: forward/backward of the entire path run on the HIP engine."""
 
@@ -269,6 +272,12 @@ class Feature3D_ViT2D_V2(VisionTransformer):
             raise RuntimeError('Feature3D_ViT2D_V2 runs on the HIP engine: move the model and the voxel batch to the '
                                'MI355X (no CPU fallback; the CPU reference lives in oracle/)')
         eng = self.s3d_engine(x.device)
+        if eng.group:
+            # nn.TransformerEncoderLayer(dropout=0.1) inside group_embed (vit_3d_2d_pretrain.py:381): active under model.train(),
+            # identity under model.eval(); every training forward draws fresh masks
+            eng.set_dropout(GROUP_EMBED_DROPOUT if self.training else 0.0)
+            if self.training:
+                eng.advance_dropout_seed()
         own = dict(self.named_parameters())
         return _VoxelForward.apply(self, x, *[own[k] for k in eng.shapes])
 

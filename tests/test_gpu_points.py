@@ -483,18 +483,44 @@ def test_pipelined_steps_equal_plain_steps():
     eng2 = PointEngine(task='seg', device=DEV, **kw); eng2.load_state_dict(sd)
     xs = [batches[0][0].clone(), batches[1][0].clone()]; ys = [batches[0][1].clone(), batches[1][1].clone()]
     sts = [tuple(t.clone() for t in batches[0][2]), tuple(t.clone() for t in batches[1][2])]
-    snap = (eng2.arena.p.clone(), eng2.buf.clone(), eng2.sgd_steps.clone(), [b.clone() for b in eng2.bn_buffers()])
+    snap = [t.clone() for t in eng2.train_state()]
     graphs, loss = eng2.capture_train_step_pipelined(xs, ys, sts)
-    eng2.arena.p.copy_(snap[0]); eng2.buf.copy_(snap[1]); eng2.sgd_steps.copy_(snap[2]); eng2.arena.g.zero_()
-    for b, v in zip(eng2.bn_buffers(), snap[3]):
-        b.copy_(v)
-    eng2.refresh_weight_planes()
+    # the capture's warm-up steps must leave no trace: parameters, momentum buffer, step flag, BatchNorm running statistics
+    assert all(torch.equal(a, b) for a, b in zip(eng2.train_state(), snap)), 'capture warm-up leaked into the training state'
     eng2.prepare_geometry(xs[0], sts[0], 0)
     got2 = []
     for i in range(4):
         graphs[i % 2].replay()
         got2.append(float(loss))
     assert max(abs(a - b) for a, b in zip(want, got2)) <= 2e-3, (want, got2)
+
+
+def test_captured_graph_follows_lr_and_bn_momentum_schedules():
+    """train_partseg.py:121-130 decays the learning rate and the BatchNorm momentum every epoch; both live in device memory
+    (PointEngine.hyper), so a graph captured once keeps following them -- and capturing mid-training applies no update."""
+    kw = dict(backbone='deit_tiny_patch16_224', d_points=6, n_classes=5)
+    sd = po.init_state_dict(seed=3, **kw)
+    eng = PointEngine(task='cls', device=DEV, n_points=64, **kw); eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 64, 6, generator=g).to(DEV); y = torch.randint(0, 5, (2,), generator=g).to(DEV)
+    sts = tuple(torch.randint(0, n, (2,), generator=g).to(DEV) for n in (64, 64))
+    before = [t.clone() for t in eng.train_state()]
+    graph, loss = eng.capture_train_step(x, y, sts)
+    assert all(torch.equal(a, b) for a, b in zip(eng.train_state(), before)), 'capture warm-up leaked into the training state'
+    eng.set_lr(0.0)                                   # lr = 0: a replay must leave the parameters alone
+    p0 = eng.arena.p.clone()
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(eng.arena.p, p0)
+    rm0 = eng.bn_buffers()[0].clone()
+    eng.set_bn_momentum(0.0)                          # momentum = 0: running statistics frozen
+    graph.replay(); torch.cuda.synchronize()
+    rm1 = eng.bn_buffers()[0].clone()
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(eng.bn_buffers()[0], rm1)
+    eng.set_lr(0.01); eng.set_bn_momentum(0.1)
+    graph.replay(); torch.cuda.synchronize()
+    assert not torch.equal(eng.arena.p, p0) and not torch.equal(eng.bn_buffers()[0], rm1)
+    assert eng.lr == 0.01 and eng.bn_momentum == 0.1 and eng.grad_scale == 1.0
 
 
 @pytest.mark.parametrize('B,N,C', [(3, 64, 48), (128, 1024, 48), (2, 100, 192), (2, 50, 320)])

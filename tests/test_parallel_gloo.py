@@ -35,14 +35,24 @@ class FakeEngine:
         self.arena = _Arena(depth, width, seed)
         self.grad_scale, self.lr = 1.0, 0.1
         self.launch_log = []
+        self.dropout_seed = torch.zeros(1, dtype=torch.int64)
 
     def W(self, i, flat=None):
         flat = self.arena.p if flat is None else flat
         o = self.arena.offsets[f'blocks.{i}.norm1.weight']
         return flat[o:o + self.width ** 2].view(self.width, self.width)
 
+    capture_epoch = 0
+
     def refresh_weight_planes(self): pass
-    def set_optimizer(self, lr=1e-3, betas=None, eps=None, grad_scale=1.0): self.grad_scale = grad_scale
+    def advance_dropout_seed(self): self.dropout_seed += 1
+
+    def set_optimizer(self, lr=None, betas=None, eps=None, grad_scale=None):
+        if lr is not None: self.lr = lr
+        if grad_scale is not None: self.grad_scale = grad_scale
+
+    def pack_grads(self, start, end, wire):                     # s3d_pack_bf16: round-to-nearest-even, as torch's cast
+        wire[start:end] = self.arena.g[start:end].to(torch.bfloat16)
 
     def grad_buckets(self, n):
         from simple3d_former_amd.engine import VoxelEngine
@@ -68,8 +78,9 @@ class FakeEngine:
             if on_segment:
                 on_segment(si)
 
-    def adam_step(self, zero_grad=True):                        # plain SGD is enough to test the DP protocol
-        self.arena.p.add_(self.arena.g, alpha=-self.lr * self.grad_scale)
+    def adam_step(self, zero_grad=True, wire=None):             # plain SGD is enough to test the DP protocol
+        g = self.arena.g if wire is None else wire.float()      # s3d_adam_step_wire: the update reads the bf16 sum
+        self.arena.p.add_(g, alpha=-self.lr * self.grad_scale)
         if zero_grad:
             self.arena.g.zero_()
 
@@ -78,15 +89,19 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wire='fp32'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         torch.manual_seed(100)
         X = torch.randn(8, 8); Y = torch.randn(8, 8)            # global batch, identical on every rank
         eng = FakeEngine(seed=rank)                              # DIFFERENT initial params per rank -> broadcast must fix it
-        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=False)
-        assert tr.world == world and len(tr.slices) == 3
+        eng.lr = 0.05                                            # the trainer must keep the engine's own hyper-parameters
+        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=False, wire=wire)
+        assert tr.world == world and len(tr.slices) == 3 and eng.lr == 0.05 and eng.grad_scale == 0.5
+        tr.set_optimizer(lr=0.1)                                 # ... and a later lr change must not reset 1/world
+        assert eng.lr == 0.1 and eng.grad_scale == 0.5
+        assert int(eng.dropout_seed) == 1000003 * rank           # per-rank dropout streams
         sl = slice(rank * 4, rank * 4 + 4)                       # contiguous half of the global batch
         for _ in range(3):
             tr.step_eager(X[sl], Y[sl])
@@ -94,6 +109,7 @@ def _worker(rank, world, port, q):
         flat = torch.full((10,), float(rank + 1))
         red = BucketedGradReducer(flat, [(6, 10), (0, 6)])
         red.launch(0); red.launch(1); red.wait()
+        assert int(eng.dropout_seed) == 1000003 * rank + 3       # advanced once per step
         q.put((rank, eng.arena.p.clone(), flat.clone(), tr.segments, tr.slices))
     finally:
         dist.destroy_process_group()
@@ -123,6 +139,35 @@ def test_two_rank_data_parallel_equals_single_process_full_batch():
     assert torch.equal(res[0][2], torch.full((10,), 3.0))       # 1 + 2 summed over both buckets
     assert res[0][3] == [(5, 3), (2, 1), (0, 0)]                 # backward order, 3 buckets shrinking towards the input
     assert res[0][4] == [(192, 384), (64, 192), (0, 64)]         # contiguous arena slices tiling [0, numel)
+
+
+def test_two_rank_bf16_wire_format_stays_within_the_rounding_bound():
+    """wire='bf16': every bucket is rounded to bf16, summed over the ranks in bf16, and the update reads that sum.  Replicas must
+    stay bitwise equal, and the parameters must track the fp32 single-process run within the bf16 rounding of the gradients
+    (|delta p| <= lr * steps * 2^-8 * max|g| with two roundings per element: the pack and the bf16 sum)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, 'bf16')) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    ref = FakeEngine(seed=0)
+    segs, _ = ref.grad_buckets(1)
+    gmax = 0.0
+    for _ in range(3):
+        ref.forward(X); ref.cross_entropy(8, Y); ref.backward(8, segments=segs)
+        gmax = max(gmax, float(ref.arena.g.abs().max()))
+        ref.adam_step()
+    p0, p1 = res[0][1], res[1][1]
+    assert torch.equal(p0, p1), 'replicas diverged'
+    err = float((p0 - ref.arena.p).abs().max())
+    assert 0 < err <= 0.1 * 3 * 2 ** -8 * gmax * 1.5, (err, gmax)      # differs (it IS rounded), but only by the rounding
 
 
 class FakePointEngine(FakeEngine):

@@ -36,7 +36,6 @@ def run(name, N, K, epi, tile, cold):
     buf = torch.zeros(nwg, SLOTS, dtype=torch.int64, device=DEV)
     junk = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=DEV)
     lib = L.lib()
-    os.environ['S3D_GEMM_NT_TILE'] = str(tile)
 
     def f():
         ops.gemm(0, 0, 1, epi, A_hi=ah, A_lo=al, lda=K, B_hi=bh, B_lo=bl, ldb=K, M=M, N=N, K=K, bias=bias, R=R, ldr=N,
@@ -96,6 +95,7 @@ if __name__ == '__main__':
     for name, N, K, epi in shapes:
         if only and name not in only.split(','):
             continue
-        for tile in (3, 0, 1):
-            for cold in (True, False):
-                run(name, N, K, epi, tile, cold)
+        # the library reads S3D_GEMM_NT_TILE once per process: one tile choice per run (0 = 32x64, 1 = 64x64, 3 = 32x32)
+        tile = int(os.environ.get('S3D_GEMM_NT_TILE', {'qkv': 1, 'proj': 3, 'fc1': 0, 'fc2': 3}[name]))
+        for cold in (True, False):
+            run(name, N, K, epi, tile, cold)
