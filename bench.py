@@ -1,17 +1,24 @@
 #!/usr/bin/env python
-"""Headline benchmark: voxel-grids/s of the full training step (zero_grad -> forward -> cross-entropy -> backward ->
-gradient all-reduce -> Adam) on BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed (32^3 grid, cell 6,
-patch 5, 40 classes), batch 64 per GPU, synthetic 10 %-occupancy grids, random-init weights (reference init).
+"""Benchmarks of the full training step on synthetic inputs, one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2|cfg3|cfg4|cfg5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W)
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (the MFMA GEMM instantiation with the largest total time), algorithmic 2*M*N*K flops per
-                launch / its average launch duration measured with HIP events on the launch stream in an instrumented
-                eager pass of the same steps, against the 2.5 PFLOP/s dense bf16 MFMA peak
-  cpu_baseline  the CPU oracle's full training step (PyTorch fp32 restatement of the reference, same batch) timed on the
-                host cores of this box, rank 0 at N=1 only, bounded to ~10-20 s
+  cfg2 (default, the headline)  BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed (32^3 grid, cell 6, patch 5, 40 classes),
+                                batch 64 per GPU: zero_grad -> forward -> cross-entropy -> backward -> gradient all-reduce -> Adam
+  cfg3                          configs[2]: deit_base (3 heads) + VoxelEmbed_no_average 128^3 + group_embed (dropout 0.1), batch 64
+  cfg4 / cfg5                   configs[3] / [4]: PointTransformerCls (1024 pts, batch 128) / PointTransformerSeg (2048 pts, batch 32):
+                                FPS / kNN geometry -> forward -> CE -> backward -> all-reduce -> SGD(momentum); clouds/s (+ seg-pts/s)
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      voxel configs: the dominant MFMA GEMM instantiation, algorithmic 2*M*N*K flops per launch / its average launch
+                duration (difference timing inside the replayed HIP graph + HIP events on the launch stream), vs 2.5 PFLOP/s;
+                point configs: the dominant HBM-bound operator (BatchNorm / neighbourhood gather), algorithmic bytes / its launch
+                duration (HIP events on the launch stream) vs 8 TB/s, with the dominant GEMM nested under "mfma"
+  cpu_baseline  the CPU oracle's full training step timed on this box's host cores, rank 0 at N = 1 only, bounded to ~15-30 s
+                (cfg3 / cfg4 / cfg5: at a reduced batch, stated in "sample")
+  N > 1         rccl_ranks / distinct_devices (the process group spans N GPUs), allreduce_ms[] per gradient bucket, the step time
+                with the collectives suppressed and overlap_frac
 """
 import argparse
 import json
@@ -31,13 +38,27 @@ CONFIGS = {
                  metric='voxels/sec (train, whole node) deit_small VoxelEmbed 32^3 b64',
                  workload='BASELINE.json configs[1]: deit_small_patch16_224 + VoxelEmbed(voxel 32, cell 6, patch 5), 40 classes, '
                           'full train step incl. Adam'),
-    # BASELINE.json configs[2] (secondary; eval-mode dropout in the group encoder layer)
+    # BASELINE.json configs[2] (secondary; the group encoder layer trains with dropout 0.1 as the reference's
+    # nn.TransformerEncoderLayer does under model.train(), vit_3d_2d_pretrain.py:381)
     'cfg3': dict(cfg=dict(backbone='deit_base_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=128, cell=9,
-                          patch=14, n_classes=55), pos_embedding='group_embed', batch=64, train_flops=2.0e12,
+                          patch=14, n_classes=55), pos_embedding='group_embed', batch=64, train_flops=2.0e12, dropout=0.1,
+                 cpu_batch=1,
                  metric='voxels/sec (train, whole node) deit_base(H=3) VoxelEmbed_no_average 128^3 group_embed b64',
                  workload='BASELINE.json configs[2]: deit_base_patch16_224 (3 heads) + VoxelEmbed_no_average(voxel 128, cell 9, '
-                          'patch 14) + group_embed, 55 classes, full train step incl. Adam'),
+                          'patch 14) + group_embed (training-mode dropout 0.1), 55 classes, full train step incl. Adam'),
 }
+# BASELINE.json configs[3] / configs[4]: the point path (models/3DViT; train_cls.py:69-119, train_partseg.py:74-150)
+POINT_CONFIGS = {
+    'cfg4': dict(task='cls', n_points=1024, d_points=6, n_classes=40, batch=128, cpu_batch=8, fwd_flops=4.3e9,
+                 metric='clouds/sec (train, whole node) PointTransformerCls deit_tiny 1024 pts b128',
+                 workload='BASELINE.json configs[3]: ModelNet40 point-cloud cls, models/3DViT PointTransformerCls (deit_tiny), '
+                          '1024 points x 6 channels, 40 classes, full train step incl. SGD(momentum)'),
+    'cfg5': dict(task='seg', n_points=2048, d_points=22, n_classes=50, batch=32, cpu_batch=2, fwd_flops=9.8e9,
+                 metric='clouds/sec (train, whole node) PointTransformerSeg deit_tiny 2048 pts b32 (+ seg-pts/sec)',
+                 workload='BASELINE.json configs[4]: ShapeNetPart part-seg, models/3DViT PointTransformerSeg (deit_tiny), '
+                          '2048 points x 22 channels (6 + one-hot 16), 50 parts, per-point head, full train step incl. SGD(momentum)'),
+}
+HBM_PEAK_GBPS = 8000.0                  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 CFG = CONFIGS['cfg2']['cfg']
 BATCH_PER_GPU = 64
 TRAIN_FLOPS_PER_SAMPLE = 3.39e9          # BASELINE.md section 2 (fwd 1.137 G, train = 3x fwd - tokenizer dgrad)
@@ -98,14 +119,19 @@ def pmc_traffic(key):
         return None, None
 
 
-def cpu_baseline(x, y, budget_s=15.0):
+def cpu_baseline(x, y, budget_s=15.0, pos_embedding='default', dropout=0.0, full_batch=None):
     """The oracle's training step (forward + CE + autograd backward + Adam on every used parameter) on host cores."""
     from oracle import voxel_oracle as vo
-    sd = vo.init_state_dict(seed=9, voxel_size=CFG['voxel_size'], **{k: CFG[k] for k in ('backbone', 'embed_layer', 'cell', 'patch', 'n_classes')})
-    names = vo.used_param_names(sd)
+    sd = vo.init_state_dict(seed=9, voxel_size=CFG['voxel_size'], pos_embedding=pos_embedding,
+                            **{k: CFG[k] for k in ('backbone', 'embed_layer', 'cell', 'patch', 'n_classes')})
+    names = vo.used_param_names(sd, pos_embedding)
     m = {k: torch.zeros_like(sd[k]) for k in names}
     v = {k: torch.zeros_like(sd[k]) for k in names}
     kw = dict(backbone=CFG['backbone'], embed_layer=CFG['embed_layer'], cell=CFG['cell'], patch=CFG['patch'])
+    if pos_embedding != 'default':
+        kw.update(pos_embedding=pos_embedding)
+        if dropout > 0:
+            kw.update(training=True, dropout_p=dropout, hash_seed=1)
     threads = torch.get_num_threads()
 
     def one(step):
@@ -114,18 +140,302 @@ def cpu_baseline(x, y, budget_s=15.0):
             vo.adam_step(sd[k], g, m[k], v[k], step)
         return float(loss)
 
-    one(1)                                                     # warm-up
+    t0 = time.perf_counter()
+    one(1)                                                     # warm-up (counted only if it already exhausts the budget)
+    warm = time.perf_counter() - t0
     t0 = time.perf_counter()
     n = 0
-    while True:
+    while warm < budget_s:
         one(n + 2)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 50:
             break
-    return dict(value=round(n * x.shape[0] / el, 2), unit='voxels/sec', cores=threads, kind='port',
-                sample=f'{n} full training steps (fwd+bwd+Adam) of the fp32 PyTorch-CPU oracle at batch {x.shape[0]}, '
+    if n == 0:
+        n, el = 1, warm
+    reduced = f' (REDUCED batch: the benchmark runs {full_batch} per GPU)' if full_batch and full_batch != x.shape[0] else ''
+    return dict(value=round(n * x.shape[0] / el, 3), unit='voxels/sec', cores=threads, kind='port',
+                sample=f'{n} full training steps (fwd+bwd+Adam) of the fp32 PyTorch-CPU oracle at batch {x.shape[0]}{reduced}, '
                        f'{threads} threads, {el:.1f} s')
+
+
+def timed(fn, reps, dev_sync=True):
+    """Average milliseconds of fn() over reps launches, HIP events on torch's current stream (= the library's launch stream)."""
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def rccl_identity(dev, world):
+    """Proof that the collective spans `world` distinct devices: every rank contributes (device index, device uuid / bus id)."""
+    import torch.distributed as dist
+    props = torch.cuda.get_device_properties(dev)
+    ident = f'{getattr(props, "uuid", "")}|{getattr(props, "pci_bus_id", "")}|{getattr(props, "pci_device_id", "")}|idx{dev.index}'
+    if world == 1 or not dist.is_initialized():
+        return dict(rccl_ranks=1, distinct_devices=1, backend=dist.get_backend() if dist.is_initialized() else None)
+    got = [None] * world
+    dist.all_gather_object(got, ident)
+    return dict(rccl_ranks=dist.get_world_size(), distinct_devices=len(set(got)), backend=dist.get_backend())
+
+
+def collective_diagnostics(trainer, step, step_ms, world, force, reps=10):
+    """Per-bucket all-reduce wall time in isolation (events around the collective on the compute stream, ranks aligned by a barrier),
+    the step time with the collectives suppressed, and from the two the fraction of the wire time that hid behind backward."""
+    import torch.distributed as dist
+    if not (world > 1 or force):
+        return {}
+    red = trainer.reducer
+    ar_ms = []
+    for (s0, e0) in red.slices:
+        buf = red.flat[s0:e0]
+        keep = buf.clone()
+
+        def one():
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=red.group)
+        if world > 1:
+            dist.barrier()
+        ar_ms.append(round(timed(one, reps), 4))
+        buf.copy_(keep)
+    red.skip = True
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    n = 30
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    t_skip = (time.perf_counter() - t0) / n * 1e3
+    red.skip = False
+    t = torch.tensor([t_skip], dtype=torch.float64, device=red.flat.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_skip = float(t.item())
+    total = sum(ar_ms)
+    exposed = max(0.0, step_ms - t_skip)
+    return dict(allreduce_ms=ar_ms, allreduce_bytes=[(e - s) * red.flat.element_size() for s, e in red.slices],
+                allreduce_busbw_GBps=[round(2 * (world - 1) / max(world, 1) * (e - s) * red.flat.element_size() / (ms * 1e-3) / 1e9, 1)
+                                      if ms > 0 else None for (s, e), ms in zip(red.slices, ar_ms)],
+                ms_per_step_without_collectives=round(t_skip, 4), exposed_comm_ms=round(exposed, 4),
+                overlap_frac=round(1.0 - min(1.0, exposed / total), 4) if total > 0 else None,
+                note='allreduce_ms: each bucket alone on an otherwise idle GPU; overlap_frac = 1 - (step - step without collectives) / '
+                     'sum(allreduce_ms)')
+
+
+def point_cpu_baseline(c, backbone, budget_s=15.0):
+    """The point oracle's training step (forward incl. FPS / kNN, CE, autograd backward, SGD+momentum) on host cores, reduced batch."""
+    from oracle import point_oracle as po
+    B = c['cpu_batch']
+    sd = po.init_state_dict(backbone=backbone, n_classes=c['n_classes'], d_points=c['d_points'], seed=9)
+    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9)
+    names = po.used_param_names(sd)
+    buf = {k: torch.zeros_like(sd[k]) for k in names}
+    threads = torch.get_num_threads()
+
+    def one(first):
+        _, loss, grads, _ = po.loss_and_grads(sd, x, y, backbone=backbone, starts=starts, task=c['task'])
+        for k, g in grads.items():
+            po.sgd_momentum_step(sd[k], g, buf[k], first=first)
+        return float(loss)
+
+    t0 = time.perf_counter()
+    one(True)
+    warm = time.perf_counter() - t0
+    t0, n, el = time.perf_counter(), 0, warm
+    while warm < budget_s:
+        one(False)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    if n == 0:
+        n, el = 1, warm
+    return dict(value=round(n * B / el, 3), unit='clouds/sec', cores=threads, kind='port',
+                sample=f'{n} full training steps (FPS/kNN + fwd + bwd + SGD) of the fp32 PyTorch-CPU oracle at batch {B} (REDUCED: the '
+                       f'benchmark runs {c["batch"]} per GPU), {threads} threads, {el:.1f} s')
+
+
+def main_points(args):
+    """BASELINE.json configs[3] / configs[4]: one step = FPS/kNN geometry + forward + CE + backward + (all-reduce) + SGD(momentum)."""
+    import ctypes
+    import torch.distributed as dist
+    import simple3d_former_amd as s3d                           # noqa: F401
+    from simple3d_former_amd import _lib as L
+    from simple3d_former_amd.point_engine import PointEngine, KNN
+    from simple3d_former_amd.parallel import PointDataParallelTrainer
+    from oracle import point_oracle as po                      # synthetic-input recipe + cpu_baseline leg only
+
+    c = POINT_CONFIGS[args.config]
+    backbone = 'deit_tiny_patch16_224'
+    B = args.batch or c['batch']
+    world, rank, local_rank = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    dev_index = int(os.environ.get('S3D_BENCH_DEVICE', local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1 or args.force_collectives:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29541')
+        dist.init_process_group(backend=os.environ.get('S3D_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
+    eng = PointEngine(backbone=backbone, n_points=c['n_points'], d_points=c['d_points'], n_classes=c['n_classes'], task=c['task'],
+                      device=dev, lr=0.01, momentum=0.9)       # config/cls.yaml:3,6; train_cls.py:91
+    eng.load_state_dict(po.init_state_dict(backbone=backbone, n_classes=c['n_classes'], d_points=c['d_points'], seed=9))
+    x, y, starts = po.synthetic_points(B, c['n_points'], c['d_points'], c['n_classes'], c['task'], seed=9 + rank)
+    x, y, starts = x.to(dev), y.to(dev), tuple(t.to(dev) for t in starts)
+    ident = rccl_identity(dev, world)
+    dp = world > 1 or args.force_collectives
+    pipelined = args.pipeline and not dp and not args.no_graphs
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier(); torch.cuda.synchronize()
+
+    if dp:
+        tr = PointDataParallelTrainer(eng, use_graphs=not args.no_graphs, force_collectives=args.force_collectives)
+        loss_t = tr.step(x, y, starts)
+        step = tr.step_graph if not args.no_graphs else (lambda: tr.step_eager(x, y, starts))
+        launch = ('hipGraph replay (3 graphs + 2 host-launched all-reduces)' if not args.no_graphs else 'eager')
+    elif pipelined:
+        xs, ys, sts = [x, x.clone()], [y, y.clone()], [starts, tuple(t.clone() for t in starts)]
+        graphs, loss_t = eng.capture_train_step_pipelined(xs, ys, sts)
+        state = {'p': 0}
+
+        def step():
+            graphs[state['p']].replay(); state['p'] ^= 1
+        launch = 'hipGraph replay, geometry (FPS/kNN) one step ahead on a side stream'
+    elif not args.no_graphs:
+        graph, loss_t = eng.capture_train_step(x, y, starts)
+        step = graph.replay
+        launch = 'hipGraph replay'
+    else:
+        step = lambda: eng.train_step(x, y, starts)
+        loss_t = eng.workspace(B).loss[0:1]
+        launch = 'eager'
+    first_loss = None
+    for i in range(max(args.warmup, 1)):
+        step()
+        if i == 0:
+            first_loss = float(eng.workspace(B).loss[0])
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    last_loss = float(eng.workspace(B).loss[0])
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    out = {'metric': c['metric'], 'value': round(value, 1), 'unit': 'clouds/sec', 'n_gpus': world, 'steps': args.steps,
+           'warmup': args.warmup, 'ms_per_step': round(ms, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+           'dtype': 'bf16',
+           'precision_note': 'bf16 MFMA operands (split-bf16 forward, plain bf16 backward), fp32 accumulation / BatchNorm (fp64 column sums) / '
+                             'LayerNorm / softmax / loss / SGD; FPS, kNN and 3-NN indices bit-exact vs the fp32 reference',
+           'data': f'synthetic (seeded unit-ball clouds with unit normals{" + one-hot(16) object label" if c["d_points"] > 6 else ""}, '
+                   'random-init weights of the reference architecture, FPS start draws as explicit inputs)',
+           'config': {'workload': c['workload'], 'batch_per_gpu': B, 'global_batch': world * B, 'points_per_cloud': c['n_points'],
+                      'parallelism': f'dp{world}', 'launch': launch,
+                      'collectives': 'none' if not dp else 'host-launched between graph segments (fp32, 2 buckets)'},
+           'points_per_sec': round(value * c['n_points'], 0),
+           'rccl_ranks': ident['rccl_ranks'], 'distinct_devices': ident['distinct_devices'], 'dist_backend': ident['backend'],
+           'loss_first_step': round(first_loss, 5), 'loss_last_step': round(last_loss, 5)}
+    if c['task'] == 'seg':
+        out['seg_points_per_sec'] = out['points_per_sec']
+    if dp and not args.no_diagnostics:
+        out.update(collective_diagnostics(tr, step, ms, world, args.force_collectives))
+    if rank == 0 and not args.no_roofline:
+        # ---- HBM-bound side: the non-GEMM operators of TransitionDown 0, timed live on this step's own tensors (HIP events on the
+        # launch stream, 20 launches each).  Algorithmic bytes = what the operator must move once (SURVEY 8(d)): inputs read once,
+        # outputs written once -- re-reads (e.g. the statistics pass of BatchNorm) count against the achieved rate.
+        ws = eng.workspace(B)
+        t0_, lay = ws.td[0], eng.td[0]
+        R, ch, G = t0_.R, eng.ch[0], B * t0_.S
+        hbm = []
+
+        def add(name, fn, nbytes, reps=20, note=None):
+            ms_ = timed(fn, reps)
+            hbm.append(dict(kernel=name, avg_us=round(ms_ * 1e3, 2), bytes_per_launch=int(nbytes),
+                            achieved=round(nbytes / (ms_ * 1e-3) / 1e9, 1), frac=round(nbytes / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            **({'note': note} if note else {})))
+        eng.training = True
+        keep = [b.clone() for b in eng.bn_buffers()]
+        add('batchnorm_bwd (td0.mlp_bns.1: relu/max backward + stats + apply; s3d_batchnorm_bwd)',
+            lambda: lay['b1'].bwd(t0_.x2, R, t0_.dout, t0_.dx, K=KNN, arg=t0_.arg), R * ch * (4 + 2) + G * ch * (4 + 1))
+        add('batchnorm_bwd (td0.mlp_bns.0: relu backward + stats + apply)',
+            lambda: lay['b0'].bwd(t0_.x1, R, t0_.dy1, t0_.dx), R * ch * (4 + 4 + 2))
+        add('batchnorm_fwd + relu + max over 16 neighbours (td0.mlp_bns.1; s3d_batchnorm_fwd)',
+            lambda: lay['b1'].fwd(t0_.x2, R, K=KNN, y=t0_.out, arg=t0_.arg), R * ch * 4 + G * ch * (4 + 1))
+        add('group_project_fwd (td0: Pf[idx] + xyz_rel.Wx^T + b, BatchNorm column sums fused)',
+            lambda: L.check(eng.lib.s3d_group_project_fwd(ctypes.byref(lay['gp'].args(t0_, t0_.xyz_in, B, Pf=t0_.Pf, x=t0_.x1, ldx=ch,
+                                                                                        sums=lay['b0'].sums)), L.current_stream()), 'gp'),
+            R * ch * 4 + B * t0_.Nin * ch * 4 + R * 4)
+        g0 = ws.geo[0].td[0]
+        add('fps (level 0: one workgroup per cloud, npoint sequential rounds; latency-bound by construction)',
+            lambda: L.check(eng.lib.s3d_fps(L.ptr(ws.geo[0].xyz), ctypes.c_long(3), L.ptr(starts[0]), B, t0_.Nin, t0_.S, L.ptr(g0['fps_idx']),
+                                            L.ptr(g0['new_xyz']), L.current_stream()), 'fps'),
+            B * (t0_.Nin * 12 + t0_.S * 16), reps=5, note='HBM-minimal bytes N*12 in + npoint*16 out per cloud (SURVEY 8(d)); the kernel is a chain of npoint dependent arg-max rounds')
+        add('knn16 (level 0)',
+            lambda: L.check(eng.lib.s3d_knn(L.ptr(g0['new_xyz']), L.ptr(ws.geo[0].xyz), B, t0_.S, t0_.Nin, KNN, L.ptr(g0['idx']), None,
+                                            L.current_stream()), 'knn'),
+            B * (t0_.Nin * 12 + t0_.S * 12 + t0_.S * KNN * 4), reps=5)
+        for b_, k_ in zip(eng.bn_buffers(), keep):
+            b_.copy_(k_)
+        dom = max(hbm[:4], key=lambda k: k['avg_us'])          # dominant bandwidth-bound operator (FPS / kNN are latency chains)
+        # ---- MFMA side: GEMM launches of an instrumented eager step
+        lib = L.lib()
+        lib.s3d_prof_enable(1)
+        n_inst = 3
+        for _ in range(n_inst):
+            eng.train_step(x, y, starts)
+        torch.cuda.synchronize()
+        rows = (ctypes.c_double * (4 * 64))()
+        n = lib.s3d_prof_collect(rows, 64)
+        lib.s3d_prof_enable(0)
+        ov = ctypes.c_double(0.0)
+        lib.s3d_prof_event_overhead(L.current_stream(), ctypes.byref(ov))
+        ks = [(rows[4 * i], rows[4 * i + 1], max(rows[4 * i + 2] - rows[4 * i + 1] * ov.value * 1e-3, 1e-9), rows[4 * i + 3]) for i in range(min(n, 64))]
+        mf = None
+        if ks:
+            d = max(ks, key=lambda k: k[2])
+            ach = d[3] / (d[2] * 1e-3) / 1e12
+            mf = dict(bound='mfma', kernel=kernel_name(d[0]), achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                      frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 5), avg_launch_us=round(d[2] / d[1] * 1e3, 3),
+                      launches_per_step=round(d[1] / n_inst, 1), flops_per_launch=round(d[3] / d[1], 0),
+                      mfma_issue_factor=3 if 'split3' in kernel_name(d[0]) else 1,
+                      timing='HIP events on the launch stream around every GEMM launch of an instrumented eager step, minus the empty-bracket time',
+                      all_gemm_kernels=dict(achieved=round(sum(k[3] for k in ks) / (sum(k[2] for k in ks) * 1e-3) / 1e12, 2),
+                                            ms_per_step=round(sum(k[2] for k in ks) / n_inst, 4)))
+        out['roofline'] = dict(bound='hbm', kernel=dom['kernel'], achieved=dom['achieved'], peak=HBM_PEAK_GBPS, unit='GB/s', frac=dom['frac'],
+                               traffic=None, avg_launch_us=dom['avg_us'], bytes_per_launch=dom['bytes_per_launch'],
+                               timing='HIP events on the launch stream around 20 back-to-back launches of the operator on the step\'s own tensors',
+                               per_kernel=hbm, mfma=mf)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = point_cpu_baseline(c, backbone)
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        barrier()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1 or args.force_collectives:
+        if world > 1:
+            barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -143,14 +453,18 @@ def main():
                     help='experimental: one HIP graph per step with the RCCL all-reduces captured inside (default: one graph per '
                          'backward segment, collectives launched from the host in between)')
     ap.add_argument('--buckets', type=int, default=4)
-    ap.add_argument('--config', choices=sorted(CONFIGS), default='cfg2')
+    ap.add_argument('--config', choices=sorted(CONFIGS) + sorted(POINT_CONFIGS), default='cfg2')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
+    ap.add_argument('--wire', choices=['auto', 'fp32', 'bf16'], default='auto',
+                    help="gradient all-reduce format: fp32 (DDP's arithmetic) or bf16 (half the xGMI bytes); auto = bf16 when N > 1")
+    ap.add_argument('--no-diagnostics', action='store_true', help='skip the per-bucket all-reduce / overlap measurement at N > 1')
+    ap.add_argument('--pipeline', action='store_true', help='point configs: geometry (FPS / kNN) of batch i+1 during step i')
     args = ap.parse_args()
+    if args.config in POINT_CONFIGS:
+        return main_points(args)
     global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE
     conf = CONFIGS[args.config]
     CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
-    if args.config != 'cfg2':
-        args.no_cpu_baseline = True
 
     import torch.distributed as dist
     import simple3d_former_amd as s3d
@@ -178,9 +492,16 @@ def main():
     eng.load_state_dict(sd)
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
     x, y = x_cpu.to(dev), y_cpu.to(dev)
+    if conf.get('dropout'):
+        eng.set_dropout(conf['dropout'], seed=9)                # model.train(): nn.TransformerEncoderLayer(dropout=0.1)
+    wire = ('bf16' if world > 1 else 'fp32') if args.wire == 'auto' else args.wire
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
-                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives)
+                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives, wire=wire)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
+    ident = rccl_identity(dev, world)
+    if world > 1:
+        assert ident['rccl_ranks'] == world and ident['distinct_devices'] == world or os.environ.get('S3D_BENCH_DEVICE') is not None, \
+            f'the process group does not span {world} distinct GPUs: {ident}'
 
     def barrier():
         torch.cuda.synchronize()
@@ -226,14 +547,17 @@ def main():
         'config': {'workload': conf['workload'], 'batch_per_gpu': BATCH_PER_GPU,
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
-                   'grad_buckets': len(trainer.slices),
+                   'grad_buckets': len(trainer.slices), 'grad_wire': wire,
                    'collectives': ('none' if not (world > 1 or args.force_collectives) else 'captured in the step graph'
                                    if args.graph_collectives else 'host-launched between graph segments')},
+        'rccl_ranks': ident['rccl_ranks'], 'distinct_devices': ident['distinct_devices'], 'dist_backend': ident['backend'],
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
         'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         'loss_first_step': round(first_loss, 5) if first_loss is not None else None, 'loss_last_step': round(final_loss, 5),
     }
 
+    if (world > 1 or args.force_collectives) and not args.no_diagnostics and not args.graph_collectives:
+        out.update(collective_diagnostics(trainer, step, ms, world, args.force_collectives))   # every rank takes part
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass: HIP events around every GEMM launch, on the launch stream
         lib = L.lib()
@@ -312,7 +636,9 @@ def main():
                                for k in sorted(ks, key=lambda k: -k[2])],
             }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(x_cpu, y_cpu)
+        cb = conf.get('cpu_batch') or BATCH_PER_GPU             # cfg-3: one 128^3 sample is ~2 TFLOP of fp32 CPU work per step
+        out['cpu_baseline'] = cpu_baseline(x_cpu[:cb], y_cpu[:cb], pos_embedding=conf['pos_embedding'], dropout=conf.get('dropout', 0.0),
+                                           full_batch=BATCH_PER_GPU)
 
     # RCCL writes a version banner to the C stdout of every rank, block-buffered until the process exits -- i.e. AFTER a JSON line
     # printed from Python.  Push it out on every rank first, so that the JSON line is the last thing on stdout.

@@ -521,18 +521,25 @@ constexpr int TL_SLOTS = 40;
 #define TL_HWID(i) do {} while (0)
 #endif
 
-template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128>
-__global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
+// WM x WN waves (4 or 8 waves = 256 or 512 threads) each own a (BM / WM) x (BN / WN) sub-tile.  The k-loop of these launches runs at
+// the rate the CU can pull operand bytes out of L2 (tools/probes/dma_bw_probe: ~20 TB/s chip-wide whatever the ring depth), so the
+// lever is bytes per flop: one fat workgroup per CU (128x96 / 64x128 with eight waves) moves 2-2.6x fewer bytes than 2-5 thin ones.
+template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
     static_assert((NPL * (BM + BN) * BK * 2) % 4096 == 0, "a stage must split into whole 1 KB pieces per wave");
     constexpr int ROWB = BK * 2;                                       // bytes per tile row: 128 (BK = 64) or 64 (BK = 32)
     constexpr int CPRW = ROWB / 16, RPP = 1024 / ROWB;                 // 16-byte chunks per row, rows per 1 KB DMA piece
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = NPL * (A_BYTES + B_BYTES);
-    constexpr int PPW = STAGE / 1024 / 4;                              // DMA pieces per wave per stage
-    constexpr int FM = BM / 32, FN = BN / 32;
+    constexpr int NW = WM * WN, NTHR = 64 * NW;
+    static_assert((STAGE / 1024) % NW == 0, "every wave issues the same number of 1 KB pieces per stage");
+    constexpr int PPW = STAGE / 1024 / NW;                             // DMA pieces per wave per stage
+    constexpr int TM = BM / WM, TN = BN / WN;                          // rows / columns of a wave's sub-tile
+    static_assert(TM % 16 == 0 && TN % 16 == 0, "wave sub-tiles are built from 16x16 MFMA blocks");
+    constexpr int FM = TM / 16, FN = TN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
     const int ntx = gridDim.x, nty = gridDim.y;
     {
@@ -598,13 +605,13 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
             bf16x8 a_hi[FM], b_hi[FN], a_lo[SPLIT ? FM : 1], b_lo[SPLIT ? FN : 1];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int r = wm * (BM / 2) + i * 16 + (lane & 15);
+                const int r = wm * TM + i * 16 + (lane & 15);
                 a_hi[i] = frag(sA, r, kc);
                 if constexpr (SPLIT) a_lo[i] = frag(sA + A_BYTES, r, kc);
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int r = wn * (BN / 2) + j * 16 + (lane & 15);
+                const int r = wn * TN + j * 16 + (lane & 15);
                 b_hi[j] = frag(sB, r, kc);
                 if constexpr (SPLIT) b_lo[j] = frag(sB + B_BYTES, r, kc);
             }
@@ -629,10 +636,10 @@ __global__ __launch_bounds__(256) void gemm_nt_dma_kernel(const GemmArgs p) {
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-            *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) = acc[i][j];
+            *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
     __syncthreads();
 #pragma unroll
-    for (int c = tid; c < BM * CPR; c += 256) {
+    for (int c = tid; c < BM * CPR; c += NTHR) {
         const int row = c / CPR, col = (c % CPR) * 8;
         float v[8];
         ld_f32<8>(v, ct + row * LDC + col);
@@ -923,12 +930,13 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
 }
 
 // the forward DMA kernel on the small cfg-2 tiles (k = 64 stages)
-template <bool SPLIT, int EPI, int BM, int BN, int NS>
+template <bool SPLIT, int EPI, int BM, int BN, int NS, int WM = 2, int WN = 2>
 int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
     constexpr int BK = 64;
     constexpr int STAGE = (SPLIT ? 2 : 1) * (BM + BN) * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, BM * (BN + 4) * 4);
-    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN>;
+    static_assert(LDS <= 160 * 1024, "stage ring exceeds the CU's LDS");
+    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -943,11 +951,11 @@ int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
         sl.flops = 2.0 * a.M * a.N * a.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
         (void)hipEventRecord(sl.e1, stream);
         g_prof.push_back(sl);
     } else {
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
     }
     S3D_CHECK_LAUNCH("gemm_nt_dma_small");
     return 0;
@@ -1039,6 +1047,11 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // cfg-2, us: qkv 12.1 -> 9.7, proj 7.8 -> 6.4, fc1 18.8 -> 16.2, fc2 19.8 -> 14.6; three stages or k = 32 stages were neutral.
         static const int dma_small = env_int("S3D_GEMM_DMA_SMALL");
         if (dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+            if (tile == 4) return launch_nt_dma_small<SPLIT, EPI, 128, 96, 2, 4, 2>(a, s);      // eight waves, one workgroup per CU
+            if (tile == 5) return launch_nt_dma_small<SPLIT, EPI, 64, 128, 3, 2, 4>(a, s);
+            if (tile == 6) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 4>(a, s);
+            if (tile == 7) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 2, 4, 2>(a, s);
+            if (tile == 8) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 3, 2, 2>(a, s);
             if (tile == 1) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 2>(a, s);
             if (tile == 0) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2>(a, s);
             if (tile == 3) {

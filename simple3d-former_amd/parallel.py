@@ -36,6 +36,7 @@ class BucketedGradReducer:
         self.flat, self.slices, self.group = flat_grad, list(slices), group
         self.force = force                   # issue the collective even at world size 1 (exercises the RCCL path)
         self.prepare = prepare
+        self.skip = False                    # diagnostics only (bench.py): time the step with the collectives suppressed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._works = []
         covered = sorted(self.slices)
@@ -46,7 +47,7 @@ class BucketedGradReducer:
         s, e = self.slices[i]
         if self.prepare is not None:
             self.prepare(s, e)
-        if self.world == 1 and not self.force:
+        if (self.world == 1 and not self.force) or self.skip:
             return
         self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
@@ -154,6 +155,7 @@ class DataParallelTrainer:
                 self.reducer.wait()
                 eng.adam_step(zero_grad=True, wire=self.wire)
             self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
+            self._guarded_first_replay(g, state)
             return self._cap
         graphs = []
         for k in range(len(self.segments)):
@@ -166,6 +168,35 @@ class DataParallelTrainer:
             eng.adam_step(zero_grad=True, wire=self.wire)
         self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
         return self._cap
+
+    def _guarded_first_replay(self, graph, state, timeout_s=None):
+        """First replay of a graph that holds RCCL kernels, under a watchdog: a capture problem that only shows with real peers
+        would otherwise hang the job forever inside the device queue.  The replay is enqueued, the host polls an event for at
+        most timeout_s (S3D_GRAPH_COLLECTIVE_TIMEOUT, default 120 s) and, if it never completes, reports and leaves the process
+        with exit code 3 (a hung device queue cannot be recovered in-process).  The training state is restored afterwards."""
+        import os
+        import sys
+        import time
+        timeout_s = float(os.environ.get('S3D_GRAPH_COLLECTIVE_TIMEOUT', '120')) if timeout_s is None else timeout_s
+        snap = [t.clone() for t in state]
+        torch.cuda.synchronize()
+        graph.replay()
+        ev = torch.cuda.Event()
+        ev.record()
+        t0 = time.monotonic()
+        while not ev.query():
+            if time.monotonic() - t0 > timeout_s:
+                rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+                sys.stderr.write(f'[s3d] rank {rank}: the first replay of the step graph with captured all-reduces did not finish within '
+                                 f'{timeout_s:.0f} s -- giving up (use the host-launched collectives, the default)\n')
+                sys.stderr.flush()
+                os._exit(3)
+            time.sleep(0.002)
+        for t, sv in zip(state, snap):
+            t.copy_(sv)
+        self.eng.refresh_weight_planes()
+        torch.cuda.synchronize()
+        self.first_replay_s = time.monotonic() - t0
 
     def step_graph(self):
         """Replays the captured step on the static buffers (cap['x'], cap['y'] must already hold the batch)."""
