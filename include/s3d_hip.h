@@ -69,6 +69,12 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int sp
  * the median time between two events recorded back-to-back on the stream with nothing in between (microseconds). */
 int s3d_prof_enable(int on);
 int s3d_prof_collect(double* rows, int cap);
+/* Deterministic mode (default: environment S3D_DETERMINISTIC=1, else off).  On: no reduction combines partial sums from several
+ * workgroups with fp32 atomics -- wgrads run without split-K, the token / conv-bias gradients, the loss and the final-norm
+ * gamma / beta gradients take single-writer kernels -- so a training step (train_cls_voxel.py:277-288) is bitwise reproducible
+ * run to run.  Slower; meant for parity and trajectory tests.  Process-wide; set it before capturing graphs. */
+int s3d_set_deterministic(int on);
+int s3d_get_deterministic(void);
 int s3d_prof_event_overhead(s3d_stream_t stream, double* microseconds);
 /* Difference timing: while key != 0, launches of the GEMM instantiation with that key (as reported by s3d_prof_collect) are
  * suppressed (they return 0 without enqueuing anything).  bench.py captures the training step once with and once without the

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "attention.h"
 #include "gemm.h"
@@ -9,6 +10,14 @@
 #include "s3d_hip.h"
 
 static thread_local char g_err[512] = "";
+static int g_deterministic = -1;                  // -1: not set yet -> S3D_DETERMINISTIC decides
+bool s3d_deterministic() {
+    if (g_deterministic < 0) {
+        const char* v = getenv("S3D_DETERMINISTIC");
+        g_deterministic = (v && atoi(v) > 0) ? 1 : 0;
+    }
+    return g_deterministic != 0;
+}
 
 void s3d_set_error(const char* fmt, ...) {
     va_list ap;
@@ -271,6 +280,9 @@ size_t s3d_sizeof(const char* n) {
 #undef SZ
     return 0;
 }
+
+int s3d_set_deterministic(int on) { g_deterministic = on ? 1 : 0; return 0; }
+int s3d_get_deterministic(void) { return s3d_deterministic() ? 1 : 0; }
 
 int s3d_prof_enable(int on) { s3d_gemm_prof_enable(on != 0); return 0; }
 int s3d_prof_collect(double* rows, int cap) { return s3d_gemm_prof_collect(rows, cap); }

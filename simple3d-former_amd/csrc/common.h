@@ -102,6 +102,10 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomic
 
 // ---- host-side error plumbing (capi.hip owns the storage) ----
 void s3d_set_error(const char* fmt, ...);
+// Deterministic mode (s3d_set_deterministic / S3D_DETERMINISTIC=1): every reduction that would otherwise combine partial sums
+// with fp32 atomics from several workgroups (split-K wgrads, token / bias gradients, loss, final-norm gamma/beta) takes a
+// single-writer path instead, so a training step is bitwise reproducible run to run.  Slower; for parity tests.
+bool s3d_deterministic();
 #define S3D_CHECK_LAUNCH(name)                                                         \
     do {                                                                               \
         hipError_t e__ = hipGetLastError();                                            \

@@ -457,22 +457,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
 
     if constexpr (TA && EPI == EPI_ATOMIC) {
         if (want_bsum) {   // block-uniform
-            float* red = reinterpret_cast<float*>(smem);
-            __syncthreads();
-            for (int i = tid; i < BM; i += 256) red[i] = 0.f;
+            // every task q = (row chunk rc, k pair kp) holds 8 row partials: park them in LDS and let one thread per row add the
+            // 32 k-pair partials in a FIXED order (LDS float atomics would leave the order to the hardware: run-to-run noise)
+            float* part = reinterpret_cast<float*>(smem);               // [CH * 32 tasks][8]  (<= 8 KB)
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < SA::NT; ++j) {
                 const int q = tid + j * 256;
                 if (q < SA::CH * 32) {
-                    const int rc = q % SA::CH;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) atomicAdd(&red[rc * 8 + i], bsum[j][i]);
+                    for (int i = 0; i < 8; ++i) part[q * 8 + i] = bsum[j][i];
                 }
             }
             __syncthreads();
-            for (int i = tid; i < BM; i += 256)
-                if (m0 + i < p.M) atomic_add_f32(&p.bias_grad[m0 + i], red[i] * p.alpha);
+            for (int i = tid; i < BM; i += 256) {
+                const int rc = i >> 3, ii = i & 7;
+                float t = 0.f;
+                for (int kp = 0; kp < 32; ++kp) t += part[(kp * SA::CH + rc) * 8 + ii];
+                if (m0 + i < p.M) atomic_add_f32(&p.bias_grad[m0 + i], t * p.alpha);
+            }
         }
     }
 }
@@ -1111,6 +1114,7 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
 static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
+    if (s3d_deterministic()) splitk = 1;       // one workgroup per output tile: a single fp32 add per element, no ordering freedom
     static const int big_min = env_int("S3D_WGRAD_BIG_MIN") > 0 ? env_int("S3D_WGRAD_BIG_MIN") : 48;   // narrow long-k wgrads (point path: 96 x 56 x 2.1 M) stream well on the DMA kernel too
     if (splitk <= 0 && a.K >= 16384 && a.M >= big_min && a.N >= big_min) {
         // long reductions (cfg-3: k = 188k token rows): 128x128 tiles re-read 4x less than 64x64 ones, and k is long enough

@@ -223,6 +223,8 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     if (a.partial) {
         S3D_REQUIRE(a.partial_blocks > 0, "layernorm bwd: partial mode needs partial_blocks > 0");
         blocks = a.partial_blocks;                       // the caller sized the buffer; the kernel grid-strides over rows
+    } else if (s3d_deterministic() && (a.dgamma || a.dbeta)) {
+        blocks = 1;                                      // single writer of dgamma / dbeta (the atomic path's order is free otherwise)
     }
     // rows each wave handles per trip: as many as the grid leaves it (clamped duplicate rows would only add loads)
     const long per_wave = (a.rows + blocks * 4 - 1) / (blocks * 4);

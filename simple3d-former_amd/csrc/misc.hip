@@ -111,6 +111,21 @@ __global__ __launch_bounds__(64) void posgrad_kernel(const PosGradArgs p, long g
     else if (p.dbias) atomic_add_f32(p.dbias + d, s);
 }
 
+// deterministic mode: one thread per feature column walks every (group, token) in a fixed order -- single writer per destination
+__global__ __launch_bounds__(64) void posgrad_det_kernel(const PosGradArgs p) {
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    if (d >= p.D) return;
+    float cls = 0.f, bias = 0.f;
+    for (int t = 0; t < p.ntok; ++t) {
+        float s = 0.f;
+        for (long g = 0; g < p.groups; ++g) s += p.dx[(g * p.ntok + t) * p.D + d];
+        if (p.dpos) p.dpos[(long)t * p.D + d] += s;
+        if (t == 0) cls = s; else bias += s;
+    }
+    if (p.dcls) p.dcls[d] += cls;
+    if (p.dbias) p.dbias[d] += bias;
+}
+
 // ------------------------------------------------------------------------------------------- token assemble (pass 2)
 // out[b*(n+1) + t][:] = (t == 0 ? cls : src[b*n + t - 1]) + pos[t]      ('(b px py) c -> b (px py) c' + cat cls + pos add,
 // vit_3d_2d_pretrain.py:485-491);  bwd: dsrc[b*n + j] = dout[b*(n+1) + 1 + j]
@@ -313,6 +328,13 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
             for (int c = lane; c < ld; c += 64)
                 p.dlogits[row * ld + c] = (c < p.C) ? p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den : 0.f;
     }
+    if (gridDim.x == 1) {                        // deterministic mode: the four wave sums are combined in a fixed order
+        __shared__ float part[4];
+        if (lane == 0) part[threadIdx.x >> 6] = acc / den;
+        __syncthreads();
+        if (threadIdx.x == 0) p.loss[0] += (part[0] + part[1]) + (part[2] + part[3]);
+        return;
+    }
     if (lane == 0 && acc != 0.f) atomic_add_f32(p.loss, acc / den);
 }
 
@@ -393,6 +415,11 @@ int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
     const long gchunk = (a.groups + gs - 1) / gs;
     gs = (a.groups + gchunk - 1) / gchunk;
     S3D_REQUIRE(a.ntok <= 65535, "posgrad: ntok=%d too large", a.ntok);
+    if (s3d_deterministic()) {
+        hipLaunchKernelGGL(posgrad_det_kernel, dim3((unsigned)((a.D + 63) / 64)), dim3(64), 0, s, a);
+        S3D_CHECK_LAUNCH("posgrad (deterministic)");
+        return 0;
+    }
     hipLaunchKernelGGL(posgrad_kernel, dim3((unsigned)a.ntok, (unsigned)((a.D + 63) / 64), (unsigned)gs), dim3(64), 0, s, a, gchunk);
     S3D_CHECK_LAUNCH("posgrad");
     return 0;
@@ -450,6 +477,8 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(ce_den_kernel, dim3(1), dim3(256), 0, s, a);
     long blocks = (a.rows + 3) / 4;
     if (blocks > 1024) blocks = 1024;
+    if (s3d_deterministic() && a.rows <= 4096) blocks = 1;       // one workgroup: four fixed-order partial sums (large row counts keep
+                                                                  // the parallel grid: only the reported loss value, never a gradient, depends on the order)
     hipLaunchKernelGGL(ce_main_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     S3D_CHECK_LAUNCH("cross_entropy");
     return 0;

@@ -1,0 +1,138 @@
+"""Size-independent properties at BASELINE.json's full sizes for configs[2..4] (cfg-2 has test_cfg2_full_size_properties in
+test_gpu_model.py): the kernels that only run at scale -- the cooperative long-sequence attention, 128x128 split-K wgrads, packed
+pass-1 attention at 47 k groups, the 2.1 M-row BatchNorm / neighbourhood kernels -- are exercised at the sizes bench.py times.
+
+Invariants are chosen per model: group_embed attends ACROSS the samples of a batch (vit_3d_2d_pretrain.py:472-480), so batch
+independence / sub-batch gradient linearity do not hold there (permutation equivariance and linearity in d(logits) do); the point
+models couple samples through train-mode BatchNorm, so per-sample checks run in eval mode (running statistics)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import simple3d_former_amd as s3d
+    from simple3d_former_amd.point_engine import PointEngine
+
+from oracle import point_oracle as po
+from oracle import voxel_oracle as vo
+
+DEV = 'cuda'
+LOGIT_TOL = 1e-3
+
+
+def test_cfg3_full_geometry_properties_at_batch_16():
+    """BASELINE cfg-3 geometry (deit_base H=3, VoxelEmbed_no_average 128^3, cell 9, patch 14, group_embed, 55 classes) at B = 16:
+    L = 16 * 196 = 3136 keys per (token, head) in the seq-first encoder layer (cooperative attention kernels), 47 040 pass-1
+    sequences of 15 tokens (packed pairs), M = 47 040 rows in every pass-1 GEMM (128x128 tiles, split-K wgrads)."""
+    kw = dict(backbone='deit_base_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=128, cell=9, patch=14, n_classes=55)
+    sd = vo.init_state_dict(seed=9, pos_embedding='group_embed', exercise_all=True, **kw)
+    B = 16
+    x, y = vo.synthetic_batch(B, 128, 55, seed=9)
+    eng = s3d.VoxelEngine(device=DEV, pos_embedding='group_embed', **kw)
+    eng.load_state_dict(sd)
+    xd, yd = x.to(DEV), y.to(DEV)
+    logits = eng.forward(xd).clone()
+    assert torch.isfinite(logits).all()
+    # (1) the forward has no atomics: bitwise run-to-run
+    assert torch.equal(logits, eng.forward(xd))
+    # (2) permuting the samples permutes the logits (attention over the B*196 groups is permutation-equivariant; only the
+    #     summation order inside the flash tiles changes)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).to(DEV)
+    lp = eng.forward(xd[perm].contiguous()).clone()
+    assert float((lp - logits[perm]).abs().max()) <= 2e-4
+    # (3) parity with the CPU oracle (same full-size weights) on a 2-sample batch: the cross-sample attention makes a SLICE of the
+    #     16-batch incomparable, so the engine runs the 2-sample batch too
+    l2 = eng.forward(xd[:2].contiguous()).clone().cpu()
+    with torch.no_grad():
+        ref = vo.forward(sd, x[:2], backbone=kw['backbone'], embed_layer=kw['embed_layer'], cell=9, patch=14, pos_embedding='group_embed')
+    assert float((l2 - ref).abs().max()) <= LOGIT_TOL, float((l2 - ref).abs().max())
+    assert torch.equal(l2.argmax(1), ref.argmax(1))
+    # (4) the backward is linear in d(logits): gradients of 2 * dlogits == 2 * gradients (within the split-K atomic / bf16 noise)
+    eng.forward(xd); eng.cross_entropy(B, yd)
+    ws = eng.workspace(B)
+    d1 = ws.dlogits.clone()
+    eng.zero_grad(); eng.backward(B, d1)
+    g1 = eng.arena.g.clone()
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    eng.zero_grad(); eng.backward(B, 2 * d1)
+    rel = float((eng.arena.g - 2 * g1).norm() / (2 * g1).norm())
+    assert rel < 2e-2, f'backward not linear in dlogits: rel err {rel:.3e}'
+    # every used parameter receives a gradient (shared blocks: both passes accumulate)
+    for k in ('group_embed.self_attn.in_proj_weight', 'blocks.0.attn.qkv.weight', 'blocks.11.mlp.fc2.weight', 'voxel_embed.proj.conv3d_1.weight',
+              'group_pos_embed', 'voxel_pos_embed'):
+        assert float(eng.arena.grad(k).abs().max()) > 0, k
+    # (5) training-mode dropout(0.1) + a few fused steps reduce the loss on a fixed batch
+    eng.set_dropout(0.1, seed=3)
+    eng.zero_grad()
+    l0 = float(eng.train_step(xd, yd))
+    for _ in range(6):
+        l1 = float(eng.train_step(xd, yd))
+    assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
+
+
+def _point_fullsize(task, n_points, d_points, n_classes, B, n_slice):
+    backbone = 'deit_tiny_patch16_224'
+    sd = po.init_state_dict(backbone=backbone, n_classes=n_classes, d_points=d_points, seed=9)
+    x, y, starts = po.synthetic_points(B, n_points, d_points, n_classes, task, seed=9)
+    eng = PointEngine(backbone=backbone, n_points=n_points, d_points=d_points, n_classes=n_classes, task=task, device=DEV)
+    eng.load_state_dict(sd)
+    xd, yd, sts = x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts)
+    # ---- eval mode (running statistics): samples are independent
+    le = eng.forward(xd, sts, training=False).clone()
+    assert torch.isfinite(le).all()
+    assert torch.equal(le, eng.forward(xd, sts, training=False)), 'eval-mode forward is not bitwise reproducible'
+    ws = eng.workspace(B)
+    fps_idx = [t.fps_idx.clone().cpu() for t in ws.td]
+    knn_idx = [t.idx.clone().cpu() for t in ws.td]
+    half = eng.forward(xd[:B // 2].contiguous(), tuple(s[:B // 2].contiguous() for s in sts), training=False).clone()
+    assert float((half - le[:B // 2]).abs().max()) <= 1e-5, 'batch independence (eval mode)'
+    # parity with the CPU oracle on a slice: logits + bit-exact FPS / kNN indices
+    xs, ss = x[:n_slice], tuple(s[:n_slice] for s in starts)
+    with torch.no_grad():
+        ref = po.forward(sd, xs, task=task, backbone=backbone, starts=ss, training=False)
+    got = le[:n_slice].cpu()
+    assert float((got - ref).abs().max()) <= LOGIT_TOL, float((got - ref).abs().max())
+    if task == 'cls':
+        assert torch.equal(got.argmax(-1), ref.argmax(-1))
+    else:                                               # per-point argmax: allow ties inside the tolerance band only
+        top2 = ref.topk(2, dim=-1).values
+        clear = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_TOL
+        assert torch.equal(got.argmax(-1)[clear], ref.argmax(-1)[clear])
+    xyz = xs[..., :3]
+    f0 = po.farthest_point_sample(xyz, eng.S[0], ss[0])
+    assert torch.equal(fps_idx[0][:n_slice].long(), f0), 'FPS indices (level 0) differ from the reference algorithm'
+    nx0 = po.index_points(xyz, f0)
+    assert torch.equal(knn_idx[0][:n_slice].long(), po.knn_indices(nx0, xyz, 16)), 'kNN indices (level 0)'
+    f1 = po.farthest_point_sample(nx0, eng.S[1], ss[1])
+    assert torch.equal(fps_idx[1][:n_slice].long(), f1), 'FPS indices (level 1)'
+    # ---- train mode: batch statistics couple the samples; check reproducibility within the fp64-atomic noise, linearity of the
+    # backward in d(logits), and that SGD steps reduce the loss on a fixed batch
+    lt = eng.forward(xd, sts).clone()
+    lt2 = eng.forward(xd, sts).clone()
+    assert float((lt - lt2).abs().max()) <= 1e-4
+    eng.cross_entropy(B, yd)
+    d1 = ws.dlogits.clone()
+    eng.zero_grad(); eng.backward(B)
+    g1 = eng.arena.g.clone()
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    eng.forward(xd, sts)
+    ws.dlogits.copy_(2 * d1)
+    eng.zero_grad(); eng.backward(B)
+    rel = float((eng.arena.g - 2 * g1).norm() / (2 * g1).norm())
+    assert rel < 2e-2, f'backward not linear in dlogits: rel err {rel:.3e}'
+    eng.zero_grad()
+    l0 = float(eng.train_step(xd, yd, sts))
+    for _ in range(8):
+        l1 = float(eng.train_step(xd, yd, sts))
+    assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
+
+
+def test_cfg4_full_size_properties():
+    """BASELINE cfg-4: PointTransformerCls, 1024 points x 6 channels, 40 classes, batch 128 (2.1 M grouped rows in TransitionDown 0)."""
+    _point_fullsize('cls', 1024, 6, 40, 128, n_slice=4)
+
+
+def test_cfg5_full_size_properties():
+    """BASELINE cfg-5: PointTransformerSeg, 2048 points x 22 channels, 50 parts, batch 32 (513-token sequences, 65 536 head rows)."""
+    _point_fullsize('seg', 2048, 22, 50, 32, n_slice=2)

@@ -1,0 +1,85 @@
+"""Training-trajectory parity (the "cls-acc parity" half of BASELINE.json's metric): 50 fused HIP training steps of the cfg-2
+model (deit_small + VoxelEmbed 32^3, 40 classes) at batch 8 against the CPU oracle's fp32 forward / autograd backward / Adam on
+the SAME batches (train_cls_voxel.py:275-288), in deterministic mode (s3d_set_deterministic: no split-K atomics) so that the
+run is reproducible bit for bit."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    import simple3d_former_amd as s3d
+    from simple3d_former_amd import _lib as L
+
+from oracle import voxel_oracle as vo
+
+DEV = 'cuda'
+KW = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5, n_classes=40)
+FKW = dict(backbone=KW['backbone'], embed_layer='VoxelEmbed', cell=6, patch=5)
+
+
+@pytest.fixture
+def deterministic():
+    lib = L.lib()
+    lib.s3d_set_deterministic(1)
+    yield
+    lib.s3d_set_deterministic(0)
+
+
+def _engine(sd):
+    eng = s3d.VoxelEngine(device=DEV, lr=1e-3, **KW)           # README recipe: Adam, lr 1e-3
+    eng.load_state_dict(sd)
+    return eng
+
+
+def test_deterministic_mode_makes_the_training_step_bitwise_reproducible(deterministic):
+    sd = vo.init_state_dict(seed=9, exercise_all=True, **KW)
+    x, y = vo.synthetic_batch(8, 32, 40, seed=11)
+    runs = []
+    for _ in range(2):
+        eng = _engine(sd)
+        losses = [float(eng.train_step(x.to(DEV), y.to(DEV))) for _ in range(6)]
+        runs.append((losses, eng.arena.p.clone()))
+    assert runs[0][0] == runs[1][0], 'losses differ between two identical runs'
+    assert torch.equal(runs[0][1], runs[1][1]), 'parameters differ between two identical runs'
+
+
+def test_fifty_step_trajectory_tracks_the_oracle(deterministic):
+    steps, B, nb = 50, 8, 5
+    sd = vo.init_state_dict(seed=9, **KW)                       # the reference's own initialisation
+    batches = [vo.synthetic_batch(B, 32, 40, seed=100 + i) for i in range(nb)]       # five batches, cycled (ten "epochs")
+    x_held, y_held = vo.synthetic_batch(32, 32, 40, seed=999)
+    eng = _engine(sd)
+    names = vo.used_param_names(sd)
+    ref = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(ref[k]) for k in names}
+    v = {k: torch.zeros_like(ref[k]) for k in names}
+    worst = 0.0
+    got_curve, ref_curve = [], []
+    for step in range(1, steps + 1):
+        x, y = batches[(step - 1) % nb]
+        loss = float(eng.train_step(x.to(DEV), y.to(DEV)))
+        _, loss_ref, grads = vo.loss_and_grads(ref, x, y, **FKW)
+        for k, g in grads.items():
+            vo.adam_step(ref[k], g, m[k], v[k], step)
+        loss_ref = float(loss_ref)
+        got_curve.append(loss); ref_curve.append(loss_ref)
+        rel = abs(loss - loss_ref) / max(abs(loss_ref), 1e-6)
+        worst = max(worst, rel)
+        assert rel <= 2e-2, f'step {step}: HIP loss {loss:.5f} vs oracle {loss_ref:.5f} (rel {rel:.3e})'
+    assert ref_curve[-1] < 0.9 * ref_curve[0], f'the oracle run did not train: {ref_curve[0]:.3f} -> {ref_curve[-1]:.3f}'
+    # held-out synthetic batch: same class decisions, hence the same accuracy
+    logits = eng.forward(x_held.to(DEV)).cpu()
+    with torch.no_grad():
+        ref_logits = vo.forward(ref, x_held, **FKW)
+    acc = float((logits.argmax(1) == y_held).float().mean())
+    acc_ref = float((ref_logits.argmax(1) == y_held).float().mean())
+    top2 = ref_logits.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 5e-2                    # decisions that are not inside the trajectory noise
+    assert int(clear.sum()) >= 24, 'held-out batch has too few clear-cut decisions to be meaningful'
+    assert torch.equal(logits.argmax(1)[clear], ref_logits.argmax(1)[clear]), 'class decisions differ on clear-cut held-out samples'
+    assert abs(acc - acc_ref) <= 1.0 / 32 + 1e-9, (acc, acc_ref)
+    print(f'50-step trajectory: worst relative loss deviation {worst:.3e}; loss {ref_curve[0]:.3f} -> {ref_curve[-1]:.3f}; '
+          f'held-out accuracy {acc:.3f} (oracle {acc_ref:.3f}), {int(clear.sum())}/32 clear-cut decisions all equal')

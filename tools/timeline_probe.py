@@ -19,7 +19,7 @@ from simple3d_former_amd import _lib as L, ops  # noqa: E402
 SLOTS = 40
 M, D = 1664, 384
 DEV = 'cuda'
-TILES = {0: (32, 64), 1: (64, 64), 3: (32, 32), 2: (128, 128)}
+TILES = {0: (32, 64), 1: (64, 64), 3: (32, 32), 2: (128, 128), 4: (128, 96), 5: (64, 128), 6: (64, 64), 7: (128, 128), 8: (64, 96)}
 
 
 def planes(r, c):
