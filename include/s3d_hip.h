@@ -56,10 +56,21 @@ typedef struct S3dGemmArgs {
      * the gradient): keep(m*N + n) = hash(*drop_seed, drop_site, index) >= drop_thr, kept values scaled by drop_scale.
      * drop_thr = 0 disables it.  The seed lives in device memory so that HIP-graph replays see a fresh value. */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
+    /* optional fused LayerNorm of the RESID output (forward NT GEMMs whose N is the whole model dimension: attn.proj -> norm2,
+     * mlp.fc2 -> the next block's norm1).  ln_tickets = one zero-initialised int per row band of the launch (>= ceil(M / 32)
+     * entries; the library leaves them zero): the workgroup whose tile completes a band LAST normalises the band's rows of C
+     * (nn.LayerNorm(eps), gamma / beta) into the split planes ln_hi / ln_lo (row pitch ld_ln) and writes ln_mean / ln_rstd [M].
+     * NULL disables it.  s3d_gemm_ln_fusable() tells whether a launch will take the fused path (else call s3d_layernorm_fwd). */
+    int* ln_tickets;
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    uint16_t* ln_hi; uint16_t* ln_lo; long ld_ln;
+    float* ln_mean; float* ln_rstd;
 } S3dGemmArgs;
 /* ta / tb: operand stored k-major.  (0,0) forward "x @ W^T"; (0,1) dgrad "dy @ W"; (1,1) wgrad "dy^T @ x" (split-K,
  * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
+/* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
+int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
 
 /* Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
  * launch stream.  s3d_prof_collect synchronises those events and fills rows of 4 doubles
@@ -214,6 +225,9 @@ typedef struct S3dBlockShape {
     int Bb, N, D, H, hidden;      /* sequences, tokens per sequence, model dim, heads, MLP hidden */
     float eps;
     int split;                    /* 1: split-bf16 forward (default), 0: plain bf16 */
+    int* ln_tickets;              /* optional: >= ceil(Bb*N / 32) zero-initialised ints (left zero by every call).  When set, norm2 and
+                                   * (in s3d_blocks_fwd) the NEXT block's norm1 run inside the attn.proj / mlp.fc2 GEMM launches
+                                   * (S3dGemmArgs::ln_tickets) instead of as LayerNorm kernels of their own */
 } S3dBlockShape;
 typedef struct S3dBlockParams {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;

@@ -44,17 +44,21 @@ GemmArgs gemm_zero() {
     return g;
 }
 
-int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockActs& a, hipStream_t s) {
+// next_p / next_a: the block that follows (s3d_blocks_fwd), whose norm1 can ride on this block's fc2 launch; ln1_done: this block's
+// norm1 was already produced that way.  Returns 0 / error; *next_ln1_done tells the caller whether the next block may skip norm1.
+int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockActs& a, hipStream_t s, bool ln1_done = false,
+              const S3dBlockParams* next_p = nullptr, const S3dBlockActs* next_a = nullptr, bool* next_ln1_done = nullptr) {
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     const bool split = sh.split != 0;
     S3D_REQUIRE(M < (1L << 31), "block: too many rows");
+    if (next_ln1_done) *next_ln1_done = false;
     // 1. norm1
     LnArgs ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = a.x_in; ln.ldx = D; ln.rows = M; ln.D = D; ln.eps = sh.eps; ln.gamma = p.ln1_w; ln.beta = p.ln1_b;
     ln.out_hi = a.xn1_hi; ln.out_lo = split ? a.xn1_lo : nullptr; ln.ldo = D; ln.mean = a.mean1; ln.rstd = a.rstd1;
-    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    if (!ln1_done) S3D_TRY(s3d_launch_ln_fwd(ln, s));
     // 2. qkv = xn1 @ Wqkv^T + b
     GemmArgs g = gemm_zero();
     g.A_hi = a.xn1_hi; g.A_lo = a.xn1_lo; g.lda = D; g.B_hi = p.qkv_w_hi; g.B_lo = p.qkv_w_lo; g.ldb = D;
@@ -67,25 +71,34 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
-    // 4. x_mid = x_in + att @ Wproj^T + b
+    // 4. x_mid = x_in + att @ Wproj^T + b   [+ norm2 by the last-arriving tile of every row band]
     g = gemm_zero();
     g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D;
     g.M = (int)M; g.N = D; g.K = D; g.bias = p.proj_b; g.R = a.x_in; g.ldr = D; g.C = a.x_mid; g.ldc = D;
+    g.ln_tickets = sh.ln_tickets; g.ln_gamma = p.ln2_w; g.ln_beta = p.ln2_b; g.ln_eps = sh.eps; g.ln_hi = a.xn2_hi;
+    g.ln_lo = split ? a.xn2_lo : nullptr; g.ld_ln = D; g.ln_mean = a.mean2; g.ln_rstd = a.rstd2;
+    const bool fused2 = s3d_gemm_ln_fusable(split, g);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
-    // 5. norm2
+    // 5. norm2 (stand-alone only when the GEMM could not carry it)
     ln.x = a.x_mid; ln.gamma = p.ln2_w; ln.beta = p.ln2_b; ln.out_hi = a.xn2_hi; ln.out_lo = split ? a.xn2_lo : nullptr;
     ln.mean = a.mean2; ln.rstd = a.rstd2;
-    S3D_TRY(s3d_launch_ln_fwd(ln, s));
+    if (!fused2) S3D_TRY(s3d_launch_ln_fwd(ln, s));
     // 6. h = gelu(xn2 @ W1^T + b1)
     g = gemm_zero();
     g.A_hi = a.xn2_hi; g.A_lo = a.xn2_lo; g.lda = D; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D;
     g.M = (int)M; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = Hd; g.O_hi = a.hact_hi;
     g.O_lo = split ? a.hact_lo : nullptr; g.ldo = Hd;
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_GELU, g, 1, s));
-    // 7. x_out = x_mid + h @ W2^T + b2
+    // 7. x_out = x_mid + h @ W2^T + b2   [+ the next block's norm1]
     g = gemm_zero();
     g.A_hi = a.hact_hi; g.A_lo = a.hact_lo; g.lda = Hd; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd;
     g.M = (int)M; g.N = D; g.K = Hd; g.bias = p.fc2_b; g.R = a.x_mid; g.ldr = D; g.C = a.x_out; g.ldc = D;
+    if (next_p && next_a) {
+        g.ln_tickets = sh.ln_tickets; g.ln_gamma = next_p->ln1_w; g.ln_beta = next_p->ln1_b; g.ln_eps = sh.eps;
+        g.ln_hi = next_a->xn1_hi; g.ln_lo = split ? next_a->xn1_lo : nullptr; g.ld_ln = D; g.ln_mean = next_a->mean1; g.ln_rstd = next_a->rstd1;
+        if (next_ln1_done) *next_ln1_done = s3d_gemm_ln_fusable(split, g);
+        if (!next_ln1_done || !*next_ln1_done) g.ln_tickets = nullptr;
+    }
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
     return 0;
 }
@@ -306,6 +319,7 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int split
     S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");
     return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));
 }
+int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* a) { return (a != nullptr && s3d_gemm_ln_fusable(split != 0, *a)) ? 1 : 0; }
 int s3d_layernorm_fwd(const S3dLnArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_layernorm_fwd: null args");
     return s3d_launch_ln_fwd(*a, st(s));
@@ -379,7 +393,13 @@ int s3d_block_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlo
 }
 int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, int depth, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_blocks_fwd: null args");
-    for (int i = 0; i < depth; ++i) S3D_TRY(block_fwd(*sh, p[i], a[i], st(s)));
+    bool ln1_done = false;
+    for (int i = 0; i < depth; ++i) {
+        const bool has_next = i + 1 < depth && a[i + 1].x_in == a[i].x_out;     // the next block normalises exactly this block's output
+        bool next_done = false;
+        S3D_TRY(block_fwd(*sh, p[i], a[i], st(s), ln1_done, has_next ? &p[i + 1] : nullptr, has_next ? &a[i + 1] : nullptr, &next_done));
+        ln1_done = next_done;
+    }
     return 0;
 }
 int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockGrads* g, const S3dBlockActs* a,

@@ -20,6 +20,9 @@ typedef S3dGemmArgs GemmArgs;
 // ta/tb: operand stored k-major.  splitk <= 0: automatic (wgrad only).  Returns 0 on success.
 int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a, int splitk, hipStream_t stream);
 
+// forward NT RESID launch that would run the fused LayerNorm epilogue (GemmArgs::ln_tickets), see gemm.hip
+bool s3d_gemm_ln_fusable(bool split, const GemmArgs& a);
+
 // dgrad (k-major B, epilogue epi_a) and the wgrad that consumes the same dy, fused into one launch (see gemm.hip)
 int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad, hipStream_t stream);
 

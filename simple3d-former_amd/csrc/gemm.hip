@@ -11,6 +11,7 @@
 //     ds_read_b128 fragment reads are at most 2-way,
 //   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
 #include "gemm.h"
+#include "ln_row.h"
 
 #include <stdio.h>
 #include <stdint.h>
@@ -167,6 +168,21 @@ template <int W> __device__ __forceinline__ void st_f32(float* dst, const float 
 #pragma unroll
     for (int q = 0; q < W / 4; ++q) *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
+// Write-through / L1-bypassing 16-byte accesses for data handed from one workgroup to another INSIDE a launch (fused LayerNorm):
+// "sc1" (agent-scope) stores leave the XCD's L2 for memory as they complete and "sc1" loads are served past the CU's L1, so producer
+// stores -> s_waitcnt vmcnt(0) -> agent-scope ticket -> consumer loads needs no cache-wide release / acquire fence (1.7-6.5 us each).
+__device__ __forceinline__ void st_f32x4_wt(float* dst, f32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ f32x4 ld_f32x4_sc(const float* src) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(src) : "memory");
+    return v;
+}
+template <int W> __device__ __forceinline__ void st_f32_wt(float* dst, const float (&v)[W]) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) st_f32x4_wt(dst + 4 * q, f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]});
+}
 template <int W> struct BfVec;
 template <> struct BfVec<4> { union { u32x2 u; bf16_t h[4]; }; };
 template <> struct BfVec<8> { union { u32x4 u; bf16_t h[8]; }; };
@@ -216,7 +232,8 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, con
         ld_f32<W>(rr, p.R + (long)m * p.ldr + n);
 #pragma unroll
         for (int r = 0; r < W; ++r) o[r] = (v[r] + bq[r]) * dm[r] + rr[r];
-        st_f32<W>(p.C + (long)m * p.ldc + n, o);
+        if (p.ln_tickets) st_f32_wt<W>(p.C + (long)m * p.ldc + n, o);     // block-uniform: another workgroup of THIS launch reads it
+        else st_f32<W>(p.C + (long)m * p.ldc + n, o);
         if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
 #pragma unroll
             for (int r = 0; r < W; ++r) hi.h[r] = f2bf(o[r]);
@@ -494,6 +511,65 @@ __device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// Fused LayerNorm (GemmArgs::ln_tickets).  Every tile of the row band [m0, m0 + BM) has stored its part of C write-through; the
+// caller found out (ticket) that its tile was the last one.  The NW waves of the workgroup normalise the band: one row per wave at
+// a time, RB rows' loads in flight together (the rows come from memory / the Infinity Cache, ~1-2 us away).
+template <int MC, int NW>
+__device__ __forceinline__ void ln_band_rows(const GemmArgs& p, const int m0, const int BM, const int tid) {
+    constexpr int RB = MC <= 2 ? 8 : 4;
+    const int lane = tid & 63, wave = tid >> 6, D = p.N;
+    for (int rb = wave * RB; rb < BM; rb += NW * RB) {
+        f32x4 raw[RB][MC];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const long row = min((long)m0 + rb + i, (long)p.M - 1);
+#pragma unroll
+            for (int c = 0; c < MC; ++c)
+                raw[i][c] = ld_f32x4_sc(p.C + row * p.ldc + min(c * 256 + lane * 4, D - 4));
+        }
+        // one wait for the whole batch, tied to the loaded registers so that no use can be scheduled above it
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int c = 0; c < MC; ++c) asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[i][c])::"memory");
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const long row = (long)m0 + rb + i;
+            if (rb + i < BM && row < p.M) {                              // wave-uniform
+                float4 v[MC];
+#pragma unroll
+                for (int c = 0; c < MC; ++c) {
+                    const float keep = (c * 256 + lane * 4 < D) ? 1.f : 0.f;
+                    v[c] = make_float4(raw[i][c][0] * keep, raw[i][c][1] * keep, raw[i][c][2] * keep, raw[i][c][3] * keep);
+                }
+                ln_row_finish<MC>(v, lane, D, p.ln_eps, p.ln_gamma, p.ln_beta, p.ln_mean ? p.ln_mean + row : nullptr,
+                                  p.ln_rstd ? p.ln_rstd + row : nullptr, p.ln_hi ? p.ln_hi + row * p.ld_ln : nullptr,
+                                  p.ln_lo ? p.ln_lo + row * p.ld_ln : nullptr, nullptr);
+            }
+        }
+    }
+}
+
+// Epilogue tail of a RESID tile with the fused LayerNorm: publish the tile, take a ticket of the row band, and if every other
+// tile of the band was there first, normalise the band.  `flag` is one int of LDS.  Placement-independent (any block -> XCD map).
+template <int NW>
+__device__ __forceinline__ void ln_band_tail(const GemmArgs& p, const int m0, const int BM, const int band, const int ntx, int* flag,
+                                             const int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's write-through stores of C have left the chip's caches
+    __syncthreads();                                                   // ... and so have everybody else's in this workgroup
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(p.ln_tickets + band, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (old == ntx - 1) ? 1 : 0;
+        if (last) __hip_atomic_store(p.ln_tickets + band, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0) return;                                            // block-uniform
+    if (p.N <= 256) ln_band_rows<1, NW>(p, m0, BM, tid);
+    else if (p.N <= 512) ln_band_rows<2, NW>(p, m0, BM, tid);
+    else ln_band_rows<4, NW>(p, m0, BM, tid);
+}
+
 // ---- in-kernel timeline (debug builds only: make TL=1 -> libs3d_hip_tl.so; tools/timeline_probe.py) -------------------------
 // wave 0 / lane 0 of every workgroup stamps s_memtime (shader clock) at the phase boundaries of the DMA forward kernel and
 // s_memrealtime (100 MHz, chip-wide) at entry / exit: where a 10-20 us launch of ~600 workgroups spends its time.
@@ -647,6 +723,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         float v[8];
         ld_f32<8>(v, ct + row * LDC + col);
         epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
+    }
+    if constexpr (EPI == EPI_RESID) {
+        if (p.ln_tickets) {                                            // block-uniform
+            __syncthreads();                                           // the staged tile in LDS has been consumed: reuse a word of it
+            ln_band_tail<NW>(p, m0, BM, m0 / BM, ntx, reinterpret_cast<int*>(smem), tid);
+        }
     }
 #ifdef S3D_TIMELINE
     TL_STAMP(5);                                                       // epilogue stores issued (this wave)
@@ -1218,8 +1300,20 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     }
 }
 
+// Mirrors the dispatch of s3d_launch_gemm / launch_nt_epi: only the LDS-DMA forward kernels carry the fused LayerNorm tail.
+bool s3d_gemm_ln_fusable(bool split, const GemmArgs& a) {
+    static const int off = env_int("S3D_LN_FUSE");                      // S3D_LN_FUSE=0: always the stand-alone LayerNorm kernel
+    if (off == 0 || a.ln_tickets == nullptr || a.ln_hi == nullptr || a.C == nullptr) return false;
+    if (a.N % 4 != 0 || a.N > 1024 || a.ldc % 4 != 0 || a.drop_thr != 0) return false;
+    static const int forced_nt = env_int("S3D_GEMM_NT_TILE"), dma = env_int("S3D_GEMM_DMA"), dma_small = env_int("S3D_GEMM_DMA_SMALL");
+    const int tile = forced_nt >= 0 ? forced_nt : s3d_gemm_pick_tile(a.M, a.N, 1, split);
+    if (tile == 2) return dma != 0 && (a.K & (split ? 31 : 63)) == 0 && (a.N & 7) == 0;
+    return split && dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0;
+}
+
 int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in, int splitk, hipStream_t stream) {
     GemmArgs a = a_in;
+    if (a.ln_tickets && !(!ta && !tb && epi == EPI_RESID && s3d_gemm_ln_fusable(split, a))) a.ln_tickets = nullptr;   // never half-fused
     S3D_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem M=%d N=%d K=%d", a.M, a.N, a.K);
     S3D_REQUIRE((a.lda % 8) == 0 && (a.ldb % 8) == 0, "gemm: lda/ldb must be multiples of 8 (got %ld %ld)", a.lda, a.ldb);
     if (!ta) S3D_REQUIRE((a.K % 8) == 0, "gemm: K=%d must be a multiple of 8 for a k-contiguous A", a.K);

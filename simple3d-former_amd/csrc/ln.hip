@@ -2,6 +2,7 @@
 // Forward emits the normalised row as split-bf16 planes (GEMM A operand) and optionally fp32; backward fuses the
 // residual-gradient add, a bf16 copy of dx (operand of the next wgrad/dgrad GEMM) and the gamma/beta gradients.
 #include "kernels.h"
+#include "ln_row.h"
 
 #include <stdlib.h>
 
@@ -19,48 +20,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
     if (row >= p.rows) return;
     const float* x = p.x + row * p.ldx;
     float4 v[MC];
-    float s = 0.f;
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
         const int col = c * 256 + lane * 4;
         const float4 t = *reinterpret_cast<const float4*>(x + min(col, p.D - 4));      // unconditional, clamped
         const float keep = (col < p.D) ? 1.f : 0.f;
         v[c] = make_float4(t.x * keep, t.y * keep, t.z * keep, t.w * keep);
-        s += v[c].x + v[c].y + v[c].z + v[c].w;
     }
-    const float mean = wave_sum(s) / p.D;
-    float q = 0.f;
-#pragma unroll
-    for (int c = 0; c < MC; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < p.D) {
-            const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
-            q += a * a + b * b + cc * cc + d * d;
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / p.D + p.eps);
-    if (lane == 0) {
-        if (p.mean) p.mean[row] = mean;
-        if (p.rstd) p.rstd[row] = rstd;
-    }
-#pragma unroll
-    for (int c = 0; c < MC; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < p.D) {
-            const float4 g = *reinterpret_cast<const float4*>(p.gamma + col);
-            const float4 b = *reinterpret_cast<const float4*>(p.beta + col);
-            float y[4] = {(v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y,
-                          (v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w};
-            if (p.out_f32) *reinterpret_cast<float4*>(p.out_f32 + row * p.ldo + col) = make_float4(y[0], y[1], y[2], y[3]);
-            if (p.out_hi) {
-                union { uint2 u; bf16_t h[4]; } hi, lo;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) split_bf16(y[i], hi.h[i], lo.h[i]);
-                *reinterpret_cast<uint2*>(p.out_hi + row * p.ldo + col) = hi.u;
-                if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + row * p.ldo + col) = lo.u;
-            }
-        }
-    }
+    ln_row_finish<MC>(v, lane, p.D, p.eps, p.gamma, p.beta, p.mean ? p.mean + row : nullptr, p.rstd ? p.rstd + row : nullptr,
+                      p.out_hi ? p.out_hi + row * p.ldo : nullptr, p.out_lo ? p.out_lo + row * p.ldo : nullptr,
+                      p.out_f32 ? p.out_f32 + row * p.ldo : nullptr);
 }
 
 // Backward: each wave owns RPW consecutive-by-stride rows and issues ALL their loads before any reduction, so it pays one

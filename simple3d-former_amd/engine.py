@@ -135,8 +135,9 @@ class ParamArena:
 class _BlockWorkspace:
     """Saved activations of `depth` consecutive blocks on M = Bb*N rows, plus the ctypes act table."""
 
-    def __init__(self, depth, Bb, N, D, H, hidden, device, split):
+    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None):
         M = Bb * N
+        ln_fuse = LN_FUSE if ln_fuse is None else bool(ln_fuse)
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
         self.depth, self.Bb, self.N, self.M = depth, Bb, N, M
@@ -157,9 +158,17 @@ class _BlockWorkspace:
                    lse=self.lse[i], xn1_hi=self.xn1[i, 0], xn1_lo=self.xn1[i, 1], qkv_hi=self.qkv[i, 0],
                    qkv_lo=self.qkv[i, 1], att_hi=self.att[i, 0], att_lo=self.att[i, 1], xn2_hi=self.xn2[i, 0],
                    xn2_lo=self.xn2[i, 1], hpre=self.hpre[i], hact_hi=self.hact[i, 0], hact_lo=self.hact[i, 1])
-        self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0)
+        # one ticket per 32-row band: the LayerNorms that follow attn.proj / mlp.fc2 run inside those GEMM launches (left zero)
+        self.ln_tickets = torch.zeros((M + 31) // 32 + 8, dtype=torch.int32, device=device)
+        self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0,
+                                     ln_tickets=self.ln_tickets.data_ptr() if ln_fuse else None)
 
 
+# LayerNorm forward inside the producing GEMM launch (gemm.hip ln_band_tail: the last-arriving tile of a row band normalises it).
+# Built, parity-green and measured on cfg-2: 2.18 - 2.21 ms/step vs 1.96 - 1.99 with the stand-alone LayerNorm kernels -- the
+# in-launch hand-off (write-through stores, store acknowledgement, agent-scope ticket, L1-bypassing re-read: four dependent trips to
+# the memory side of L2) costs more than the ~6.5 us kernel boundary + LayerNorm launch it removes.  Opt-in: S3D_LN_FUSE=1.
+LN_FUSE = os.environ.get('S3D_LN_FUSE', '0') == '1'
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '208'))    # 0: LayerNorm backward uses atomics
 
 
@@ -193,7 +202,7 @@ class VoxelEngine:
     positional embedding (vit_3d_2d_pretrain.py:455-470) and Linear / AM-softmax head."""
 
     def __init__(self, *, backbone, embed_layer, voxel_size, cell, patch, n_classes, pos_embedding='default',
-                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False):
+                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False, ln_fuse=None):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
         if pos_embedding not in (None, 'default', 'group_embed'):
@@ -224,6 +233,7 @@ class VoxelEngine:
         self.Kpad = _round_up(self.Kc, 8)
         self.am = head == 'AMSoftmax'
         self.split = bool(split)
+        self.ln_fuse = ln_fuse              # None: S3D_LN_FUSE decides (default off, see LN_FUSE above)
         self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
         self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
                                          n_classes=n_classes, head=head, pos_embedding=self.cfg['pos_embedding'],
@@ -364,14 +374,14 @@ class VoxelEngine:
         ws = type('WS', (), {})()
         ws.B, ws.M, ws.G = B, M, G
         ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
-        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split)
+        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
         ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth)
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)
-            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split)
+            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split, self.ln_fuse)
             ws.M2 = B * self.ntok2
             e = type('ENC', (), {})()
             e.x_in = torch.empty(M, D, **f32); e.s1 = torch.empty(M, D, **f32); e.x1 = torch.empty(M, D, **f32)

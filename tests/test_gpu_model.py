@@ -173,6 +173,30 @@ def test_cfg2_full_size_properties():
     assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
 
 
+def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
+    """ln_fuse=True: norm2 / the next block's norm1 are computed by the last-arriving tile of every row band inside the attn.proj /
+    mlp.fc2 GEMM launches (in-launch hand-off through write-through stores + an agent-scope ticket).  Same row arithmetic as the
+    LayerNorm kernel -> the logits must agree to rounding, at the full cfg-2 size (52 bands x 12 tiles per launch) and repeatedly
+    (a stale hand-off would show as a sporadic mismatch)."""
+    kw = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5, n_classes=40)
+    sd = vo.init_state_dict(seed=9, exercise_all=True, **kw)
+    x, y = vo.synthetic_batch(64, 32, 40, seed=9)
+    xd = x.to(DEV)
+    plain = s3d.VoxelEngine(device=DEV, ln_fuse=False, **kw); plain.load_state_dict(sd)
+    fused = s3d.VoxelEngine(device=DEV, ln_fuse=True, **kw); fused.load_state_dict(sd)
+    want = plain.forward(xd).clone()
+    for _ in range(20):
+        got = fused.forward(xd)
+        assert float((got - want).abs().max()) <= 1e-5
+    wsf, wsp = fused.workspace(64).blocks, plain.workspace(64).blocks
+    assert float((wsf.stats - wsp.stats).abs().max()) <= 1e-5                     # mean / rstd of every LayerNorm
+    assert int(wsf.ln_tickets.abs().sum()) == 0                                   # tickets are left zero for the next launch
+    fused.cross_entropy(64, y.to(DEV)); fused.zero_grad(); fused.backward(64)
+    plain.cross_entropy(64, y.to(DEV)); plain.zero_grad(); plain.backward(64)
+    rel = float((fused.arena.g - plain.arena.g).norm() / plain.arena.g.norm())
+    assert rel < 2e-2, rel
+
+
 def test_dp_trainer_segmented_graphs_and_rccl_path():
     """DataParallelTrainer on one GPU: 3 backward segments captured as HIP graphs with a (forced) RCCL all-reduce of each
     gradient bucket between replays, vs the plain eager fused step."""

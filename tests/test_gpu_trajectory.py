@@ -68,7 +68,7 @@ def test_fifty_step_trajectory_tracks_the_oracle(deterministic):
         got_curve.append(loss); ref_curve.append(loss_ref)
         rel = abs(loss - loss_ref) / max(abs(loss_ref), 1e-6)
         worst = max(worst, rel)
-        assert rel <= 2e-2, f'step {step}: HIP loss {loss:.5f} vs oracle {loss_ref:.5f} (rel {rel:.3e})'
+        assert rel <= 5e-3, f'step {step}: HIP loss {loss:.5f} vs oracle {loss_ref:.5f} (rel {rel:.3e})'
     assert ref_curve[-1] < 0.9 * ref_curve[0], f'the oracle run did not train: {ref_curve[0]:.3f} -> {ref_curve[-1]:.3f}'
     # held-out synthetic batch: same class decisions, hence the same accuracy
     logits = eng.forward(x_held.to(DEV)).cpu()
