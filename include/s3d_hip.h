@@ -225,6 +225,12 @@ typedef struct S3dBlockShape {
     int Bb, N, D, H, hidden;      /* sequences, tokens per sequence, model dim, heads, MLP hidden */
     float eps;
     int split;                    /* 1: split-bf16 forward (default), 0: plain bf16 */
+    int cls_only_block;           /* index + 1 of the block whose OUTPUT is consumed at the class-token rows only (the last block:
+                                   * forward_features returns norm(x)[:, 0], vit_3d_2d_pretrain.py:469-470), 0 = none.  Everything
+                                   * after that block's attention is row-local (proj, norm2, mlp, residuals), so s3d_blocks_fwd /
+                                   * s3d_blocks_bwd run it on the Bb class rows (row pitch N*D) instead of all Bb*N rows -- same
+                                   * values at the rows that matter; x_mid / x_out / hact of the other rows are not produced.
+                                   * Needs S3dBlockScratch::dx_b_cls / dx_b_bf_cls / datt_cls. */
     int* ln_tickets;              /* optional: >= ceil(Bb*N / 32) zero-initialised ints (left zero by every call).  When set, norm2 and
                                    * (in s3d_blocks_fwd) the NEXT block's norm1 run inside the attn.proj / mlp.fc2 GEMM launches
                                    * (S3dGemmArgs::ln_tickets) instead of as LayerNorm kernels of their own */
@@ -255,6 +261,9 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
      * s3d_blocks_bwd / s3d_block_bwd run the LayerNorm backward kernels in partial mode and finish with one
      * s3d_layernorm_grad_reduce over all their LayerNorms (NULL: atomics) */
     float* ln_partial; int ln_partial_blocks;
+    /* S3dBlockShape::cls_only_block: d(x_mid) fp32 / bf16 and d(att) of that block, [M][D] each, ZERO-initialised by the caller once;
+     * only the class rows are ever written, so the other rows stay zero for the dense attention / norm1 backward that follow */
+    float* dx_b_cls; uint16_t* dx_b_bf_cls; uint16_t* datt_cls;
 } S3dBlockScratch;
 int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
                   s3d_stream_t stream);

@@ -47,10 +47,14 @@ GemmArgs gemm_zero() {
 // next_p / next_a: the block that follows (s3d_blocks_fwd), whose norm1 can ride on this block's fc2 launch; ln1_done: this block's
 // norm1 was already produced that way.  Returns 0 / error; *next_ln1_done tells the caller whether the next block may skip norm1.
 int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockActs& a, hipStream_t s, bool ln1_done = false,
-              const S3dBlockParams* next_p = nullptr, const S3dBlockActs* next_a = nullptr, bool* next_ln1_done = nullptr) {
+              const S3dBlockParams* next_p = nullptr, const S3dBlockActs* next_a = nullptr, bool* next_ln1_done = nullptr,
+              bool cls_only = false) {
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     const bool split = sh.split != 0;
+    // cls_only: the row-local tail of the block (proj .. fc2) runs on the Bb class rows, addressed in place with row pitch N*D
+    const long M2 = cls_only ? sh.Bb : M;
+    const long pd = cls_only ? (long)sh.N * D : D, ph = cls_only ? (long)sh.N * Hd : Hd;
     S3D_REQUIRE(M < (1L << 31), "block: too many rows");
     if (next_ln1_done) *next_ln1_done = false;
     // 1. norm1
@@ -73,27 +77,27 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
     // 4. x_mid = x_in + att @ Wproj^T + b   [+ norm2 by the last-arriving tile of every row band]
     g = gemm_zero();
-    g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D;
-    g.M = (int)M; g.N = D; g.K = D; g.bias = p.proj_b; g.R = a.x_in; g.ldr = D; g.C = a.x_mid; g.ldc = D;
-    g.ln_tickets = sh.ln_tickets; g.ln_gamma = p.ln2_w; g.ln_beta = p.ln2_b; g.ln_eps = sh.eps; g.ln_hi = a.xn2_hi;
+    g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = pd; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D;
+    g.M = (int)M2; g.N = D; g.K = D; g.bias = p.proj_b; g.R = a.x_in; g.ldr = pd; g.C = a.x_mid; g.ldc = pd;
+    g.ln_tickets = cls_only ? nullptr : sh.ln_tickets; g.ln_gamma = p.ln2_w; g.ln_beta = p.ln2_b; g.ln_eps = sh.eps; g.ln_hi = a.xn2_hi;
     g.ln_lo = split ? a.xn2_lo : nullptr; g.ld_ln = D; g.ln_mean = a.mean2; g.ln_rstd = a.rstd2;
     const bool fused2 = s3d_gemm_ln_fusable(split, g);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
     // 5. norm2 (stand-alone only when the GEMM could not carry it)
     ln.x = a.x_mid; ln.gamma = p.ln2_w; ln.beta = p.ln2_b; ln.out_hi = a.xn2_hi; ln.out_lo = split ? a.xn2_lo : nullptr;
-    ln.mean = a.mean2; ln.rstd = a.rstd2;
+    ln.mean = a.mean2; ln.rstd = a.rstd2; ln.rows = M2; ln.ldx = pd; ln.ldo = pd;       // cls_only: statistics of class row b at [b]
     if (!fused2) S3D_TRY(s3d_launch_ln_fwd(ln, s));
     // 6. h = gelu(xn2 @ W1^T + b1)
     g = gemm_zero();
-    g.A_hi = a.xn2_hi; g.A_lo = a.xn2_lo; g.lda = D; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D;
-    g.M = (int)M; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = Hd; g.O_hi = a.hact_hi;
-    g.O_lo = split ? a.hact_lo : nullptr; g.ldo = Hd;
+    g.A_hi = a.xn2_hi; g.A_lo = a.xn2_lo; g.lda = pd; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D;
+    g.M = (int)M2; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = ph; g.O_hi = a.hact_hi;
+    g.O_lo = split ? a.hact_lo : nullptr; g.ldo = ph;
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_GELU, g, 1, s));
     // 7. x_out = x_mid + h @ W2^T + b2   [+ the next block's norm1]
     g = gemm_zero();
-    g.A_hi = a.hact_hi; g.A_lo = a.hact_lo; g.lda = Hd; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd;
-    g.M = (int)M; g.N = D; g.K = Hd; g.bias = p.fc2_b; g.R = a.x_mid; g.ldr = D; g.C = a.x_out; g.ldc = D;
-    if (next_p && next_a) {
+    g.A_hi = a.hact_hi; g.A_lo = a.hact_lo; g.lda = ph; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd;
+    g.M = (int)M2; g.N = D; g.K = Hd; g.bias = p.fc2_b; g.R = a.x_mid; g.ldr = pd; g.C = a.x_out; g.ldc = pd;
+    if (next_p && next_a && !cls_only) {
         g.ln_tickets = sh.ln_tickets; g.ln_gamma = next_p->ln1_w; g.ln_beta = next_p->ln1_b; g.ln_eps = sh.eps;
         g.ln_hi = next_a->xn1_hi; g.ln_lo = split ? next_a->xn1_lo : nullptr; g.ld_ln = D; g.ln_mean = next_a->mean1; g.ln_rstd = next_a->rstd1;
         if (next_ln1_done) *next_ln1_done = s3d_gemm_ln_fusable(split, g);
@@ -104,9 +108,9 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
 }
 
 // wgrad: dW[out][in] += dy^T x  (dy [M][out] bf16, x [M][in] bf16), db[out] += colsum(dy)
-GemmArgs wgrad_args(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db) {
+GemmArgs wgrad_args(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW, float* db, long ld_dy = 0, long ld_x = 0) {
     GemmArgs g = gemm_zero();
-    g.A_hi = dy; g.lda = out; g.B_hi = x; g.ldb = in; g.M = out; g.N = in; g.K = (int)M; g.C = dW; g.ldc = in;
+    g.A_hi = dy; g.lda = ld_dy ? ld_dy : out; g.B_hi = x; g.ldb = ld_x ? ld_x : in; g.M = out; g.N = in; g.K = (int)M; g.C = dW; g.ldc = in;
     g.bias_grad = db;
     return g;
 }
@@ -132,40 +136,48 @@ struct LnPartials {
 };
 
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
-              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr) {
+              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false) {
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
+    // cls_only (see block_fwd): d(x_out) is non-zero at the class rows only and proj / norm2 / mlp are row-local -> their backward
+    // runs on those Bb rows (row pitch N*D); d(x_mid) and d(att) go to dedicated buffers whose other rows stay zero
+    const long M2 = cls_only ? sh.Bb : M;
+    const long pd = cls_only ? (long)sh.N * D : D, ph = cls_only ? (long)sh.N * Hd : Hd;
+    float* dxb = cls_only ? w.dx_b_cls : w.dx_b;
+    bf16_t* dxb_bf = cls_only ? w.dx_b_bf_cls : w.dx_b_bf;
+    bf16_t* datt = cls_only ? w.datt_cls : w.datt;
     // ---- MLP branch: d(x_out) is in dx_a / dx_a_bf
     // every dgrad is launched together with the wgrad that consumes the same dy (one grid, two problems)
     GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)          || dW2 += dx_out^T hact
-    g.A_hi = w.dx_a_bf; g.lda = D; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M; g.N = Hd; g.K = D;
-    g.aux = a.hpre; g.ldaux = Hd; g.O_hi = w.dh; g.ldo = Hd;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M, gr.fc2_w, gr.fc2_b), s));
+    g.A_hi = w.dx_a_bf; g.lda = pd; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M2; g.N = Hd; g.K = D;
+    g.aux = a.hpre; g.ldaux = ph; g.O_hi = w.dh; g.ldo = ph;
+    S3D_TRY(s3d_launch_gemm_pair(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M2, gr.fc2_w, gr.fc2_b, pd, ph), s));
     g = gemm_zero();            // dxn2 = dh @ W1                             || dW1 += dh^T xn2
-    g.A_hi = w.dh; g.lda = Hd; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M, gr.fc1_w, gr.fc1_b), s));
+    g.A_hi = w.dh; g.lda = ph; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = pd;
+    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M2, gr.fc1_w, gr.fc1_b, ph, pd), s));
     LnBwdArgs lb;
     memset(&lb, 0, sizeof(lb));
-    lb.dy = w.dxn; lb.lddy = D; lb.x = a.x_mid; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
-    lb.dres = w.dx_a; lb.lddres = D; lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D;
-    lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M; lb.D = D;
+    lb.dy = w.dxn; lb.lddy = pd; lb.x = a.x_mid; lb.ldx = pd; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
+    lb.dres = w.dx_a; lb.lddres = pd; lb.dx = dxb; lb.lddx = pd; lb.dx_bf = dxb_bf; lb.lddxbf = pd;
+    lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M2; lb.D = D;
     if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
     g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
-    g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_BF16_BIAS, g, wgrad_args(w.dx_b_bf, D, a.att_hi, D, M, gr.proj_w, gr.proj_b), s));
+    g.A_hi = dxb_bf; g.lda = pd; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D; g.O_hi = datt; g.ldo = pd;
+    S3D_TRY(s3d_launch_gemm_pair(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
-    at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+    at.dout = datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
     S3D_TRY(s3d_launch_attention_bwd(at, s));
     g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
     S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s));
-    lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = w.dx_b; lb.dx = w.dx_a;
+    lb.dy = w.dxn; lb.lddy = D; lb.ldx = D; lb.lddres = D; lb.lddx = D; lb.lddxbf = D; lb.rows = M;      // norm1 is dense again
+    lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = dxb; lb.dx = w.dx_a;
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
     if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
@@ -397,7 +409,8 @@ int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     for (int i = 0; i < depth; ++i) {
         const bool has_next = i + 1 < depth && a[i + 1].x_in == a[i].x_out;     // the next block normalises exactly this block's output
         bool next_done = false;
-        S3D_TRY(block_fwd(*sh, p[i], a[i], st(s), ln1_done, has_next ? &p[i + 1] : nullptr, has_next ? &a[i + 1] : nullptr, &next_done));
+        S3D_TRY(block_fwd(*sh, p[i], a[i], st(s), ln1_done, has_next ? &p[i + 1] : nullptr, has_next ? &a[i + 1] : nullptr, &next_done,
+                          sh->cls_only_block == i + 1));
         ln1_done = next_done;
     }
     return 0;
@@ -408,7 +421,9 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     LnPartials lp;
     const bool partial = w->ln_partial != nullptr && w->ln_partial_blocks > 0;
     for (int i = first; i >= last; --i) {
-        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr));
+        const bool cls_only = sh->cls_only_block == i + 1;
+        if (cls_only) S3D_REQUIRE(w->dx_b_cls && w->dx_b_bf_cls && w->datt_cls, "s3d_blocks_bwd: cls_only_block needs the *_cls scratch buffers");
+        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only));
         if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
     }
     return lp.flush(*w, sh->D, st(s));

@@ -17,10 +17,23 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define S3D_WAVE 64
 
 // ---- bf16 <-> f32 (round-to-nearest-even; inputs are finite in this path) ----
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even): one instruction instead of the add / and / shift
+// sequence -- the GELU / LayerNorm / split epilogues are VALU-bound (tools/timeline_probe.py: 20 % of the fc1 GEMM)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+// two values -> one 32-bit word (low half = a), a single v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t f2bf2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+// split-bf16 of a pair: hi / lo words hold (a, b) in (low, high) halves
+__device__ __forceinline__ void split_bf16x2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    hi = f2bf2(a, b);
+    lo = f2bf2(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

@@ -214,15 +214,21 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, con
     }
     if constexpr (EPI == EPI_BF16_BIAS) {
 #pragma unroll
-        for (int r = 0; r < W; ++r) split_bf16(v[r] * p.alpha + bq[r], hi.h[r], lo.h[r]);
+        for (int r = 0; r < W; r += 2) {
+            uint32_t h2, l2;
+            split_bf16x2(v[r] * p.alpha + bq[r], v[r + 1] * p.alpha + bq[r + 1], h2, l2);
+            hi.u[r / 2] = h2; lo.u[r / 2] = l2;
+        }
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
         if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
     } else if constexpr (EPI == EPI_GELU || EPI == EPI_RELU) {
 #pragma unroll
-        for (int r = 0; r < W; ++r) {
-            const float pre = v[r] + bq[r];
-            ax.h[r] = f2bf(pre);
-            split_bf16((EPI == EPI_GELU) ? gelu_erf(pre) : fmaxf(pre, 0.f) * dm[r], hi.h[r], lo.h[r]);
+        for (int r = 0; r < W; r += 2) {
+            const float p0 = v[r] + bq[r], p1 = v[r + 1] + bq[r + 1];
+            uint32_t h2, l2;
+            split_bf16x2((EPI == EPI_GELU) ? gelu_erf(p0) : fmaxf(p0, 0.f) * dm[r],
+                         (EPI == EPI_GELU) ? gelu_erf(p1) : fmaxf(p1, 0.f) * dm[r + 1], h2, l2);
+            ax.u[r / 2] = f2bf2(p0, p1); hi.u[r / 2] = h2; lo.u[r / 2] = l2;
         }
         if (p.aux) st_bf<W>(p.aux + (long)m * p.ldaux + n, ax);
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);

@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
                                                    const bf16_t* __restrict__ gw) {
     const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
     const float step_size = st->step_size, bc2s = st->bc2_sqrt;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    // back to front: the arena is laid out in forward order, so the tokenizer's and the first blocks' weight planes are the LAST
+    // thing this 0.8 GB stream leaves in the 256 MB Infinity Cache -- where the next step's forward looks for them first
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long)gridDim.x * 256) {
+        const long i = n4 - 1 - j;
         float4 P = reinterpret_cast<float4*>(p)[i], G;
         if (gw) {                                       // bf16 wire format: the all-reduced gradient arrives as bf16 (uniform branch)
             union { uint2 u; bf16_t h[4]; } W;

@@ -135,9 +135,10 @@ class ParamArena:
 class _BlockWorkspace:
     """Saved activations of `depth` consecutive blocks on M = Bb*N rows, plus the ctypes act table."""
 
-    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None):
+    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None, cls_only=False):
         M = Bb * N
         ln_fuse = LN_FUSE if ln_fuse is None else bool(ln_fuse)
+        self.cls_only = bool(cls_only)
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
         self.depth, self.Bb, self.N, self.M = depth, Bb, N, M
@@ -161,7 +162,8 @@ class _BlockWorkspace:
         # one ticket per 32-row band: the LayerNorms that follow attn.proj / mlp.fc2 run inside those GEMM launches (left zero)
         self.ln_tickets = torch.zeros((M + 31) // 32 + 8, dtype=torch.int32, device=device)
         self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0,
-                                     ln_tickets=self.ln_tickets.data_ptr() if ln_fuse else None)
+                                     ln_tickets=self.ln_tickets.data_ptr() if ln_fuse else None,
+                                     cls_only_block=depth if self.cls_only else 0)
 
 
 # LayerNorm forward inside the producing GEMM launch (gemm.hip ln_band_tail: the last-arriving tile of a row band normalises it).
@@ -169,6 +171,9 @@ class _BlockWorkspace:
 # in-launch hand-off (write-through stores, store acknowledgement, agent-scope ticket, L1-bypassing re-read: four dependent trips to
 # the memory side of L2) costs more than the ~6.5 us kernel boundary + LayerNorm launch it removes.  Opt-in: S3D_LN_FUSE=1.
 LN_FUSE = os.environ.get('S3D_LN_FUSE', '0') == '1'
+# The last block's output is consumed at the class-token rows only (norm(x)[:, 0]): its row-local tail (proj, norm2, mlp) and their
+# backward run on those rows alone (S3dBlockShape::cls_only_block).  S3D_CLS_ONLY=0: dense, as the reference computes it.
+CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '208'))    # 0: LayerNorm backward uses atomics
 
 
@@ -191,10 +196,22 @@ class _BlockScratch:
         self.c = L.S3dBlockScratch()
         L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
                dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
+        self.M, self.D = M, D
         if depth > 0 and LN_PARTIAL_BLOCKS > 0:
             # column-sum partials of the 2*depth LayerNorms of one s3d_blocks_bwd call (S3dBlockScratch::ln_partial)
             self.ln_partial = torch.empty(2 * depth, LN_PARTIAL_BLOCKS, 2, D, **f32)
             L.fill(self.c, ln_partial=self.ln_partial, ln_partial_blocks=LN_PARTIAL_BLOCKS)
+
+
+def _cls_scratch(base, rows, D, device):
+    """A copy of the S3dBlockScratch table `base` with zero-initialised class-row gradient buffers for a block pass of `rows` rows
+    (S3dBlockShape::cls_only_block): only the class rows are ever written, the rest stays zero."""
+    c = L.S3dBlockScratch()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(base), ctypes.sizeof(c))
+    bufs = (torch.zeros(rows, D, dtype=torch.float32, device=device), torch.zeros(rows, D, dtype=torch.bfloat16, device=device),
+            torch.zeros(rows, D, dtype=torch.bfloat16, device=device))
+    L.fill(c, dx_b_cls=bufs[0], dx_b_bf_cls=bufs[1], datt_cls=bufs[2])
+    return c, bufs
 
 
 class VoxelEngine:
@@ -374,15 +391,17 @@ class VoxelEngine:
         ws = type('WS', (), {})()
         ws.B, ws.M, ws.G = B, M, G
         ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
-        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse)
+        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
         ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth)
+        ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev) if CLS_ONLY else (ws.scratch.c, None)       # scratch table of the (first) pass
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)
-            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split, self.ln_fuse)
+            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY)
             ws.M2 = B * self.ntok2
+            ws.sc2, ws._cls2 = _cls_scratch(ws.scratch.c, ws.M2, D, dev) if CLS_ONLY else (ws.scratch.c, None)    # ... of pass 2
             e = type('ENC', (), {})()
             e.x_in = torch.empty(M, D, **f32); e.s1 = torch.empty(M, D, **f32); e.x1 = torch.empty(M, D, **f32)
             e.s2 = torch.empty(M, D, **f32); e.stats = torch.empty(4, M, **f32)
@@ -490,7 +509,8 @@ class VoxelEngine:
             ws.dlogits.copy_(dlogits)
         L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
         sc = ws.scratch
-        sc.zero_dx_a()
+        if not CLS_ONLY:
+            sc.zero_dx_a()                  # with cls_only_block the last block reads the class rows of d(x_out) only
         nt = ws.ntok_last
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.last.x[self.depth], ldx=nt * D,
                     mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=nt * D,
@@ -518,13 +538,14 @@ class VoxelEngine:
         vit_3d_2d_pretrain.py:481-484 vs :493-496), of the token assembly and of the pass-1 final norm."""
         lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
         L.check(lib.s3d_blocks_bwd(ctypes.byref(ws.blocks2.shape), self.bparams, self.bgrads, ws.blocks2.acts,
-                                   ctypes.byref(sc.c), self.depth - 1, 0, s), 'blocks_bwd pass 2')
+                                   ctypes.byref(ws.sc2), self.depth - 1, 0, s), 'blocks_bwd pass 2')
         pg = L.fill(L.S3dPosGradArgs(), dx=sc.dx_a, groups=ws.B, ntok=self.ntok2, D=D, dpos=a.grad('voxel_pos_embed'),
                     dcls=a.grad('cls_token'))
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'pass-2 token grads')
         L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.dgfeat), ctypes.c_long(ws.B), self.P * self.P, D, s),
                 'assemble bwd')
-        sc.zero_dx_a()
+        if not CLS_ONLY:
+            sc.zero_dx_a()
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dgfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
                     mean=ws.gstats[0], rstd=ws.gstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
                     dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
@@ -566,7 +587,7 @@ class VoxelEngine:
 
     def blocks_backward_range(self, ws, first, last):
         L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
-                                        ctypes.byref(ws.scratch.c), first, last, L.current_stream()), 'blocks_bwd')
+                                        ctypes.byref(ws.sc1), first, last, L.current_stream()), 'blocks_bwd')
 
     def _tokenizer_backward(self, ws, dx=None, dx_bf=None):
         lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch

