@@ -609,8 +609,17 @@ constexpr int TL_SLOTS = 40;
 // WM x WN waves (4 or 8 waves = 256 or 512 threads) each own a (BM / WM) x (BN / WN) sub-tile.  The k-loop of these launches runs at
 // the rate the CU can pull operand bytes out of L2 (tools/probes/dma_bw_probe: ~20 TB/s chip-wide whatever the ring depth), so the
 // lever is bytes per flop: one fat workgroup per CU (128x96 / 64x128 with eight waves) moves 2-2.6x fewer bytes than 2-5 thin ones.
-template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2>
+// ILV: the DMA pieces of the stage being prefetched are issued one at a time BETWEEN the MFMA groups of the current k-tile instead of
+// in one burst before them: a wave that issues a burst of global_load_lds sits in the issue stage until the memory pipeline has taken
+// every piece (tools/timeline_probe.py: 2.5 k cycles for seven pieces on a fat tile), and only then starts its MFMAs.
+// MODE 2 (PIPE): software-pipelined fragments.  In the plain loop every wave of the workgroup passes the k-tile barrier, reads its
+// fragments, waits for them and only then feeds the matrix pipe: with one fat workgroup per CU all waves are in the same phase, the
+// LDS-read phase (~500 cycles for a 128x128 split tile) and the MFMA phase (~800) add up (measured 1.7 k cycles per k = 32 step).
+// Here the fragments of sub-step s+1 are requested BEFORE the MFMAs of sub-step s are issued (two register sets), across the
+// stage boundary too: [stage t+1 landed: counted vmcnt + barrier] -> refill the ring -> read fragments(t+1) -> MFMAs(t).
+template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2, int MODE = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArgs p) {
+    constexpr bool ILV = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
     static_assert((NPL * (BM + BN) * BK * 2) % 4096 == 0, "a stage must split into whole 1 KB pieces per wave");
@@ -675,13 +684,85 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
     for (int u = 0; u < NS - 1; ++u)
         if (u < ntiles) issue(u);
     TL_STAMP(3);
+    if constexpr (MODE == 2) {
+        static_assert(MODE != 2 || NS >= 3, "the pipelined loop refills the buffer of stage t-1 while stage t is being consumed");
+        constexpr int KS = BK / 32;
+        bf16x8 fa[2][SPLIT ? 2 : 1][FM], fb[2][SPLIT ? 2 : 1][FN];
+        // `set` is a compile-time tag everywhere: a run-time index into the two register sets would push them to scratch memory
+        auto load_frags = [&](auto set_tag, int t, int ks) {
+            constexpr int set = decltype(set_tag)::value;
+            const unsigned char* sA = smem + (t % NS) * STAGE;
+            const unsigned char* sB = sA + NPL * A_BYTES;
+            const int kc = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wm * TM + i * 16 + (lane & 15);
+                fa[set][0][i] = frag(sA, r, kc);
+                if constexpr (SPLIT) fa[set][1][i] = frag(sA + A_BYTES, r, kc);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = wn * TN + j * 16 + (lane & 15);
+                fb[set][0][j] = frag(sB, r, kc);
+                if constexpr (SPLIT) fb[set][1][j] = frag(sB + B_BYTES, r, kc);
+            }
+        };
+        auto mfmas = [&](auto set_tag) {
+            constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (SPLIT) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][0][j], fa[set][1][i], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][1][j], fa[set][0][i], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][0][j], fa[set][0][i], acc[i][j], 0, 0, 0);
+                }
+        };
+        // one sub-step: request the NEXT fragment set (crossing into stage t+1 when ks is the stage's last sub-step), then the MFMAs
+        auto substep = [&](auto cur_tag, int t, int ks) {
+            constexpr int cur = decltype(cur_tag)::value;
+            using Nxt = std::integral_constant<int, cur ^ 1>;
+            if (ks + 1 < KS) {
+                load_frags(Nxt{}, t, ks + 1);
+            } else if (t + 1 < ntiles) {
+                // stage t+1 must have landed: stages up to t+NS-2 are in flight -> at most NS-3 younger ones may stay outstanding
+                if (t + NS - 2 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                       // ... for every wave; and nobody reads stage t-1 any more
+                TL_STAMP(8 + t + 1);
+                if (t + NS - 1 < ntiles) issue(t + NS - 1);            // into the buffer of stage t-1
+                load_frags(Nxt{}, t + 1, 0);
+            }
+            mfmas(cur_tag);
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // stage 0 landed -> first fragment set
+        if (ntiles >= NS - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        TL_STAMP(8);
+        load_frags(S0{}, 0, 0);
+        if constexpr (KS == 2) {
+            for (int t = 0; t < ntiles; ++t) { substep(S0{}, t, 0); substep(S1{}, t, 1); }
+        } else {
+            int t = 0;
+            for (; t + 1 < ntiles; t += 2) { substep(S0{}, t, 0); substep(S1{}, t + 1, 0); }
+            if (t < ntiles) substep(S0{}, t, 0);
+        }
+    } else
     for (int t = 0; t < ntiles; ++t) {
         // stage t is complete once at most the younger stages' pieces of this wave are outstanding
         if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                               // everyone's pieces landed; buffer (t-1) % NS is free
         TL_STAMP(8 + t);                                               // tile t landed for the whole workgroup
-        if (t + NS - 1 < ntiles) issue(t + NS - 1);
+        const bool pre = t + NS - 1 < ntiles;
+        if constexpr (!ILV) { if (pre) issue(t + NS - 1); }
+        const unsigned dst_n = lds0 + (unsigned)(((t + NS - 1) % NS) * STAGE + wave * PPW * 1024);
+        constexpr int GROUPS = (BK / 32) * FM * FN;                    // MFMA groups (one output block each) per k-tile
         const unsigned char* sA = smem + (t % NS) * STAGE;
         const unsigned char* sB = sA + NPL * A_BYTES;
 #pragma unroll
@@ -709,6 +790,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], acc[i][j], 0, 0, 0);
                     }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+                    if constexpr (ILV) {
+                        const int g = (ks * FM + i) * FN + j;          // compile-time after unrolling
+#pragma unroll
+                        for (int q = 0; q < PPW; ++q)
+                            if (q * GROUPS / PPW == g && pre) glds16(gp[q] + (long)(t + NS - 1) * BK, dst_n + q * 1024);
+                        __builtin_amdgcn_sched_barrier(0);             // keep the pieces where they were placed
+                    }
                 }
         }
     }
@@ -1021,13 +1109,12 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
 }
 
 // the forward DMA kernel on the small cfg-2 tiles (k = 64 stages)
-template <bool SPLIT, int EPI, int BM, int BN, int NS, int WM = 2, int WN = 2>
+template <bool SPLIT, int EPI, int BM, int BN, int NS, int WM = 2, int WN = 2, int ILV = 0, int BK = 64>
 int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BK = 64;
     constexpr int STAGE = (SPLIT ? 2 : 1) * (BM + BN) * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, BM * (BN + 4) * 4);
     static_assert(LDS <= 160 * 1024, "stage ring exceeds the CU's LDS");
-    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN>;
+    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1138,11 +1225,26 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // cfg-2, us: qkv 12.1 -> 9.7, proj 7.8 -> 6.4, fc1 18.8 -> 16.2, fc2 19.8 -> 14.6; three stages or k = 32 stages were neutral.
         static const int dma_small = env_int("S3D_GEMM_DMA_SMALL");
         if (dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0) {
-            if (tile == 4) return launch_nt_dma_small<SPLIT, EPI, 128, 96, 2, 4, 2>(a, s);      // eight waves, one workgroup per CU
-            if (tile == 5) return launch_nt_dma_small<SPLIT, EPI, 64, 128, 3, 2, 4>(a, s);
-            if (tile == 6) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 4>(a, s);
-            if (tile == 7) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 2, 4, 2>(a, s);
-            if (tile == 8) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 3, 2, 2>(a, s);
+            if (tile == 4) return launch_nt_dma_small<SPLIT, EPI, 128, 96, 4, 2, 2, 1, 32>(a, s);   // deep ring of k = 32 stages
+            if (tile == 5) return launch_nt_dma_small<SPLIT, EPI, 64, 128, 4, 2, 4, 1, 32>(a, s);
+            if (tile == 11) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 4, 4, 2, 1, 32>(a, s);
+            if (tile == 14) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 4, 4, 4, 2, 32>(a, s);   // sixteen waves, pipelined fragments
+            if (tile == 15) return launch_nt_dma_small<SPLIT, EPI, 64, 192, 4, 4, 4, 2, 32>(a, s);
+            if (tile == 16) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 4, 4, 2, 2, 32>(a, s);   // eight waves, pipelined
+            if (tile == 17) return launch_nt_dma_small<SPLIT, EPI, 128, 96, 4, 2, 2, 2, 32>(a, s);    // four waves, pipelined
+            if (tile == 18) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 4, 2, 2, 2, 32>(a, s);
+            if (tile == 19) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 4, 2, 2, 2, 32>(a, s);
+            if (tile == 20) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 3, 2, 2, 0, 32>(a, s);     // 48 KB: three workgroups per CU
+            if (tile == 21) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 2, 2, 2, 0, 32>(a, s);     // 40 KB: four per CU
+            if (tile == 22) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 3, 2, 2, 0, 32>(a, s);     // 60 KB: two per CU
+            if (tile == 23) return launch_nt_dma_small<SPLIT, EPI, 64, 128, 2, 2, 2, 0, 32>(a, s);    // 48 KB: three per CU
+            if (tile == 12) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 4, 2, 2, 1, 32>(a, s);   // 64 KB: two workgroups per CU
+            if (tile == 13) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 4, 2, 2, 0, 32>(a, s);
+            if (tile == 6) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 2, 2, 2, 1>(a, s);
+            if (tile == 7) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 2, 4, 2, 1>(a, s);
+            if (tile == 8) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 2, 2, 2, 1>(a, s);
+            if (tile == 9) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2, 2, 2, 1>(a, s);
+            if (tile == 10) return launch_nt_dma_small<SPLIT, EPI, 32, 32, 2, 2, 2, 1>(a, s);
             if (tile == 1) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 2>(a, s);
             if (tile == 0) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2>(a, s);
             if (tile == 3) {

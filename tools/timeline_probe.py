@@ -19,7 +19,7 @@ from simple3d_former_amd import _lib as L, ops  # noqa: E402
 SLOTS = 40
 M, D = 1664, 384
 DEV = 'cuda'
-TILES = {0: (32, 64), 1: (64, 64), 3: (32, 32), 2: (128, 128), 4: (128, 96), 5: (64, 128), 6: (64, 64), 7: (128, 128), 8: (64, 96)}
+TILES = {0: (32, 64), 1: (64, 64), 3: (32, 32), 2: (128, 128), 4: (128, 96), 5: (64, 128), 6: (64, 64), 7: (128, 128), 8: (64, 96), 9: (32, 64), 10: (32, 32), 11: (128, 128), 12: (64, 64), 13: (32, 64), 14: (128, 128), 15: (64, 192), 16: (128, 128), 17: (128, 96), 18: (64, 64), 19: (32, 64)}
 
 
 def planes(r, c):
@@ -53,7 +53,7 @@ def run(name, N, K, epi, tile, cold):
     torch.cuda.synchronize()
     lib.s3d_debug_timeline_set(ctypes.c_void_p(0))
     t = buf.cpu().numpy().astype(np.int64)
-    nk = K // 64
+    nk = K // int(os.environ.get('TL_BK', '64'))
     real0, real1 = t[:, 0], t[:, 7]
     span = (real1.max() - real0.min()) * 10e-3                      # us (100 MHz)
     start = (real0 - real0.min()) * 10e-3
