@@ -199,6 +199,27 @@ typedef struct S3dCeArgs {
 } S3dCeArgs;
 int s3d_cross_entropy(const S3dCeArgs* args, s3d_stream_t stream);
 
+/* The loss end of the training step in two launches instead of six: final norm of the class rows (vit_3d_2d_pretrain.py:469-470)
+ * -> voxel_head Linear (:364) -> F.cross_entropy (train_cls_voxel.py:282-285) -> d(logits) -> d(feat) -> backward of the final
+ * norm, one workgroup per sample; then the reductions over the batch (head weight / bias gradients, gamma / beta gradients, the
+ * loss) with one writer per output -- deterministic, no atomics.  Same arithmetic as s3d_layernorm_fwd + s3d_head_fwd +
+ * s3d_cross_entropy + s3d_head_bwd + s3d_layernorm_bwd. */
+typedef struct S3dHeadLossArgs {
+    const float* x; long ldx;                 /* class row of sample b = x + b*ldx (the last block's output) */
+    int B, D, C; float eps;
+    const float* gamma; const float* beta;    /* final LayerNorm */
+    const float* W; const float* bias;        /* Linear head, W [C][D] */
+    const long long* target; const float* weight;   /* class indices [B]; optional class weights [C] */
+    float grad_scale;                          /* multiplies d(logits) (1 for plain training) */
+    float* feat; float* mean; float* rstd;    /* out: norm(x)[:, 0] [B][D] and its statistics [B] */
+    float* logits; float* dlogits;            /* out: [B][C] */
+    float* loss;                               /* out: loss[0] = (weighted) mean CE, loss[1] = its denominator */
+    float* dx; uint16_t* dx_bf; long lddx;    /* out: d(loss)/d(x) at the class rows, fp32 and bf16, row pitch lddx */
+    float* dW; float* dbias; float* dgamma; float* dbeta;   /* accumulated (+=) */
+    float* scratch;                            /* B * (2*D + 1) floats */
+} S3dHeadLossArgs;
+int s3d_head_loss_fused(const S3dHeadLossArgs* args, s3d_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * torch.optim.Adam(model.parameters(), lr) .step() (train_cls_voxel.py:195,288) over a flat parameter arena; also
  * refreshes the split-bf16 weight planes and (optionally) zeroes the gradients (optimizer.zero_grad(), :277). */

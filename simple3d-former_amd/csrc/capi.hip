@@ -299,7 +299,7 @@ const char* s3d_last_error_string(void) { return g_err; }
 size_t s3d_sizeof(const char* n) {
 #define SZ(T) if (strcmp(n, #T) == 0) return sizeof(T)
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
-    SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
+    SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dHeadLossArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
     SZ(S3dGroupProjArgs);
 #undef SZ
@@ -371,6 +371,10 @@ int s3d_head_fwd(const S3dHeadArgs* a, s3d_stream_t s) {
 int s3d_head_bwd(const S3dHeadArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_head_bwd: null args");
     return s3d_launch_head_bwd(*a, st(s));
+}
+int s3d_head_loss_fused(const S3dHeadLossArgs* a, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_head_loss_fused: null args");
+    return s3d_launch_head_loss(*a, st(s));
 }
 int s3d_cross_entropy(const S3dCeArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_cross_entropy: null args");

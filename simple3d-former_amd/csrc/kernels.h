@@ -36,6 +36,8 @@ int s3d_launch_head_bwd(const HeadArgs& a, hipStream_t s);
 typedef S3dCeArgs CeArgs;
 int s3d_launch_ce(const CeArgs& a, hipStream_t s);
 
+int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s);
+
 // ---- fused Adam over a flat fp32 arena (+ split-bf16 shadow planes) ----
 typedef S3dAdamState AdamState;
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,

@@ -338,6 +338,172 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
     if (lane == 0 && acc != 0.f) atomic_add_f32(p.loss, acc / den);
 }
 
+// ------------------------------------------------------------------------------------------- fused loss end of the step
+// block-wide sum of one float per thread (256 threads), result in every thread; `red` = 4 floats of LDS
+__device__ __forceinline__ float block_sum4(float v, float* red, int tid) {
+    v = wave_sum(v);
+    __syncthreads();                                   // `red` may still be read from the previous use
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one workgroup per sample: final norm -> logits -> cross entropy -> d(logits) -> d(feat) -> d(x) of the class row
+__global__ __launch_bounds__(256) void head_loss_sample_kernel(const S3dHeadLossArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* feat = reinterpret_cast<float*>(smem);      // [D]
+    float* xhat = feat + p.D;                           // [D]
+    float* dfe = xhat + p.D;                            // [D]
+    float* lg = dfe + p.D;                              // [C] logits, then d(logits)
+    float* red = lg + ((p.C + 3) & ~3);                 // [4]
+    float* Wl = red + 4;                                // [C][D] copy of the head weight (when it fits: p.scratch_w != 0)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x, D = p.D, C = p.C;
+    const float* x = p.x + (long)b * p.ldx;
+    const bool w_lds = (long)C * D * 4 <= 96 * 1024;    // uniform
+    if (w_lds) {                                        // every load of the copy is in flight before anything waits (latency-bound kernel)
+        const int n4 = C * D / 4;
+        for (int i0 = tid; i0 < n4; i0 += 256 * 8) {
+            f32x4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const f32x4*>(p.W)[min(i0 + u * 256, n4 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + u * 256 < n4) reinterpret_cast<f32x4*>(Wl)[i0 + u * 256] = t[u];
+        }
+    }
+    const float* Wsrc = w_lds ? Wl : p.W;
+    // ---- final LayerNorm of the class row (two-pass statistics, as ln_row_finish)
+    float xv[4], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int d = tid + i * 256; xv[i] = d < D ? x[d] : 0.f; s += xv[i]; }
+    const float mean = block_sum4(s, red, tid) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int d = tid + i * 256; if (d < D) { const float a = xv[i] - mean; q += a * a; } }
+    const float rstd = rsqrtf(block_sum4(q, red, tid) / D + p.eps);
+    if (tid == 0) { if (p.mean) p.mean[b] = mean; if (p.rstd) p.rstd[b] = rstd; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = tid + i * 256;
+        if (d < D) {
+            const float xh = (xv[i] - mean) * rstd, f = xh * p.gamma[d] + p.beta[d];
+            xhat[d] = xh; feat[d] = f;
+            if (p.feat) p.feat[(long)b * D + d] = f;
+            p.scratch[(long)b * (2 * D + 1) + D + d] = xh;
+        }
+    }
+    __syncthreads();
+    // ---- logits: one wave per class (round robin)
+    for (int c = wave; c < C; c += 4) {
+        const float* w = Wsrc + (long)c * D;
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += feat[d] * w[d];
+        dot = wave_sum(dot);
+        if (lane == 0) { const float l = dot + (p.bias ? p.bias[c] : 0.f); lg[c] = l; p.logits[(long)b * C + c] = l; }
+    }
+    // ---- denominator of the (weighted) mean: every workgroup derives it from the targets (B is a batch size)
+    float dsum = 0.f;
+    if (p.weight) for (int r = tid; r < p.B; r += 256) dsum += p.weight[p.target[r]];
+    const float den = p.weight ? block_sum4(dsum, red, tid) : (float)p.B;
+    __syncthreads();                                   // logits complete
+    // ---- cross entropy of the row (wave 0) and d(logits)
+    if (wave == 0) {
+        float mx = -INFINITY;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, lg[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int c = lane; c < C; c += 64) se += expf(lg[c] - mx);
+        se = wave_sum(se);
+        const long t = p.target[b];
+        const float w = p.weight ? p.weight[t] : 1.f, lse = mx + logf(se);
+        if (lane == 0) p.scratch[(long)b * (2 * D + 1) + 2 * D] = w * (lse - lg[t]) / den;       // this sample's share of the loss
+        float dl[4];                                     // C <= 256
+        for (int k = 0, c = lane; c < C; c += 64, ++k) dl[k] = p.grad_scale * w * (expf(lg[c] - lse) - (c == t ? 1.f : 0.f)) / den;
+        for (int k = 0, c = lane; c < C; c += 64, ++k) { lg[c] = dl[k]; p.dlogits[(long)b * C + c] = dl[k]; }
+    }
+    __syncthreads();
+    // ---- d(feat) = d(logits) . W, then the LayerNorm backward of the row
+    float g[4], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = tid + i * 256;
+        g[i] = 0.f;
+        if (d < D) {
+            float a0 = 0.f, a1 = 0.f;
+            int c = 0;
+            for (; c + 1 < C; c += 2) { a0 += lg[c] * Wsrc[(long)c * D + d]; a1 += lg[c + 1] * Wsrc[(long)(c + 1) * D + d]; }
+            if (c < C) a0 += lg[c] * Wsrc[(long)c * D + d];
+            const float df = a0 + a1;
+            p.scratch[(long)b * (2 * D + 1) + d] = df;
+            g[i] = df * p.gamma[d];
+            s1 += g[i]; s2 += g[i] * xhat[d];
+        }
+    }
+    s1 = block_sum4(s1, red, tid) / D;
+    s2 = block_sum4(s2, red, tid) / D;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = tid + i * 256;
+        if (d < D) {
+            const float dx = rstd * (g[i] - s1 - xhat[d] * s2);
+            if (p.dx) p.dx[(long)b * p.lddx + d] = dx;
+            if (p.dx_bf) p.dx_bf[(long)b * p.lddx + d] = f2bf(dx);
+        }
+    }
+}
+
+// reductions over the batch, one thread per output (fixed order: deterministic): dW [C][D], dbias [C], dgamma / dbeta [D], loss
+__global__ __launch_bounds__(256) void head_loss_reduce_kernel(const S3dHeadLossArgs p) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int D = p.D, C = p.C, B = p.B;
+    const long nw = (long)C * D, st = 2 * D + 1;
+    if (idx < nw) {
+        const int c = (int)(idx / D), d = (int)(idx % D);
+        // 16 independent load pairs per trip (clamped, masked): the sum over the batch is a latency chain otherwise (32 us at B = 64)
+        float acc = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            float dl[16], ft[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int bb = min(b0 + u, B - 1);
+                dl[u] = p.dlogits[(long)bb * C + c]; ft[u] = p.feat[(long)bb * D + d];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += (b0 + u < B) ? dl[u] * ft[u] : 0.f;
+        }
+        if (p.dW) p.dW[idx] += acc;
+    } else if (idx < nw + C) {
+        const int c = (int)(idx - nw);
+        float a = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            float dl[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) dl[u] = p.dlogits[(long)min(b0 + u, B - 1) * C + c];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += (b0 + u < B) ? dl[u] : 0.f;
+        }
+        if (p.dbias) p.dbias[c] += a;
+    } else if (idx < nw + C + 2 * D) {
+        const int j = (int)(idx - nw - C), d = j % D;
+        float a = 0.f;
+        for (int b0 = 0; b0 < B; b0 += 16) {
+            float df[16], xh[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const long bb = min(b0 + u, B - 1);
+                df[u] = p.scratch[bb * st + d]; xh[u] = (j < D) ? p.scratch[bb * st + D + d] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += (b0 + u < B) ? df[u] * xh[u] : 0.f;
+        }
+        if (j < D) { if (p.dgamma) p.dgamma[d] += a; } else { if (p.dbeta) p.dbeta[d] += a; }
+    } else if (idx == nw + C + 2 * D) {
+        float a = 0.f, den = (float)B;
+        for (int b = 0; b < B; ++b) a += p.scratch[b * st + 2 * D];
+        if (p.weight) { den = 0.f; for (int b = 0; b < B; ++b) den += p.weight[p.target[b]]; }
+        p.loss[0] = a; p.loss[1] = den;
+    }
+}
+
 // ------------------------------------------------------------------------------------------- Adam
 __global__ void adam_prelude_kernel(AdamState* st) {
     st->step += 1;
@@ -484,6 +650,21 @@ int s3d_launch_ce(const CeArgs& a, hipStream_t s) {
                                                                   // the parallel grid: only the reported loss value, never a gradient, depends on the order)
     hipLaunchKernelGGL(ce_main_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     S3D_CHECK_LAUNCH("cross_entropy");
+    return 0;
+}
+
+int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.x && a.gamma && a.beta && a.W && a.target && a.feat && a.logits && a.dlogits && a.loss && a.scratch,
+                "head_loss_fused: null argument");
+    S3D_REQUIRE(a.B > 0 && a.D > 0 && a.D <= 1024 && a.C > 0 && a.C <= 256, "head_loss_fused: B=%d D=%d (<= 1024) C=%d (<= 256)", a.B, a.D, a.C);
+    size_t lds = (size_t)(3 * a.D + ((a.C + 3) & ~3) + 4) * sizeof(float);
+    if ((long)a.C * a.D * 4 <= 96 * 1024) lds += (size_t)a.C * a.D * sizeof(float);       // the head weight rides along in LDS
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(head_loss_sample_kernel, dim3((unsigned)a.B), dim3(256), lds, s, a);
+    const long n = (long)a.C * a.D + a.C + 2 * a.D + 1;
+    hipLaunchKernelGGL(head_loss_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("head_loss_fused");
     return 0;
 }
 

@@ -174,6 +174,7 @@ LN_FUSE = os.environ.get('S3D_LN_FUSE', '0') == '1'
 # The last block's output is consumed at the class-token rows only (norm(x)[:, 0]): its row-local tail (proj, norm2, mlp) and their
 # backward run on those rows alone (S3dBlockShape::cls_only_block).  S3D_CLS_ONLY=0: dense, as the reference computes it.
 CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
+FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '208'))    # 0: LayerNorm backward uses atomics
 
 
@@ -433,6 +434,18 @@ class VoxelEngine:
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         """x: [B,1,V,V,V] float32 on the device (the trainer's voxel.float(), train_cls_voxel.py:276) -> logits."""
+        ws = self.forward_features(x)
+        a, lib, s, B = self.arena, self.lib, L.current_stream(), x.shape[0]
+        ln = L.fill(L.S3dLnArgs(), x=ws.last.x[self.depth], ldx=ws.ntok_last * self.D, rows=B, D=self.D, eps=LN_EPS,
+                    gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
+                    mean=ws.fstats[0], rstd=ws.fstats[1])
+        L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
+        L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
+        self._loss_end_done = False
+        return ws.logits
+
+    def forward_features(self, x):
+        """Everything up to the last block's output (the class rows of ws.last.x[depth] feed the final norm + head)."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(), 'voxel grid must be a contiguous fp32 device tensor'
         B, Cc, H, W, V = x.shape
         assert Cc == 1 and H == self.V and W == self.V and V == self.V, \
@@ -468,12 +481,28 @@ class VoxelEngine:
             L.check(lib.s3d_assemble_tokens(L.ptr(ws.gfeat), L.ptr(a.param('cls_token')), L.ptr(a.param('voxel_pos_embed')),
                                             L.ptr(ws.blocks2.x[0]), ctypes.c_long(B), self.P * self.P, self.D, s), 'assemble')
             L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks2.shape), self.bparams, ws.blocks2.acts, self.depth, s), 'blocks_fwd 2')
-        ln = L.fill(L.S3dLnArgs(), x=ws.last.x[self.depth], ldx=ws.ntok_last * self.D, rows=B, D=self.D, eps=LN_EPS,
-                    gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
-                    mean=ws.fstats[0], rstd=ws.fstats[1])
-        L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
-        L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
-        return ws.logits
+        return ws
+
+    def head_loss(self, B, target, weight=None, grad_scale=1.0):
+        """Final norm -> Linear head -> F.cross_entropy -> d(logits) -> d(feat) -> final-norm backward in two launches
+        (s3d_head_loss_fused) instead of six; leaves d(loss)/d(x_final) where backward() expects it.  Linear head only."""
+        assert not self.am, 'head_loss: the AM-softmax head takes the unfused kernels'
+        ws = self.workspace(B)
+        a, D, nt, sc = self.arena, self.D, ws.ntok_last, ws.scratch
+        assert target.dtype == torch.int64 and target.is_cuda
+        if not hasattr(ws, 'hl_scratch'):
+            ws.hl_scratch = torch.empty(B * (2 * D + 1), dtype=torch.float32, device=self.device)
+        if not CLS_ONLY:
+            sc.zero_dx_a()
+        hl = L.fill(L.S3dHeadLossArgs(), x=ws.last.x[self.depth], ldx=nt * D, B=B, D=D, C=self.C, eps=LN_EPS,
+                    gamma=a.param('norm.weight'), beta=a.param('norm.bias'), W=a.param('voxel_head.weight'),
+                    bias=a.param('voxel_head.bias'), target=target, weight=weight, grad_scale=grad_scale, feat=ws.feat,
+                    mean=ws.fstats[0], rstd=ws.fstats[1], logits=ws.logits, dlogits=ws.dlogits, loss=ws.loss, dx=sc.dx_a,
+                    dx_bf=sc.dx_a_bf, lddx=nt * D, dW=a.grad('voxel_head.weight'), dbias=a.grad('voxel_head.bias'),
+                    dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'), scratch=ws.hl_scratch)
+        L.check(self.lib.s3d_head_loss_fused(ctypes.byref(hl), L.current_stream()), 'head_loss_fused')
+        self._loss_end_done = True
+        return ws.loss[0]
 
     def _head_args(self, ws):
         a = self.arena
@@ -505,6 +534,9 @@ class VoxelEngine:
         """head backward + final-norm backward: leaves d(loss)/d(x_final) in the scratch ping-pong buffer."""
         ws = self.workspace(B)
         lib, s, a, D = self.lib, L.current_stream(), self.arena, self.D
+        if getattr(self, '_loss_end_done', False) and dlogits is None:
+            self._loss_end_done = False          # head_loss() already produced d(loss)/d(x_final) and the head / norm gradients
+            return ws
         if dlogits is not None and dlogits.data_ptr() != ws.dlogits.data_ptr():
             ws.dlogits.copy_(dlogits)
         L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
@@ -639,11 +671,18 @@ class VoxelEngine:
         HIP path.  Gradients are zeroed by the previous step's Adam kernel.  Returns the loss as a device scalar."""
         B = x.shape[0]
         self.advance_dropout_seed()                       # fresh masks every step (device-side, graph-replay safe)
-        self.forward(x)
-        loss = self.cross_entropy(B, target, weight)
+        loss = self.forward_loss(x, target, weight)
         self.backward(B)
         self.adam_step(zero_grad=True)
         return loss
+
+    def forward_loss(self, x, target, weight=None):
+        """model(voxel) + F.cross_entropy for a training step; with the Linear head the loss end runs fused (head_loss)."""
+        if self.am or not FUSE_LOSS_END:
+            self.forward(x)
+            return self.cross_entropy(x.shape[0], target, weight)
+        self.forward_features(x)
+        return self.head_loss(x.shape[0], target, weight)
 
     def lwf_train_step(self, x, target, img, img_target, lambda_weight=0.1, weight=None):
         """One learning-without-forgetting step (train_cls_voxel.py:240-268): loss = CE(model(voxel), cls_idx) +

@@ -105,8 +105,7 @@ class DataParallelTrainer:
     def step_eager(self, x, y, weight=None):
         eng, B = self.eng, x.shape[0]
         eng.advance_dropout_seed()
-        eng.forward(x)
-        loss = eng.cross_entropy(B, y, weight)
+        loss = eng.forward_loss(x, y, weight)
         eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
         self.reducer.wait()
         eng.adam_step(zero_grad=True, wire=self.wire)
@@ -117,8 +116,7 @@ class DataParallelTrainer:
         eng = self.eng
         if k == 0:
             eng.advance_dropout_seed()                                  # captured: every replay draws fresh masks
-            eng.forward(sx)
-            eng.cross_entropy(B, sy, weight)
+            eng.forward_loss(sx, sy, weight)
             ws = eng.backward_begin(B)
         else:
             ws = eng.workspace(B)

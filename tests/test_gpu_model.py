@@ -173,6 +173,31 @@ def test_cfg2_full_size_properties():
     assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
 
 
+@pytest.mark.parametrize('weighted', [False, True])
+def test_fused_loss_end_equals_the_six_kernel_chain(weighted):
+    """s3d_head_loss_fused (final norm -> head -> cross entropy -> d(logits) -> d(feat) -> final-norm backward + single-writer batch
+    reductions) against s3d_layernorm_fwd + s3d_head_fwd + s3d_cross_entropy + s3d_head_bwd + s3d_layernorm_bwd on the same model."""
+    cfg = dict(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed', voxel_size=12, cell=4, patch=3, n_classes=10,
+               pos_embedding='default', head='default', batch=7)
+    sd = vo.init_state_dict(seed=21, exercise_all=True, **{k: cfg[k] for k in MODEL_KEYS})
+    x, y = vo.synthetic_batch(7, 12, 10, seed=22)
+    w = (torch.rand(10, generator=torch.Generator().manual_seed(3)) + 0.5).to(DEV) if weighted else None
+    ref, eng = make_engine(cfg, sd), make_engine(cfg, sd)
+    ref.forward(x.to(DEV)); l_ref = float(ref.cross_entropy(7, y.to(DEV), w)); ref.zero_grad(); ref.backward(7)
+    eng.forward_features(x.to(DEV)); l_got = float(eng.head_loss(7, y.to(DEV), w)); eng.zero_grad()
+    # zero_grad wiped the head / norm gradients head_loss had accumulated: run it again on the clean arena, then the blocks
+    eng.head_loss(7, y.to(DEV), w); eng.backward(7)
+    wr, wg = ref.workspace(7), eng.workspace(7)
+    assert abs(l_ref - l_got) <= 1e-6 * max(1.0, abs(l_ref))
+    assert float((wr.logits - wg.logits).abs().max()) <= 1e-5 and float((wr.dlogits - wg.dlogits).abs().max()) <= 1e-7
+    assert float((wr.feat - wg.feat).abs().max()) <= 1e-5
+    for k in ('voxel_head.weight', 'voxel_head.bias', 'norm.weight', 'norm.bias'):
+        a, b = ref.arena.grad(k), eng.arena.grad(k)
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), k
+    rel = float((ref.arena.g - eng.arena.g).norm() / ref.arena.g.norm())
+    assert rel < 2e-2, rel                                       # the blocks below see the same d(x_final) up to bf16 / atomics noise
+
+
 def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
     """ln_fuse=True: norm2 / the next block's norm1 are computed by the last-arriving tile of every row band inside the attn.proj /
     mlp.fc2 GEMM launches (in-launch hand-off through write-through stores + an agent-scope ticket).  Same row arithmetic as the
