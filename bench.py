@@ -292,7 +292,7 @@ def main_points(args):
     x, y, starts = x.to(dev), y.to(dev), tuple(t.to(dev) for t in starts)
     ident = rccl_identity(dev, world)
     dp = world > 1 or args.force_collectives
-    pipelined = args.pipeline and not dp and not args.no_graphs
+    pipelined = not args.no_pipeline and not args.no_graphs
 
     def barrier():
         torch.cuda.synchronize()
@@ -301,9 +301,14 @@ def main_points(args):
 
     if dp:
         tr = PointDataParallelTrainer(eng, use_graphs=not args.no_graphs, force_collectives=args.force_collectives)
-        loss_t = tr.step(x, y, starts)
-        step = tr.step_graph if not args.no_graphs else (lambda: tr.step_eager(x, y, starts))
-        launch = ('hipGraph replay (3 graphs + 2 host-launched all-reduces)' if not args.no_graphs else 'eager')
+        if pipelined:
+            tr.prime(x, y, starts)
+            step = lambda: tr.step_pipelined(x, y, starts)
+            launch = 'hipGraph replay (3 graphs + 2 host-launched all-reduces), geometry (FPS/kNN) one step ahead on a side stream'
+        else:
+            loss_t = tr.step(x, y, starts)
+            step = tr.step_graph if not args.no_graphs else (lambda: tr.step_eager(x, y, starts))
+            launch = ('hipGraph replay (3 graphs + 2 host-launched all-reduces)' if not args.no_graphs else 'eager')
     elif pipelined:
         xs, ys, sts = [x, x.clone()], [y, y.clone()], [starts, tuple(t.clone() for t in starts)]
         graphs, loss_t = eng.capture_train_step_pipelined(xs, ys, sts)
@@ -458,7 +463,8 @@ def main():
     ap.add_argument('--wire', choices=['auto', 'fp32', 'bf16'], default='auto',
                     help="gradient all-reduce format: fp32 (DDP's arithmetic) or bf16 (half the xGMI bytes); auto = bf16 when N > 1")
     ap.add_argument('--no-diagnostics', action='store_true', help='skip the per-bucket all-reduce / overlap measurement at N > 1')
-    ap.add_argument('--pipeline', action='store_true', help='point configs: geometry (FPS / kNN) of batch i+1 during step i')
+    ap.add_argument('--no-pipeline', action='store_true',
+                    help='point configs: FPS / kNN inside the step instead of one step ahead on the side stream (the default)')
     args = ap.parse_args()
     if args.config in POINT_CONFIGS:
         return main_points(args)

@@ -125,20 +125,29 @@ def run_blocks(x, sd, depth, num_heads, bf16=False):
 
 # ----------------------------------------------------------------------------- group_embed
 def hash_keep_mask(shape, seed, site, p):
-    """Counter-based dropout mask shared with the HIP kernels (common.h: drop_key / drop_keep): element i (row-major
-    linear index) is kept iff splitmix64(i, key(seed, site)) >> 32 >= floor(p * 2^32)."""
+    """Counter-based dropout mask shared with the HIP kernels (common.h: drop_key / drop_mix32 / drop_keep): element i (row-major
+    linear index) is kept iff mix32(lo(i) * 0x9E3779B1 + (mix32(hi(i) ^ hi(key)) ^ lo(key))) >= floor(p * 2^32), with
+    key = seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019 (mod 2^64) and mix32 two rounds of
+    xor-shift / multiply."""
     import numpy as np
     n = 1
     for d in shape:
         n *= int(d)
     thr = int(p * 4294967296.0)
+    key = (seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & _MASK64
+    key_hi, key_lo = np.uint32(key >> 32), np.uint32(key & 0xFFFFFFFF)
+
+    def mix32(x):
+        x = x ^ (x >> np.uint32(16)); x = x * np.uint32(0x21f0aaad)
+        x = x ^ (x >> np.uint32(15)); x = x * np.uint32(0x735a2d97)
+        return x ^ (x >> np.uint32(15))
+
     with np.errstate(over='ignore'):
-        key = np.uint64((seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019) & _MASK64)
-        z = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + key
-        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
-        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
-    keep = (z >> np.uint64(32)) >= np.uint64(thr)
+        idx = np.arange(n, dtype=np.uint64)
+        lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
+        h = mix32(hi ^ key_hi) ^ key_lo
+        z = mix32(lo * np.uint32(0x9E3779B1) + h)
+    keep = z.astype(np.uint64) >= np.uint64(thr)
     return torch.from_numpy(keep.reshape(tuple(shape)))
 
 

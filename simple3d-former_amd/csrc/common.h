@@ -98,16 +98,20 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
-// counter-based dropout mask (splitmix64 of the element index; the oracle evaluates the same function)
+// counter-based dropout mask (hash of the element index; the oracle evaluates the same function, voxel_oracle.hash_keep_mask)
 __device__ __forceinline__ unsigned long long drop_key(const unsigned long long* seed, int site) {
     return (*seed) * 0x9E3779B97F4A7C15ull + (unsigned long long)site * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;
 }
+// 32-bit mixing (two rounds of multiply / xor-shift, "lowbias32" constants) of the element index folded with the key: the
+// attention-probability mask of the group encoder layer is evaluated (196 B)^2 * 60 times per pass, where the earlier splitmix64
+// (three 64-bit multiplies = a dozen 32-bit ones per element) was 20 - 30 % of the three long-sequence attention kernels.
+__device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+    return x;
+}
 __device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long long idx, unsigned thr) {
-    unsigned long long z = idx * 0x9E3779B97F4A7C15ull + key;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (unsigned)(z >> 32) >= thr;
+    const uint32_t hi = drop_mix32((uint32_t)(idx >> 32) ^ (uint32_t)(key >> 32)) ^ (uint32_t)key;   // changes every 2^32 elements
+    return drop_mix32((uint32_t)idx * 0x9E3779B1u + hi) >= thr;
 }
 
 // fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)

@@ -495,6 +495,26 @@ def test_pipelined_steps_equal_plain_steps():
     assert max(abs(a - b) for a, b in zip(want, got2)) <= 2e-3, (want, got2)
 
 
+def test_dp_trainer_pipelined_geometry_equals_plain_steps():
+    """PointDataParallelTrainer.prime / step_pipelined (two buffer sets, [top | bottom] graphs per set, geometry of the next batch on
+    the side stream inside the top graph) == the plain train_step sequence on alternating batches."""
+    from simple3d_former_amd.parallel import PointDataParallelTrainer
+    kw = dict(backbone='deit_tiny_patch16_224', n_points=64, d_points=22, n_classes=50)
+    sd = po.init_state_dict(backbone=kw['backbone'], n_classes=50, d_points=22, seed=3)
+    batches = []
+    for seed in (4, 5):
+        x, y, starts = po.synthetic_points(3, 64, 22, 50, 'seg', seed=seed)
+        batches.append((x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts)))
+    ref = PointEngine(task='seg', device=DEV, **kw); ref.load_state_dict(sd)
+    want = [float(ref.train_step(*batches[i % 2])) for i in range(5)]
+    eng = PointEngine(task='seg', device=DEV, **kw); eng.load_state_dict(sd)
+    tr = PointDataParallelTrainer(eng)
+    tr.prime(*batches[0])
+    got = [float(tr.step_pipelined(*batches[(i + 1) % 2])) for i in range(5)]
+    assert max(abs(a - b) for a, b in zip(want, got)) <= 2e-3, (want, got)
+    assert float((eng.arena.p - ref.arena.p).abs().max()) <= 2e-3
+
+
 def test_captured_graph_follows_lr_and_bn_momentum_schedules():
     """train_partseg.py:121-130 decays the learning rate and the BatchNorm momentum every epoch; both live in device memory
     (PointEngine.hyper), so a graph captured once keeps following them -- and capturing mid-training applies no update."""
