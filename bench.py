@@ -110,7 +110,7 @@ def rocprof_name(key):
 def pmc_traffic(key):
     """HBM-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_step.sh -> profiles/), or None.
     bench.py cannot collect PMC counters itself (they need rocprofv3 around the process, one pass per counter group)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_step_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_step_traffic.json')
     try:
         with open(path) as f:
             k = json.load(f)['kernels'].get(rocprof_name(key))
@@ -625,7 +625,7 @@ def main():
                 'bound': 'mfma', 'kernel': kernel_name(dom[0]), 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': traffic,
                 'traffic_unit': 'bytes per launch (memory side of L2: HBM + Infinity Cache)',
-                'traffic_source': ('profiles/r01_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + '
+                'traffic_source': ('profiles/r02_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + '
                                    'WRITE_SIZE, separate passes, ' + rocprof_name(dom[0])) if traffic else None,
                 'traffic_detail': tdetail,
                 'avg_launch_us': round(avg_us, 3), 'timing': method,

@@ -80,7 +80,9 @@ __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2,
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------- forward
-template <int HD, bool SPLIT, bool SEG = false>
+// DROP: attention-weight dropout compiled in (only the group encoder layer uses it; the timm blocks never do, and merely carrying
+// the masked path changed the register allocation of the 26-token kernel: 5.7 -> 8.3 us per launch)
+template <int HD, bool SPLIT, bool SEG = false, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         lsum = half_sum(lsum);
         l_i = l_i * alpha + lsum;
         m_i = mnew;
-        if (p.drop_thr) {                                         // dropout on the attention weights (normaliser undropped)
+        if constexpr (DROP) {                                     // dropout on the attention weights (normaliser undropped)
             const unsigned long long key = drop_key(p.drop_seed, p.drop_site);
             const unsigned long long rowbase = ((unsigned long long)bh * p.N + min(qrow, p.N - 1)) * p.N;
 #pragma unroll
@@ -1074,7 +1076,16 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     }
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
-    if (split) {
+    if (a.drop_thr) {                     // the masked variant (no segment packing: dropout sites are long-sequence / test shapes)
+        S3D_REQUIRE(!a.seg, "attention_fwd: dropout with packed segments is not built");
+        if (split) {
+            set_lds((attn_fwd_kernel<HD, true, false, true>), 4 * 2 * 32 * HD * 2);
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, true, false, true>), grid, dim3(64 * wpb), wpb * 2 * 32 * HD * 2, s, a);
+        } else {
+            set_lds((attn_fwd_kernel<HD, false, false, true>), 4 * 32 * HD * 2);
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, false, false, true>), grid, dim3(64 * wpb), wpb * 32 * HD * 2, s, a);
+        }
+    } else if (split) {
         const int lds = wpb * 2 * 32 * HD * 2;
         set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * HD * 2);
         set_lds(attn_fwd_kernel<HD, true, true>, 4 * 2 * 32 * HD * 2);
