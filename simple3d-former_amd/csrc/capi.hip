@@ -118,6 +118,51 @@ int wgrad(const bf16_t* dy, int out, const bf16_t* x, int in, long M, float* dW,
     return s3d_launch_gemm(true, true, false, EPI_ATOMIC, wgrad_args(dy, out, x, in, M, dW, db), 0, s);
 }
 
+// ---- backward on two streams (S3D_BWD_STREAMS=1) ------------------------------------------------------------------------------
+// The block backward is a chain (fc2 dgrad -> fc1 dgrad -> norm2 -> proj dgrad -> attention -> qkv dgrad -> norm1) with four wgrads
+// hanging off it.  Pairing every wgrad with "its" dgrad in one launch already overlaps those two; here the wgrads go to a side
+// stream instead and run beside whatever the chain does next -- the LayerNorm / attention kernels of the chain are latency-bound
+// launches that leave most CUs idle.  Works eagerly and under HIP-graph capture (fork / join through events -> graph branches).
+struct BwdStreams {
+    hipStream_t side = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool ok = false;
+    bool init(hipStream_t main) {
+        if (ok) return true;
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;   // create outside captures only
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&ready, hipEventDisableTiming) != hipSuccess) return false;
+        if (hipEventCreateWithFlags(&done, hipEventDisableTiming) != hipSuccess) return false;
+        ok = true;
+        return true;
+    }
+};
+BwdStreams g_bwd_streams;
+bool bwd_streams_enabled() {
+    static const int on = [] { const char* v = getenv("S3D_BWD_STREAMS"); return v ? atoi(v) : 0; }();
+    return on > 0;
+}
+// dgrad on `s`, wgrad on the side stream once everything `s` has enqueued so far (i.e. dy) is complete
+int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs) {
+    if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s);
+    if (hipEventRecord(bs->ready, s) != hipSuccess || hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
+        s3d_set_error("backward streams: fork failed");
+        return 3;
+    }
+    S3D_TRY(s3d_launch_gemm(true, true, false, EPI_ATOMIC, wg, 0, bs->side));
+    return s3d_launch_gemm(false, true, false, epi, dg, 1, s);
+}
+// `s` waits for every wgrad issued so far (before a buffer they read is overwritten / before the block returns)
+int bwd_streams_join(hipStream_t s, BwdStreams* bs) {
+    if (bs == nullptr) return 0;
+    if (hipEventRecord(bs->done, bs->side) != hipSuccess || hipStreamWaitEvent(s, bs->done, 0) != hipSuccess) {
+        s3d_set_error("backward streams: join failed");
+        return 3;
+    }
+    return 0;
+}
+
 // LayerNorm column-sum partials of one s3d_blocks_bwd call (see S3dBlockScratch::ln_partial): slot k of the call's LayerNorms
 struct LnPartials {
     const float* part[64]; float* dg[64]; float* db[64];
@@ -146,15 +191,16 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     float* dxb = cls_only ? w.dx_b_cls : w.dx_b;
     bf16_t* dxb_bf = cls_only ? w.dx_b_bf_cls : w.dx_b_bf;
     bf16_t* datt = cls_only ? w.datt_cls : w.datt;
+    BwdStreams* bs = (bwd_streams_enabled() && g_bwd_streams.init(s)) ? &g_bwd_streams : nullptr;
     // ---- MLP branch: d(x_out) is in dx_a / dx_a_bf
     // every dgrad is launched together with the wgrad that consumes the same dy (one grid, two problems)
     GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)          || dW2 += dx_out^T hact
     g.A_hi = w.dx_a_bf; g.lda = pd; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M2; g.N = Hd; g.K = D;
     g.aux = a.hpre; g.ldaux = ph; g.O_hi = w.dh; g.ldo = ph;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M2, gr.fc2_w, gr.fc2_b, pd, ph), s));
+    S3D_TRY(dgrad_and_wgrad(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M2, gr.fc2_w, gr.fc2_b, pd, ph), s, bs));
     g = gemm_zero();            // dxn2 = dh @ W1                             || dW1 += dh^T xn2
     g.A_hi = w.dh; g.lda = ph; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = pd;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M2, gr.fc1_w, gr.fc1_b, ph, pd), s));
+    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M2, gr.fc1_w, gr.fc1_b, ph, pd), s, bs));
     LnBwdArgs lb;
     memset(&lb, 0, sizeof(lb));
     lb.dy = w.dxn; lb.lddy = pd; lb.x = a.x_mid; lb.ldx = pd; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
@@ -165,7 +211,7 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
     g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
     g.A_hi = dxb_bf; g.lda = pd; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D; g.O_hi = datt; g.ldo = pd;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s));
+    S3D_TRY(dgrad_and_wgrad(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s, bs));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
@@ -175,7 +221,8 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     S3D_TRY(s3d_launch_attention_bwd(at, s));
     g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(s3d_launch_gemm_pair(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s));
+    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s, bs));
+    S3D_TRY(bwd_streams_join(s, bs));      // norm1 overwrites dx_a_bf (read by the fc2 wgrad); the next block reuses dh / dqkv / dx_b_bf
     lb.dy = w.dxn; lb.lddy = D; lb.ldx = D; lb.lddres = D; lb.lddx = D; lb.lddxbf = D; lb.rows = M;      // norm1 is dense again
     lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = dxb; lb.dx = w.dx_a;
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;

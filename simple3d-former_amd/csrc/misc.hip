@@ -451,55 +451,48 @@ __global__ __launch_bounds__(256) void head_loss_sample_kernel(const S3dHeadLoss
     }
 }
 
-// reductions over the batch, one thread per output (fixed order: deterministic): dW [C][D], dbias [C], dgamma / dbeta [D], loss
+// reductions over the batch (fixed order: deterministic): dW [C][D], dbias [C], dgamma / dbeta [D], loss.  A workgroup owns 64
+// consecutive outputs; its four waves each take a quarter of the batch (b = wave, wave + 4, ...) with 16 independent load pairs in
+// flight per trip, and the four partials are added in wave order -- one trip at B = 64 instead of a 64-deep latency chain.
 __global__ __launch_bounds__(256) void head_loss_reduce_kernel(const S3dHeadLossArgs p) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + lane;
     const int D = p.D, C = p.C, B = p.B;
-    const long nw = (long)C * D, st = 2 * D + 1;
-    if (idx < nw) {
-        const int c = (int)(idx / D), d = (int)(idx % D);
-        // 16 independent load pairs per trip (clamped, masked): the sum over the batch is a latency chain otherwise (32 us at B = 64)
-        float acc = 0.f;
-        for (int b0 = 0; b0 < B; b0 += 16) {
-            float dl[16], ft[16];
+    const long nw = (long)C * D, st = 2 * D + 1, nout = nw + C + 2 * D;
+    // what this output sums: u[b] * v[b] with u / v rows of stride su / sv (v == nullptr: plain sum of u)
+    const float *u = nullptr, *v = nullptr;
+    long su = 0, sv = 0;
+    if (idx < nw) { u = p.dlogits + idx / D; su = C; v = p.feat + idx % D; sv = D; }
+    else if (idx < nw + C) { u = p.dlogits + (idx - nw); su = C; }
+    else if (idx < nw + C + D) { u = p.scratch + (idx - nw - C); su = st; v = p.scratch + D + (idx - nw - C); sv = st; }
+    else if (idx < nout) { u = p.scratch + (idx - nw - C - D); su = st; }
+    float acc = 0.f;
+    if (u) {
+        for (int b0 = wave; b0 < B; b0 += 64) {
+            float uu[16], vv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int bb = min(b0 + u, B - 1);
-                dl[u] = p.dlogits[(long)bb * C + c]; ft[u] = p.feat[(long)bb * D + d];
+            for (int k = 0; k < 16; ++k) {
+                const long bb = min(b0 + 4 * k, B - 1);
+                uu[k] = u[bb * su]; vv[k] = v ? v[bb * sv] : 1.f;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += (b0 + u < B) ? dl[u] * ft[u] : 0.f;
+            for (int k = 0; k < 16; ++k) acc += (b0 + 4 * k < B) ? uu[k] * vv[k] : 0.f;
         }
-        if (p.dW) p.dW[idx] += acc;
-    } else if (idx < nw + C) {
-        const int c = (int)(idx - nw);
-        float a = 0.f;
-        for (int b0 = 0; b0 < B; b0 += 16) {
-            float dl[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) dl[u] = p.dlogits[(long)min(b0 + u, B - 1) * C + c];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) a += (b0 + u < B) ? dl[u] : 0.f;
-        }
-        if (p.dbias) p.dbias[c] += a;
-    } else if (idx < nw + C + 2 * D) {
-        const int j = (int)(idx - nw - C), d = j % D;
-        float a = 0.f;
-        for (int b0 = 0; b0 < B; b0 += 16) {
-            float df[16], xh[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const long bb = min(b0 + u, B - 1);
-                df[u] = p.scratch[bb * st + d]; xh[u] = (j < D) ? p.scratch[bb * st + D + d] : 1.f;
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) a += (b0 + u < B) ? df[u] * xh[u] : 0.f;
-        }
-        if (j < D) { if (p.dgamma) p.dgamma[d] += a; } else { if (p.dbeta) p.dbeta[d] += a; }
-    } else if (idx == nw + C + 2 * D) {
+    }
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && u) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        if (idx < nw) { if (p.dW) p.dW[idx] += t; }
+        else if (idx < nw + C) { if (p.dbias) p.dbias[idx - nw] += t; }
+        else if (idx < nw + C + D) { if (p.dgamma) p.dgamma[idx - nw - C] += t; }
+        else { if (p.dbeta) p.dbeta[idx - nw - C - D] += t; }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {      // the loss: B per-sample shares, added in order
         float a = 0.f, den = (float)B;
-        for (int b = 0; b < B; ++b) a += p.scratch[b * st + 2 * D];
-        if (p.weight) { den = 0.f; for (int b = 0; b < B; ++b) den += p.weight[p.target[b]]; }
+        for (int bb = 0; bb < B; ++bb) a += p.scratch[bb * st + 2 * D];
+        if (p.weight) { den = 0.f; for (int bb = 0; bb < B; ++bb) den += p.weight[p.target[bb]]; }
         p.loss[0] = a; p.loss[1] = den;
     }
 }
@@ -662,8 +655,8 @@ int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(head_loss_sample_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     hipLaunchKernelGGL(head_loss_sample_kernel, dim3((unsigned)a.B), dim3(256), lds, s, a);
-    const long n = (long)a.C * a.D + a.C + 2 * a.D + 1;
-    hipLaunchKernelGGL(head_loss_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    const long n = (long)a.C * a.D + a.C + 2 * a.D;
+    hipLaunchKernelGGL(head_loss_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, a);
     S3D_CHECK_LAUNCH("head_loss_fused");
     return 0;
 }
