@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p
     const bool kok = krow < p.N;
     const int krow_c = min(krow, p.N - 1);
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const DropRow dcol = drop_row(dkey, (unsigned long long)bh * p.N * p.N + krow_c);        // mask index = column base + q * N
 
     bf16x8 kf[NS], vf[NS];
     {
@@ -544,8 +545,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p
                 const bool ok = kok && (q < p.N);
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[qr]) : 0.f;
                 float dm = 1.f;
-                if (p.drop_thr)
-                    dm = drop_keep(dkey, ((unsigned long long)bh * p.N + min(q, p.N - 1)) * p.N + krow_c, p.drop_thr) ? p.drop_scale : 0.f;
+                if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)min(q, p.N - 1) * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
                 pf[s2].h[j] = f2bf(pr * dm);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[32 + qr]) * p.scale);
             }
@@ -634,6 +634,7 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
     const bool qok = qrow < p.N;
     const int qrow_c = min(qrow, p.N - 1);
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const DropRow drow = drop_row(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N);     // mask index = row base + key column
 
     bf16x8 qh[NS], ql[SPLIT ? NS : 1];
     {
@@ -707,10 +708,9 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
         l_i = l_i * alpha + lsum;
         m_i = mnew;
         if (p.drop_thr) {
-            const unsigned long long rowbase = ((unsigned long long)bh * p.N + qrow_c) * p.N;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sv[r] = drop_keep(dkey, rowbase + (k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
+                sv[r] = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
         }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
@@ -783,6 +783,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p)
     const int qrow_c = min(qrow, p.N - 1);
     const long tokrow = (long)b * p.sb + (long)qrow_c * p.st;
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const DropRow drow = drop_row(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N);     // mask index = row base + key column
 
     bf16x8 qf[NS], dof[NS];
     float delta = 0.f;
@@ -844,8 +845,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p)
                 const bool ok = (k0 + acc_row(r, h2)) < p.N;
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
-                if (p.drop_thr)
-                    dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N + (k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
                 dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
             }
 #pragma unroll

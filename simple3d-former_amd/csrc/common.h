@@ -114,6 +114,18 @@ __device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long 
     return drop_mix32((uint32_t)idx * 0x9E3779B1u + hi) >= thr;
 }
 
+// The same mask for element (base + off), off < 2^32, with the 64-bit part hoisted: the long-sequence attention kernels evaluate the
+// mask (196 B)^2 * 60 times per pass, and a 64-bit multiply-add per element to form the index cost more than the hash itself.
+struct DropRow { uint32_t lo, mix_a, mix_b; };
+__device__ __forceinline__ DropRow drop_row(unsigned long long key, unsigned long long base) {
+    const uint32_t hi = (uint32_t)(base >> 32), khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
+    return DropRow{(uint32_t)base, drop_mix32(hi ^ khi) ^ klo, drop_mix32((hi + 1u) ^ khi) ^ klo};
+}
+__device__ __forceinline__ bool drop_keep_at(const DropRow& r, uint32_t off, unsigned thr) {
+    const uint32_t lo = r.lo + off;
+    return drop_mix32(lo * 0x9E3779B1u + (lo < r.lo ? r.mix_b : r.mix_a)) >= thr;      // lo < r.lo: the add carried into the high word
+}
+
 // fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 

@@ -237,6 +237,45 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
         assert e < 2e-2, f'd{name} rms err {e:.3e}'
 
 
+@pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(3, 4, 300, 192, True),      # cooperative long-sequence kernels (>= 6 query tiles)
+                                                (2, 3, 197, 256, False), (4, 6, 26, 64, False), (3, 4, 100, 192, True)])
+def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first):
+    """Dropout on the attention weights (site 0 of nn.TransformerEncoderLayer): P' = softmax(S) * keep / (1 - p) with the
+    counter-based mask of oracle.voxel_oracle.hash_keep_mask over the [Bb*H, N, N] index space -- forward and backward of every
+    kernel family (per-wave, single-launch small, cooperative) against autograd on exactly that mask."""
+    from oracle import voxel_oracle as vo
+    g = torch.Generator().manual_seed(16)
+    D, rows, p, seed_v, site = H * hd, Bb * N, 0.1, 4321, 0
+    qkv = torch.randn(rows, 3 * D, generator=g).to(DEV)
+    sb, st = (1, Bb) if seq_first else (N, 1)
+    hi, lo = ops.split_bf16(qkv)
+    seed = torch.tensor([seed_v], dtype=torch.int64, device=DEV)
+    drop = (p, seed, site)
+    out_hi, out_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, sb, st, split=True, drop=drop)
+    keep = vo.hash_keep_mask((Bb, H, N, N), seed_v, site, p).to(DEV).double() / (1.0 - p)
+
+    def to_b(t):
+        return t.view(N, Bb, -1).transpose(0, 1) if seq_first else t.view(Bb, N, -1)
+
+    def ref_attn(x):
+        q, k, v = [x[..., i * D:(i + 1) * D].reshape(Bb, N, H, hd).transpose(1, 2) for i in range(3)]
+        s = (q @ k.transpose(-2, -1)) * hd ** -0.5
+        return (s.softmax(-1) * keep) @ v
+    x = to_b(qkv.double()).requires_grad_(True)
+    ref = ref_attn(x)
+    got = to_b(out_hi.float() + out_lo.float()).reshape(Bb, N, H, hd).transpose(1, 2)
+    e = rel_err(got, ref.detach())
+    assert e < 1e-4, f'fwd rel err {e:.3e} (a wrong mask gives ~0.3)'
+    dout = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
+    dqkv = ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop)
+    xb = to_b(hi.double()).requires_grad_(True)
+    ref_attn(xb).backward(to_b(dout.double()).reshape(Bb, N, H, hd).transpose(1, 2))
+    gotd = to_b(dqkv.float())
+    for i, name in enumerate('qkv'):
+        e = rms_err(gotd[..., i * D:(i + 1) * D], xb.grad[..., i * D:(i + 1) * D])
+        assert e < 2e-2, f'd{name} rms err {e:.3e}'
+
+
 @pytest.mark.parametrize('H,N,hd,seg', [(3, 30, 256, 15), (6, 26, 64, 13), (4, 32, 48, 16), (2, 21, 96, 11)])
 def test_attention_block_diagonal_segments(H, N, hd, seg):
     """S3dAttnArgs::seg: a query attends to the keys of its own segment only (what the launchers use to pack two short

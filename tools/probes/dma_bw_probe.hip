@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -14,6 +15,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+struct Rsrc { unsigned int w[4]; };
+__device__ __forceinline__ void bdma16(const void* base, int nbytes, unsigned char* lds_dst, int voff, int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds_dst, 16, voff, soff, 0, 0);
+#endif
 }
 
 struct Args { const unsigned short *A, *B; long ld; int M, N, K, xcd_map; unsigned long long* cyc; u32x4* sink; };
@@ -47,7 +57,34 @@ __global__ __launch_bounds__(256) void stream_kernel(const Args p) {
     }
     const int ntiles = p.K / 64;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 2) {
+        // LDS-DMA through BUFFER loads: resource descriptor (SGPRs) + 32-bit per-lane byte offset + scalar k offset, instead of a
+        // 64-bit per-lane address (global_load_lds)
+        const int nA = (int)((long)NPL * p.M * p.ld * 2), nB = (int)((long)NPL * p.N * p.ld * 2);
+        int voff[PPW];
+        bool isb[PPW];
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            isb[j] = (wave * PPW + j) >= NPL * (BM / 8);
+            voff[j] = (int)((const unsigned char*)gp[j] - (const unsigned char*)(isb[j] ? p.B : p.A));
+        }
+        auto issue = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                unsigned char* dst = smem + (t % NS) * STAGE + (wave * PPW + j) * 1024;
+                if (isb[j]) bdma16(p.B, nB, dst, voff[j], t * 128);
+                else bdma16(p.A, nA, dst, voff[j], t * 128);
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < NS - 1; ++u) if (u < ntiles) issue(u);
+        for (int t = 0; t < ntiles; ++t) {
+            if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t + NS - 1 < ntiles) issue(t + NS - 1);
+        }
+    } else if constexpr (MODE == 0) {
         auto issue = [&](int t) {
             const unsigned dst = lds0 + (unsigned)((t % NS) * STAGE + wave * PPW * 1024);
 #pragma unroll
@@ -82,7 +119,7 @@ __global__ __launch_bounds__(256) void stream_kernel(const Args p) {
 template <int BM, int BN, int NS, int NPL, int MODE>
 void run(const char* name, Args a, int reps = 30) {
     constexpr int STAGE = NPL * (BM + BN) * 128;
-    const int lds = MODE == 0 ? NS * STAGE : 0;
+    const int lds = MODE != 1 ? NS * STAGE : 0;
     auto kern = stream_kernel<BM, BN, NS, NPL, MODE>;
     if (lds > 160 * 1024) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -103,7 +140,7 @@ void run(const char* name, Args a, int reps = 30) {
     const double us = ms * 1e3 / reps;
     const double wg_per_cu = nwg / 256.0;
     printf("%-4s tile %3dx%-3d NS=%d planes=%d mode=%s map=%d  N=%4d K=%4d  %4d WGs  %7.2f us/launch  %6.1f MB  %6.2f TB/s  | in-WG: %7.0f cyc, %5.1f B/clk/WG -> x%.2f WG/CU = %5.1f B/clk/CU\n",
-           name, BM, BN, NS, NPL, MODE == 0 ? "dma " : "regs", a.xcd_map, a.N, a.K, nwg, us, bytes / 1e6, bytes / us / 1e6, mean,
+           name, BM, BN, NS, NPL, MODE == 0 ? "dma " : MODE == 2 ? "bdma" : "regs", a.xcd_map, a.N, a.K, nwg, us, bytes / 1e6, bytes / us / 1e6, mean,
            (double)STAGE * (a.K / 64) / mean, wg_per_cu, (double)STAGE * (a.K / 64) / mean * wg_per_cu);
 }
 
@@ -113,16 +150,24 @@ int main() {
     hipMalloc(&A, (size_t)2 * M * KMAX * 2); hipMalloc(&B, (size_t)2 * NMAX * KMAX * 2);
     hipMemset(A, 1, (size_t)2 * M * KMAX * 2); hipMemset(B, 2, (size_t)2 * NMAX * KMAX * 2);
     hipMalloc(&cyc, 8192 * 8); hipMalloc(&sink, 8192 * 256 * 16);
-    for (int map = 1; map >= 0; --map) {
+    const bool full = getenv("PROBE_FULL") != nullptr;
+    for (int map = 1; map >= (full ? 0 : 1); --map) {
         Args fc2{A, B, 1536, M, 384, 1536, map, cyc, sink}, fc1{A, B, 384, M, 1536, 384, map, cyc, sink}, pr{A, B, 384, M, 384, 384, map, cyc, sink};
-        printf("--- fc2 shape (N=384, K=1536), split planes, xcd_map=%d\n", map);
-        run<32, 32, 2, 2, 0>("fc2", fc2); run<32, 32, 3, 2, 0>("fc2", fc2); run<32, 32, 4, 2, 0>("fc2", fc2); run<32, 32, 2, 2, 1>("fc2", fc2);
-        run<32, 64, 2, 2, 0>("fc2", fc2); run<32, 64, 3, 2, 0>("fc2", fc2);
-        run<64, 64, 2, 2, 0>("fc2", fc2); run<64, 64, 3, 2, 0>("fc2", fc2); run<64, 64, 2, 2, 1>("fc2", fc2);
-        run<64, 128, 2, 2, 0>("fc2", fc2); run<128, 128, 2, 2, 0>("fc2", fc2);
+        printf("--- global_load_lds (dma) vs buffer_load ... lds (bdma): fc2 shape (N=384, K=1536), split planes, xcd_map=%d\n", map);
+        run<32, 32, 2, 2, 0>("fc2", fc2); run<32, 32, 2, 2, 2>("fc2", fc2); run<32, 32, 4, 2, 2>("fc2", fc2);
+        run<64, 64, 2, 2, 0>("fc2", fc2); run<64, 64, 2, 2, 2>("fc2", fc2); run<64, 64, 3, 2, 0>("fc2", fc2); run<64, 64, 3, 2, 2>("fc2", fc2);
+        run<128, 128, 2, 2, 0>("fc2", fc2); run<128, 128, 2, 2, 2>("fc2", fc2);
         printf("--- fc1 shape (N=1536, K=384)\n");
-        run<32, 64, 2, 2, 0>("fc1", fc1); run<32, 64, 3, 2, 0>("fc1", fc1); run<32, 64, 2, 2, 1>("fc1", fc1);
-        run<64, 64, 2, 2, 0>("fc1", fc1); run<64, 64, 3, 2, 0>("fc1", fc1); run<64, 128, 2, 2, 0>("fc1", fc1); run<128, 128, 2, 2, 0>("fc1", fc1);
+        run<32, 64, 2, 2, 0>("fc1", fc1); run<32, 64, 2, 2, 2>("fc1", fc1);
+        run<64, 64, 2, 2, 0>("fc1", fc1); run<64, 64, 2, 2, 2>("fc1", fc1);
+        run<128, 128, 2, 2, 0>("fc1", fc1); run<128, 128, 2, 2, 2>("fc1", fc1);
+        if (!full) continue;
+        printf("--- fc2 shape, ring depth and register loads\n");
+        run<32, 32, 3, 2, 0>("fc2", fc2); run<32, 32, 4, 2, 0>("fc2", fc2); run<32, 32, 2, 2, 1>("fc2", fc2);
+        run<32, 64, 2, 2, 0>("fc2", fc2); run<32, 64, 3, 2, 0>("fc2", fc2); run<64, 64, 2, 2, 1>("fc2", fc2);
+        run<64, 128, 2, 2, 0>("fc2", fc2);
+        printf("--- fc1 shape\n");
+        run<32, 64, 3, 2, 0>("fc1", fc1); run<32, 64, 2, 2, 1>("fc1", fc1); run<64, 64, 3, 2, 0>("fc1", fc1); run<64, 128, 2, 2, 0>("fc1", fc1);
         printf("--- proj shape (N=384, K=384)\n");
         run<32, 32, 2, 2, 0>("proj", pr); run<32, 32, 4, 2, 0>("proj", pr); run<32, 32, 2, 2, 1>("proj", pr); run<64, 64, 2, 2, 0>("proj", pr);
         printf("--- plain bf16 (one plane) fc2 shape\n");
