@@ -509,6 +509,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
 // [rows][64] bf16 tile is applied on the SOURCE side: the lane that fills 16-byte slot c of row r fetches global chunk
 // c ^ swz(r), and read_frag() finds chunk kc at slot kc ^ swz(r) as before.  NS stages are in flight; hipcc does not count
 // asm loads, so each wave retires its own pieces with a counted s_waitcnt before the one barrier per k-tile.
+__device__ __attribute__((aligned(16))) const unsigned int g_dma_zeros[4] = {0u, 0u, 0u, 0u};   // DMA source of a zero chunk
+
 __device__ __forceinline__ void glds16(const bf16_t* gsrc, unsigned lds_dst) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -866,7 +868,8 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int col
     return u.v;
 }
 
-template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128>
+// KTAIL: instantiation that accepts a partial last k-tile (kept apart: its extra per-piece state costs the cfg-2 pair launches 1.5 %)
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false>
 __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
                                                const int bz) {
     constexpr int BK = 64;
@@ -883,11 +886,13 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
     }
     const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
     const int kbeg = bz * p.kchunk;
-    const int ntiles = (min(p.K, kbeg + p.kchunk) - kbeg) >> 6;        // every k-slice tiles by 64 (checked by the launcher)
+    const int kslice = min(p.K, kbeg + p.kchunk) - kbeg;               // k-slices are whole 64-tiles except possibly the last one
+    const int ntiles = (kslice + 63) >> 6, ktail = KTAIL ? (kslice & 63) : 0;   // ktail != 0: the last k-tile is partial (K % 8 == 0)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
     const bf16_t* gp[PPW];
     long gstep[PPW];                                                   // elements per k-tile
+    int gk[KTAIL ? PPW : 1];                                           // first k (within a k-tile) this lane's 16 bytes cover
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int piece = wave * PPW + j;
@@ -903,15 +908,28 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
             const int cg = c ^ kmajor_swz<BM>(r);
             gp[j] = base + (long)(kbeg + r) * ld + min(r0 + cg * 8, R - 8);
             gstep[j] = 64 * ld;
+            if constexpr (KTAIL) gk[j] = r;                            // one k row
         } else {                                                       // piece = 8 tile rows x 8 slots (k-contiguous operand)
             const int r = q * 8 + (lane >> 3), c = lane & 7;
             const int sw = (r ^ (r >> 3)) & 7;
             gp[j] = base + (long)min(r0 + r, R - 1) * ld + kbeg + ((c ^ sw) << 3);
             gstep[j] = 64;
+            if constexpr (KTAIL) gk[j] = (c ^ sw) << 3;                // eight consecutive k
         }
     }
+    // The DMA cannot zero-fill, so the k beyond the slice of a partial last tile are fetched from a block of zeros instead (the
+    // row counts of the point path -- 32 clouds x 513 tokens -- are multiples of 32, not 64; this used to send those wgrads to the
+    // register-staged kernel)
     auto issue = [&](int t) {
         const unsigned dst = lds0 + (unsigned)((t % NS) * STAGE + wave * PPW * 1024);
+        if constexpr (KTAIL) {
+            if (ktail != 0 && t == ntiles - 1) {                       // block-uniform, once per launch
+#pragma unroll
+                for (int j = 0; j < PPW; ++j)
+                    glds16(gk[j] < ktail ? gp[j] + (long)t * gstep[j] : reinterpret_cast<const bf16_t*>(g_dma_zeros), dst + j * 1024);
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < PPW; ++j) glds16(gp[j] + (long)t * gstep[j], dst + j * 1024);
     };
@@ -1007,23 +1025,23 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
     }
 }
 
-template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128>
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false>
 __global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemm_dmat_body<TA, TB, EPI, NS, BM, BN>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+    gemm_dmat_body<TA, TB, EPI, NS, BM, BN, KTAIL>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
 }
 
 // dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
-template <int EPIA, int NS>
+template <int EPIA, int NS, bool KTAIL = false>
 __global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, const GemmArgs pb, int nA, int ntxA, int ntyA,
                                                              int ntxB, int ntyB) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
     if (bid < nA) {
-        gemm_dmat_body<false, true, EPIA, NS, 64, 64>(pa, smem, bid, ntxA, ntyA, 0);
+        gemm_dmat_body<false, true, EPIA, NS, 64, 64, KTAIL>(pa, smem, bid, ntxA, ntyA, 0);
     } else {
         const int b = bid - nA, tiles = ntxB * ntyB;
-        gemm_dmat_body<true, true, EPI_ATOMIC, NS, 64, 64>(pb, smem, b % tiles, ntxB, ntyB, b / tiles);
+        gemm_dmat_body<true, true, EPI_ATOMIC, NS, 64, 64, KTAIL>(pb, smem, b % tiles, ntxB, ntyB, b / tiles);
     }
 }
 
@@ -1176,12 +1194,15 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <bool TA, bool TB, int EPI, int BT = 128>
+template <bool TA, bool TB, int EPI, int BT = 128, bool KTAIL = false>
 int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
+    if constexpr (!KTAIL) {
+        if ((a.K & 63) != 0) return launch_dmat<TA, TB, EPI, BT, true>(a, splitk, stream);      // partial last k-tile
+    }
     constexpr int NS = BT == 128 ? 2 : 3, STAGE = 2 * BT * 64 * 2;
     constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : BT * (BT + 4) * 4);
     static bool attr_set = false;
-    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS, BT, BT>;
+    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS, BT, BT, KTAIL>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
@@ -1333,13 +1354,16 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
     if (dbg > 0 && shown < dbg) { ++shown; fprintf(stderr, "[s3d] wgrad M=%d N=%d K=%d paired=%d -> splitk=%d kchunk=%d\n", a.M, a.N, a.K, (int)paired, splitk, kchunk); }
 }
 
-template <int EPIA>
+template <int EPIA, bool KTAIL = false>
 int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream) {
+    if constexpr (!KTAIL) {
+        if (((a.K | b.K) & 63) != 0) return launch_pair_dmat<EPIA, true>(a, b, splitk, stream);   // partial last k-tile
+    }
     // three 16 KB stages (A 64x64 + B 64x64 bf16): 2.04 ms per cfg-2 step; two stages 2.15 ms, four 2.07 ms
     constexpr int NS = 3;
     constexpr int LDS = cmax(NS * 2 * 64 * 64 * 2, 64 * 68 * 4);
     static bool attr_set = false;
-    auto kern = gemm_pair_dmat_kernel<EPIA, NS>;
+    auto kern = gemm_pair_dmat_kernel<EPIA, NS, KTAIL>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
@@ -1390,7 +1414,7 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     a.kchunk = (a.K + 63) / 64 * 64;
     b.kchunk = kchunk;
     static const int pair_dmat = env_int("S3D_GEMM_PAIR_DMAT");          // S3D_GEMM_PAIR_DMAT=0: register-staged pair kernel
-    if (pair_dmat != 0 && tile_a == 1 && tile_b == 1 && (a.K & 63) == 0 && (b.K & 63) == 0 && (kchunk & 63) == 0) {
+    if (pair_dmat != 0 && tile_a == 1 && tile_b == 1 && (a.K & 7) == 0 && (b.K & 7) == 0 && (kchunk & 63) == 0) {
         switch (epi_a) {
             case EPI_F32: return launch_pair_dmat<EPI_F32>(a, b, splitk, stream);
             case EPI_DGELU: return launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream);
@@ -1438,10 +1462,10 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         a.kchunk = kchunk;
         const int tile = s3d_gemm_pick_tile(a.M, a.N, splitk, false);
         static const int dmat = env_int("S3D_GEMM_DMAT");               // S3D_GEMM_DMAT=0: register-staged kernel instead
-        if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
+        if (dmat != 0 && tile == 2 && (a.K & 7) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
             return launch_dmat<true, true, EPI_ATOMIC>(a, splitk, stream);
         static const int dmat_small = env_int("S3D_GEMM_DMAT_SMALL");   // the same pipeline on 64x64 tiles (=0: register-staged)
-        if (dmat_small != 0 && tile == 1 && (a.K & 63) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
+        if (dmat_small != 0 && tile == 1 && (a.K & 7) == 0 && (kchunk & 63) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0)
             return launch_dmat<true, true, EPI_ATOMIC, 64>(a, splitk, stream);
         return launch_tiles<true, true, false, EPI_ATOMIC>(tile, a, splitk, stream);
     }
@@ -1456,7 +1480,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
         static const int dmat = env_int("S3D_GEMM_DMAT");
         static const int dmat_small = env_int("S3D_GEMM_DMAT_SMALL");
-        if (dmat_small != 0 && tile == 1 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+        if (dmat_small != 0 && tile == 1 && (a.K & 7) == 0 && (a.N & 7) == 0) {
             switch (epi) {
                 case EPI_F32: return launch_dmat<false, true, EPI_F32, 64>(a, 1, stream);
                 case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 64>(a, 1, stream);
@@ -1464,7 +1488,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
                 default: break;
             }
         }
-        if (dmat != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+        if (dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0) {
             switch (epi) {
                 case EPI_F32: return launch_dmat<false, true, EPI_F32>(a, 1, stream);
                 case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU>(a, 1, stream);
