@@ -444,20 +444,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 // arithmetic), every operand of the MFMAs comes from LDS (row fragments by ds_read_b128 on a padded pitch, transposed fragments
 // by transpose reads), and there is one barrier per tile: a quarter of the staging traffic, no global fragment loads, and the
 // load latency hidden behind the previous tile.
-template <int HD, int DSPLIT>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p) {
+template <int HD, int DSPLIT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnArgs p) {
+    constexpr int NTHR = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT, CPR = HD / 8;
     constexpr int PITCH = HD + 8;                                      // 16-byte pad: conflict-free ds_read_b128 of a column of rows
     constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256;                // Q | dO tiles + lse / delta
-    constexpr int NCH = (32 * CPR + 255) / 256;                        // 16-byte chunks per thread per tile
+    constexpr int NCH = (32 * CPR + NTHR - 1) / NTHR;                        // 16-byte chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     const int dblk0 = blockIdx.y * NDB;
 
-    const int KT = (p.N + 31) / 32, KTB = (KT + 3) / 4;
+    const int KT = (p.N + 31) / 32, KTB = (KT + NWV - 1) / NWV;
     const int bh = blockIdx.x / KTB;
-    int kt = (blockIdx.x % KTB) * 4 + wave;
+    int kt = (blockIdx.x % KTB) * NWV + wave;
     const bool active = kt < KT;
     kt = min(kt, KT - 1);
     const int h = bh % p.H, b = bh / p.H;
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p
     auto gload = [&](int q0) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = min(tid + 256 * i, 32 * CPR - 1);
+            const int c = min(tid + NTHR * i, 32 * CPR - 1);
             const int r = c / CPR, cc = c % CPR;
             const long t = min(q0 + r, p.N - 1);
             rq[i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + base + t * st_ld + cc * 8);
@@ -506,8 +507,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p
         bf16_t* dO = q + 32 * PITCH;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            if (32 * CPR % 256 == 0 || c < 32 * CPR) {
+            const int c = tid + NTHR * i;
+            if (32 * CPR % NTHR == 0 || c < 32 * CPR) {
                 const int r = c / CPR, cc = c % CPR;
                 *reinterpret_cast<u32x4*>(q + r * PITCH + cc * 8) = rq[i];
                 *reinterpret_cast<u32x4*>(dO + r * PITCH + cc * 8) = rd[i];
@@ -582,17 +583,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_coop_kernel(const AttnArgs p
 // Counterparts of attn_fwd_kernel / attn_bwd_dq_kernel organised like attn_bwd_dkv_coop_kernel: the four waves of a workgroup own
 // four consecutive QUERY tiles of one (batch, head) and share one double-buffered stream of key tiles (K and V rows, hi and lo
 // planes in the split forward), staged by all 256 threads with the next tile prefetched into registers.
-template <int HD, int NT_>
+template <int HD, int NT_, int NTHR = 256>
 struct CoopStage {                                                     // NT_ tiles of [32 rows][HD] bf16 per buffer, padded pitch
     static constexpr int CPR = HD / 8, PITCH = HD + 8, TILE = 32 * PITCH;
-    static constexpr int NCH = (32 * CPR + 255) / 256;
+    static constexpr int NCH = (32 * CPR + NTHR - 1) / NTHR;
     static constexpr int BUF_BYTES = NT_ * TILE * 2;
     u32x4 r[NT_][NCH];
     __device__ __forceinline__ void gload(const bf16_t* const (&src)[NT_], const long (&rowoff)[NT_], const long (&pitch)[NT_], int t0,
                                           int N, int tid) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = min(tid + 256 * i, 32 * CPR - 1);
+            const int c = min(tid + NTHR * i, 32 * CPR - 1);
             const int row = c / CPR, cc = c % CPR;
             const long t = min(t0 + row, N - 1);
 #pragma unroll
@@ -603,8 +604,8 @@ struct CoopStage {                                                     // NT_ ti
         bf16_t* b = reinterpret_cast<bf16_t*>(buf);
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
-            const int c = tid + 256 * i;
-            if (32 * CPR % 256 == 0 || c < 32 * CPR) {
+            const int c = tid + NTHR * i;
+            if (32 * CPR % NTHR == 0 || c < 32 * CPR) {
                 const int row = c / CPR, cc = c % CPR;
 #pragma unroll
                 for (int k = 0; k < NT_; ++k) *reinterpret_cast<u32x4*>(b + k * TILE + row * PITCH + cc * 8) = r[k][i];
@@ -613,18 +614,20 @@ struct CoopStage {                                                     // NT_ ti
     }
 };
 
-template <int HD, bool SPLIT>
-__global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
+// NWV waves per workgroup (4 or 8): with eight, two waves share every SIMD and one's softmax / mask VALU phase runs beside the
+// other's MFMAs (the LDS stream and its footprint stay the same; twice the query rows per workgroup)
+template <int HD, bool SPLIT, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
-    using ST = CoopStage<HD, 2 * NPL>;                                 // K_hi [K_lo] V_hi [V_lo]
+    using ST = CoopStage<HD, 2 * NPL, 64 * NWV>;                       // K_hi [K_lo] V_hi [V_lo]
     constexpr int PITCH = ST::PITCH, TILE = ST::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
 
-    const int QT = (p.N + 31) / 32, QTB = (QT + 3) / 4;
+    const int QT = (p.N + 31) / 32, QTB = (QT + NWV - 1) / NWV;
     const int bh = blockIdx.x / QTB;
-    int qt = (blockIdx.x % QTB) * 4 + wave;
+    int qt = (blockIdx.x % QTB) * NWV + wave;
     const bool active = qt < QT;
     qt = min(qt, QT - 1);
     const int h = bh % p.H, b = bh / p.H;
@@ -761,18 +764,18 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_kernel(const AttnArgs p) {
     }
 }
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_coop_kernel(const AttnArgs p) {
+template <int HD, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
-    using ST = CoopStage<HD, 2>;                                       // K, V
+    using ST = CoopStage<HD, 2, 64 * NWV>;                             // K, V
     constexpr int PITCH = ST::PITCH, TILE = ST::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
 
-    const int QT = (p.N + 31) / 32, QTB = (QT + 3) / 4;
+    const int QT = (p.N + 31) / 32, QTB = (QT + NWV - 1) / NWV;
     const int bh = blockIdx.x / QTB;
-    int qt = (blockIdx.x % QTB) * 4 + wave;
+    int qt = (blockIdx.x % QTB) * NWV + wave;
     const bool active = qt < QT;
     qt = min(qt, QT - 1);
     const int h = bh % p.H, b = bh / p.H;
@@ -1056,11 +1059,31 @@ void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
+// waves per workgroup of the cooperative long-sequence kernels: S3D_ATTN_COOP_WAVES=4|8
+static int coop_waves() {
+    static const int w = [] { const char* v = getenv("S3D_ATTN_COOP_WAVES"); const int x = v ? atoi(v) : 4; return x == 8 ? 8 : 4; }();
+    return w;
+}
+
 template <int HD>
 int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     if (use_coop(a.N)) {                                        // long sequences: four query tiles share one key stream
         const int QT = (a.N + 31) / 32;
+        if (HD <= 192 && coop_waves() == 8) {                   // two waves per SIMD (the hd = 256 kernels are register-bound at one)
+            dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 7) / 8)));
+            if (split) {
+                const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
+                set_lds((attn_fwd_coop_kernel<HD, true, 8>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true, 8>), g, dim3(512), lds, s, a);
+            } else {
+                const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
+                set_lds((attn_fwd_coop_kernel<HD, false, 8>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 8>), g, dim3(512), lds, s, a);
+            }
+            S3D_CHECK_LAUNCH("attention_fwd_coop8");
+            return 0;
+        }
         dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
         if (split) {
             const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
@@ -1122,9 +1145,15 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const int KT = (a.N + 31) / 32;
     if (use_coop(a.N)) {
         const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
-        set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
-        dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
-        hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
+        if (HD <= 192 && coop_waves() == 8) {
+            set_lds((attn_bwd_dq_coop_kernel<HD, 8>), lds);
+            dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)));
+            hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 8>), g, dim3(512), lds, s, a);
+        } else {
+            set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
+            dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
+            hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
+        }
         S3D_CHECK_LAUNCH("attention_bwd_dq_coop");
     } else {
         const int lds = wpb * 32 * HD * 2;
@@ -1136,9 +1165,15 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
         const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256);
-        set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
-        dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
-        hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+        if (HD <= 192 && coop_waves() == 8) {
+            set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), lds);
+            dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)), DSPLIT);
+            hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), g2, dim3(512), lds, s, a);
+        } else {
+            set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
+            dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
+            hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+        }
         S3D_CHECK_LAUNCH("attention_bwd_dkv_coop");
     } else {
         const int lds = wpb * (2 * 32 * HD * 2 + 256);
