@@ -379,7 +379,7 @@ def main_points(args):
         add('batchnorm_bwd (td0.mlp_bns.1: relu/max backward + stats + apply; s3d_batchnorm_bwd)',
             lambda: lay['b1'].bwd(t0_.x2, R, t0_.dout, t0_.dx, K=KNN, arg=t0_.arg), R * ch * (4 + 2) + G * ch * (4 + 1))
         add('batchnorm_bwd (td0.mlp_bns.0: relu backward + stats + apply)',
-            lambda: lay['b0'].bwd(t0_.x1, R, t0_.dy1, t0_.dx), R * ch * (4 + 4 + 2))
+            lambda: lay["b0"].bwd(t0_.x1, R, t0_.dy1, t0_.dx), R * ch * (4 + 2 + 2))        # x fp32, dy bf16 (from the dgrad epilogue), dx bf16
         add('batchnorm_fwd + relu + max over 16 neighbours (td0.mlp_bns.1; s3d_batchnorm_fwd)',
             lambda: lay['b1'].fwd(t0_.x2, R, K=KNN, y=t0_.out, arg=t0_.arg), R * ch * 4 + G * ch * (4 + 1))
         add('group_project_fwd (td0: Pf[idx] + xyz_rel.Wx^T + b, BatchNorm column sums fused)',

@@ -391,6 +391,8 @@ typedef struct S3dBnArgs {
     float* y; uint16_t* y_hi; uint16_t* y_lo; int ldo;     /* fwd outputs: fp32 and/or split planes */
     unsigned char* arg;                   /* K > 0: argmax neighbour per (group, channel) */
     const float* dy; int lddy;            /* bwd: gradient wrt the (ReLU / max) output */
+    const uint16_t* dy_bf;                /* bwd: the same gradient as bf16 (row pitch lddy) instead of dy -- lets the dgrad GEMM that
+                                           * produces it write 2 bytes per element */
     uint16_t* dx; int lddx;               /* bwd: gradient wrt x as bf16 [rows][lddx] */
     float* dgamma; float* dbeta;
     int eval_mode;                        /* fwd: normalise with the running statistics (model.eval()), no update */

@@ -421,11 +421,21 @@ __global__ __launch_bounds__(256) void bn_relu_max_vec_kernel(const float* __res
     }
 }
 
+// upstream gradient quad from the fp32 tensor, or (dyb != nullptr) from its bf16 form -- the dgrad GEMM that produces it can write
+// bf16 directly: 0.4 GB instead of 0.8 GB written and half the bytes on each of the two reads of this backward (cfg-4 level 0)
+__device__ __forceinline__ f32x4 ld_grad4(const float* dy, const bf16_t* dyb, long off) {
+    if (dyb) {
+        const u32x2 w = *reinterpret_cast<const u32x2*>(dyb + off);
+        return f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+    }
+    return ld4(dy + off);
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_stats_vec_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
                                                                const unsigned char* __restrict__ arg, int K, long rows, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               double* __restrict__ sums) {
+                                                               double* __restrict__ sums, const bf16_t* __restrict__ dyb) {
     const BnLane l = bn_lane(C);
     const int c = 4 * l.q;
     const f32x4 m = ld4(mean + c), rs = ld4(rstd + c), g = ld4(gamma + c), be = ld4(beta + c);
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_vec_kernel(const float* __re
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     const long n = arg ? rows / K : rows;          // max mode iterates groups
     for (long r = (long)blockIdx.x * l.rpb + l.sub; l.on && r < n; r += (long)gridDim.x * l.rpb) {
-        const f32x4 d = ld4(dy + r * lddy + c);
+        const f32x4 d = ld_grad4(dy, dyb, r * lddy + c);
         f32x4 xv;
         if (arg) {
             const unsigned ab = *reinterpret_cast<const unsigned*>(arg + r * C + c);
@@ -459,7 +469,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ sums, bf16_t* __restrict__ dx, int lddx,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               const bf16_t* __restrict__ dyb) {
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             atomic_add_f32(dgamma + c, (float)sums[C + c]);
@@ -485,12 +496,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
             const long sg = r / uK;
             const unsigned kk = (unsigned)(r - sg * uK);
             const unsigned ab = *reinterpret_cast<const unsigned*>(arg + sg * C + c);
-            const f32x4 d = ld4(dy + sg * lddy + c);
+            const f32x4 d = ld_grad4(dy, dyb, sg * lddy + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (kk == ((ab >> (8 * i)) & 255u) && xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
         } else {
-            const f32x4 d = ld4(dy + r * lddy + c);
+            const f32x4 d = ld_grad4(dy, dyb, r * lddy + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
@@ -886,7 +897,9 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
 }
 int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     const unsigned char* arg = a.K > 0 ? a.arg : nullptr;
-    const bool vec = bn_vec_ok(a) && a.lddy % 4 == 0 && a.lddx % 4 == 0 && a.K <= 255 && al(a.dy, 16) && al(a.dx, 8) && al(arg, 4);
+    const bool vec = bn_vec_ok(a) && a.lddy % 4 == 0 && a.lddx % 4 == 0 && a.K <= 255 && al(a.dy, 16) && al(a.dy_bf, 8) && al(a.dx, 8) && al(arg, 4);
+    S3D_REQUIRE(a.dy != nullptr || a.dy_bf != nullptr, "batchnorm bwd: dy (fp32) or dy_bf (bf16) required");
+    S3D_REQUIRE(a.dy_bf == nullptr || vec, "batchnorm bwd: a bf16 upstream gradient needs the vector kernels (C %% 4 == 0, aligned rows)");
     S3D_REQUIRE(a.C > 0 && (a.C <= 256 || (a.C <= 1024 && vec)),
                 "batchnorm: C=%d must be in 1..256 (or a multiple of 4 up to 1024 with 16-byte aligned rows)", a.C);
     (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
@@ -895,9 +908,9 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     if (vec) {
         const int rpb = 256 / (a.C / 4);
         hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
-                           a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums);
+                           a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dy_bf);
         hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(a.rows, rpb, 8192)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg,
-                           a.K, a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta);
+                           a.K, a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta, a.dy_bf);
         S3D_CHECK_LAUNCH("batchnorm_bwd");
         return 0;
     }

@@ -216,9 +216,11 @@ class _BatchNorm:
         L.check(self.eng.lib.s3d_batchnorm_fwd(ctypes.byref(self._args(x, rows, K, **kw)), L.current_stream()), self.key)
 
     def bwd(self, x, rows, dy, dx, K=0, arg=None):
+        """dy: fp32 or bf16 [rows (or groups)][C] gradient wrt the output"""
         a = self.eng.arena
-        args = self._args(x, rows, K, dy=dy, lddy=self.C, dx=dx, lddx=self.C, arg=arg, dgamma=a.grad(self.key + '.weight'),
-                          dbeta=a.grad(self.key + '.bias'))
+        gkw = dict(dy_bf=dy) if dy.dtype == torch.bfloat16 else dict(dy=dy)
+        args = self._args(x, rows, K, lddy=self.C, dx=dx, lddx=self.C, arg=arg, dgamma=a.grad(self.key + '.weight'),
+                          dbeta=a.grad(self.key + '.bias'), **gkw)
         L.check(self.eng.lib.s3d_batchnorm_bwd(ctypes.byref(args), L.current_stream()), self.key + ' bwd')
 
 
@@ -401,7 +403,7 @@ class PointEngine:
             t.x2 = torch.empty(R, ch, **f32); t.out = torch.empty(B * S, ch, **f32)
             t.arg = torch.empty(B * S, ch, dtype=torch.uint8, device=dev)
             t.dx = torch.empty(R, ch, **b16)                  # bf16 gradient scratch (dx2 then dx1)
-            t.dy1 = torch.empty(R, ch, **f32)
+            t.dy1 = torch.empty(R, ch, **b16)                 # d(conv1 input) straight from the dgrad epilogue as bf16 (read twice by the BatchNorm backward)
             t.dout = torch.empty(B * S, ch, **f32)            # gradient wrt this level's output features
             ws.td.append(t)
             xyz_n, cprev = S, ch
@@ -706,7 +708,7 @@ class PointEngine:
             t, lay = ws.td[i], self.td[i]
             ch = self.ch[i]
             lay['b1'].bwd(t.x2, t.R, t.dout, t.dx, K=KNN, arg=t.arg)
-            lay['c1'].bwd(t.dx, t.y1[0], t.R, dx=t.dy1, dx_epi=4)
+            lay['c1'].bwd(t.dx, t.y1[0], t.R, dx_epi=0, O_hi=t.dy1, ldo=ch)
             lay['b0'].bwd(t.x1, t.R, t.dy1, t.dx)
             gp, a = lay['gp'], self.arena
             L.check(lib.s3d_group_project_bwd(ctypes.byref(gp.args(t, t.xyz_in, B, dx=t.dx, lddx=ch, dPf=t.dPf, inv_off=t.inv_off,
