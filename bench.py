@@ -113,7 +113,13 @@ def pmc_traffic(key):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_step_traffic.json')
     try:
         with open(path) as f:
-            k = json.load(f)['kernels'].get(rocprof_name(key))
+            kernels = json.load(f)['kernels']
+        want = rocprof_name(key)
+        k = kernels.get(want)
+        if k is None:                          # later template parameters (wave grid, loop mode, k-tail) follow the ones named here
+            stem = want[:-1]
+            hits = [n for n in kernels if n.startswith(stem + ',') or n.startswith(stem + '>')]
+            k = kernels[hits[0]] if len(hits) == 1 else None
         return (k['hbm_bytes_per_launch'], k) if k else (None, None)
     except (OSError, ValueError, KeyError):
         return None, None

@@ -616,7 +616,7 @@ struct CoopStage {                                                     // NT_ ti
 
 // NWV waves per workgroup (4 or 8): with eight, two waves share every SIMD and one's softmax / mask VALU phase runs beside the
 // other's MFMAs (the LDS stream and its footprint stay the same; twice the query rows per workgroup)
-template <int HD, bool SPLIT, int NWV = 4>
+template <int HD, bool SPLIT, int NWV = 4, bool DROP = true>
 __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
     const int q0 = qt * 32, qrow = q0 + l31;
     const bool qok = qrow < p.N;
     const int qrow_c = min(qrow, p.N - 1);
-    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const unsigned long long dkey = (DROP && p.drop_thr) ? drop_key(p.drop_seed, p.drop_site) : 0ull;
     const DropRow drow = drop_row(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N);     // mask index = row base + key column
 
     bf16x8 qh[NS], ql[SPLIT ? NS : 1];
@@ -710,7 +710,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
         lsum = half_sum(lsum);
         l_i = l_i * alpha + lsum;
         m_i = mnew;
-        if (p.drop_thr) {
+        if (DROP && p.drop_thr) {                                 // DROP = false: the masked path is compiled out (hd = 256 spilled with it)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 sv[r] = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
@@ -1087,12 +1087,22 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
         dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
         if (split) {
             const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
-            set_lds(attn_fwd_coop_kernel<HD, true>, lds);
-            hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true>), g, dim3(256), lds, s, a);
+            if (a.drop_thr) {
+                set_lds((attn_fwd_coop_kernel<HD, true, 4, true>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true, 4, true>), g, dim3(256), lds, s, a);
+            } else {
+                set_lds((attn_fwd_coop_kernel<HD, true, 4, false>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true, 4, false>), g, dim3(256), lds, s, a);
+            }
         } else {
             const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
-            set_lds(attn_fwd_coop_kernel<HD, false>, lds);
-            hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false>), g, dim3(256), lds, s, a);
+            if (a.drop_thr) {
+                set_lds((attn_fwd_coop_kernel<HD, false, 4, true>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 4, true>), g, dim3(256), lds, s, a);
+            } else {
+                set_lds((attn_fwd_coop_kernel<HD, false, 4, false>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 4, false>), g, dim3(256), lds, s, a);
+            }
         }
         S3D_CHECK_LAUNCH("attention_fwd_coop");
         return 0;
