@@ -536,19 +536,33 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsQ + off), kf[s], sacc);      // S  = Q . K^T   (col = key)
             dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsDO + off), vf[s], dpacc);   // dP = dO . V^T
         }
+        // lse / delta of the 16 query rows this lane's accumulator registers belong to: rows come in four runs of four consecutive
+        // ones (acc_row) -> eight 16-byte LDS reads instead of 32 scalar ones; the two bf16 operands are converted in pairs
+        f32x4 lse4[4], del4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            lse4[g] = *reinterpret_cast<const f32x4*>(ldsR + 8 * g + 4 * h2);
+            del4[g] = *reinterpret_cast<const f32x4*>(ldsR + 32 + 8 * g + 4 * h2);
+        }
         U128 pf[2], dsf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = 8 * s2 + j, qr = acc_row(r, h2);
-                const int q = q0 + qr;
-                const bool ok = kok && (q < p.N);
-                const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[qr]) : 0.f;
-                float dm = 1.f;
-                if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)min(q, p.N - 1) * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
-                pf[s2].h[j] = f2bf(pr * dm);
-                dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[32 + qr]) * p.scale);
+            for (int j = 0; j < 8; j += 2) {
+                float pv[2], dv2[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 8 * s2 + j + e, qr = acc_row(r, h2);
+                    const int q = q0 + qr;
+                    const bool ok = kok && (q < p.N);
+                    const float pr = ok ? fast_exp(sacc[r] * p.scale - lse4[r >> 2][r & 3]) : 0.f;
+                    float dm = 1.f;     // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
+                    if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)q * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
+                    pv[e] = pr * dm;
+                    dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
+                }
+                pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
+                dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
             }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
@@ -843,13 +857,18 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = 8 * s2 + j;
-                const bool ok = (k0 + acc_row(r, h2)) < p.N;
-                const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
-                float dpn = dpacc[r];
-                if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
-                dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
+            for (int j = 0; j < 8; j += 2) {
+                float dsv[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 8 * s2 + j + e;
+                    const bool ok = (k0 + acc_row(r, h2)) < p.N;
+                    const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+                    float dpn = dpacc[r];
+                    if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                    dsv[e] = pr * (dpn - delta) * p.scale;
+                }
+                dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
             }
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
