@@ -77,6 +77,49 @@ __device__ __forceinline__ bf16x8 gather_frag(const bf16_t* lds, int s2, int h2,
     return u.v;
 }
 
+// Both k-halves (s2 = 0, 1) of ONE staged tile, or of TWO tiles, with a single wait: the four / eight transpose reads are in flight
+// together (rows 16*s2 + .. sit at compile-time offsets from one address).  gather_frag waits after every pair of reads; the
+// value-times-probability loops issued 12 - 24 of those exposed LDS round trips per key tile.
+template <int HD, int PITCH = HD>
+__device__ __forceinline__ void gather_frag_s2(const bf16_t* lds, int h2, int col, bf16x8 (&f)[2]) {
+    const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
+    int c = (col & ~31) + 16 * (g & 1) + 4 * (t & 3);
+    if (HD % 32 != 0) c = min(c, HD - 4);
+    const unsigned addr = (unsigned)(uintptr_t)(lds + (4 * h2 + (t >> 2)) * PITCH + c);
+    u32x2 r0, r1, r2, r3;
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%5\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:%6\n\tds_read_b64_tr_b16 %3, %4 offset:%7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+                 : "v"(addr), "n"(8 * PITCH * 2), "n"(16 * PITCH * 2), "n"(24 * PITCH * 2)
+                 : "memory");
+    U128 u0, u1;
+    u0.u = u32x4{r0[0], r0[1], r1[0], r1[1]};
+    u1.u = u32x4{r2[0], r2[1], r3[0], r3[1]};
+    f[0] = u0.v; f[1] = u1.v;
+}
+template <int HD, int PITCH = HD>
+__device__ __forceinline__ void gather_frag_2x2(const bf16_t* ldsA, int colA, const bf16_t* ldsB, int colB, int h2, bf16x8 (&fa)[2],
+                                                bf16x8 (&fb)[2]) {
+    const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
+    int cA = (colA & ~31) + 16 * (g & 1) + 4 * (t & 3), cB = (colB & ~31) + 16 * (g & 1) + 4 * (t & 3);
+    if (HD % 32 != 0) { cA = min(cA, HD - 4); cB = min(cB, HD - 4); }
+    const int e = (4 * h2 + (t >> 2)) * PITCH;
+    const unsigned aA = (unsigned)(uintptr_t)(ldsA + e + cA), aB = (unsigned)(uintptr_t)(ldsB + e + cB);
+    u32x2 r0, r1, r2, r3, q0, q1, q2, q3;
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:%11\n\tds_read_b64_tr_b16 %3, %8 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:%10\n\t"
+                 "ds_read_b64_tr_b16 %6, %9 offset:%11\n\tds_read_b64_tr_b16 %7, %9 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                 : "v"(aA), "v"(aB), "n"(8 * PITCH * 2), "n"(16 * PITCH * 2), "n"(24 * PITCH * 2)
+                 : "memory");
+    U128 u;
+    u.u = u32x4{r0[0], r0[1], r1[0], r1[1]}; fa[0] = u.v;
+    u.u = u32x4{r2[0], r2[1], r3[0], r3[1]}; fa[1] = u.v;
+    u.u = u32x4{q0[0], q0[1], q1[0], q1[1]}; fb[0] = u.v;
+    u.u = u32x4{q2[0], q2[1], q3[0], q3[1]}; fb[1] = u.v;
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
 // ------------------------------------------------------------------------------------------- forward
@@ -185,17 +228,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             for (int j = 0; j < 8; j += 2) split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
         __syncthreads();                                          // V tile is staged
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; ++d) {
+            bf16x8 vh[2], vl[2];
+            if constexpr (SPLIT) gather_frag_2x2<HD>(ldsV, d * 32 + l31, ldsV + 32 * HD, d * 32 + l31, h2, vh, vl);
+            else gather_frag_s2<HD>(ldsV, h2, d * 32 + l31, vh);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 vh = gather_frag<HD>(ldsV, s2, h2, d * 32 + l31);
                 if constexpr (SPLIT) {
-                    const bf16x8 vl = gather_frag<HD>(ldsV + 32 * HD, s2, h2, d * 32 + l31);
-                    o[d] = MFMA32(vl, ph[s2].v, o[d]);
-                    o[d] = MFMA32(vh, pl[s2].v, o[d]);
+                    o[d] = MFMA32(vl[s2], ph[s2].v, o[d]);
+                    o[d] = MFMA32(vh[s2], pl[s2].v, o[d]);
                 }
-                o[d] = MFMA32(vh, ph[s2].v, o[d]);
+                o[d] = MFMA32(vh[s2], ph[s2].v, o[d]);
             }
+        }
     }
 
     if (active && qok) {
@@ -303,10 +348,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
             }
         __syncthreads();
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; d += 2) {
+            bf16x8 k0f[2], k1f[2];
+            if (d + 1 < NDB) gather_frag_2x2<HD>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0f, k1f);
+            else gather_frag_s2<HD>(ldsK, h2, d * 32 + l31, k0f);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                dq[d] = MFMA32(gather_frag<HD>(ldsK, s2, h2, d * 32 + l31), dsf[s2].v, dq[d]);   // dQ^T = K^T . dS^T
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dq[d] = MFMA32(k0f[s2], dsf[s2].v, dq[d]);                                    // dQ^T = K^T . dS^T
+                if (d + 1 < NDB) dq[d + 1] = MFMA32(k1f[s2], dsf[s2].v, dq[d + 1]);
+            }
+        }
     }
     if (active && qok) {
         const long orow = tokrow * p.lddq + h * HD;
@@ -409,13 +460,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - del_r) * p.scale);
             }
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; ++d) {
+            const int col = (dblk0 + d) * 32 + l31;
+            bf16x8 fo[2], fq[2];
+            gather_frag_2x2<HD>(ldsDO, col, ldsQ, col, h2, fo, fq);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int col = (dblk0 + d) * 32 + l31;
-                dv[d] = MFMA32(gather_frag<HD>(ldsDO, s2, h2, col), pf[s2].v, dv[d]);    // dV^T = dO^T . P
-                dk[d] = MFMA32(gather_frag<HD>(ldsQ, s2, h2, col), dsf[s2].v, dk[d]);    // dK^T = Q^T . dS
+                dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
+                dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
             }
+        }
     }
     if (active && kok) {
         const long orow = ((long)b * p.sb + (long)krow * p.st) * p.lddq + h * HD;
@@ -565,13 +619,16 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                 dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
             }
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; ++d) {
+            const int col = (dblk0 + d) * 32 + l31;
+            bf16x8 fo[2], fq[2];
+            gather_frag_2x2<HD, PITCH>(ldsDO, col, ldsQ, col, h2, fo, fq);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const int col = (dblk0 + d) * 32 + l31;
-                dv[d] = MFMA32((gather_frag<HD, PITCH>(ldsDO, s2, h2, col)), pf[s2].v, dv[d]);    // dV^T = dO^T . P
-                dk[d] = MFMA32((gather_frag<HD, PITCH>(ldsQ, s2, h2, col)), dsf[s2].v, dk[d]);    // dK^T = Q^T . dS
+                dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
+                dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
             }
+        }
         if (more) lstore((qt + 1) & 1);
         __syncthreads();
     }
@@ -744,17 +801,19 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
 #pragma unroll
             for (int j = 0; j < 8; j += 2) split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; ++d) {
+            bf16x8 vh[2], vl[2];
+            if constexpr (SPLIT) gather_frag_2x2<HD, PITCH>(ldsVh, d * 32 + l31, ldsVl, d * 32 + l31, h2, vh, vl);
+            else gather_frag_s2<HD, PITCH>(ldsVh, h2, d * 32 + l31, vh);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 vh = gather_frag<HD, PITCH>(ldsVh, s2, h2, d * 32 + l31);
                 if constexpr (SPLIT) {
-                    const bf16x8 vl = gather_frag<HD, PITCH>(ldsVl, s2, h2, d * 32 + l31);
-                    o[d] = MFMA32(vl, ph[s2].v, o[d]);
-                    o[d] = MFMA32(vh, pl[s2].v, o[d]);
+                    o[d] = MFMA32(vl[s2], ph[s2].v, o[d]);
+                    o[d] = MFMA32(vh[s2], pl[s2].v, o[d]);
                 }
-                o[d] = MFMA32(vh, ph[s2].v, o[d]);
+                o[d] = MFMA32(vh[s2], ph[s2].v, o[d]);
             }
+        }
         if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
         __syncthreads();
     }
@@ -871,10 +930,16 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
                 dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
             }
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d = 0; d < NDB; d += 2) {
+            bf16x8 k0[2], k1[2];
+            if (d + 1 < NDB) gather_frag_2x2<HD, PITCH>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0, k1);
+            else gather_frag_s2<HD, PITCH>(ldsK, h2, d * 32 + l31, k0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-                dq[d] = MFMA32((gather_frag<HD, PITCH>(ldsK, s2, h2, d * 32 + l31)), dsf[s2].v, dq[d]);   // dQ^T = K^T . dS^T
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dq[d] = MFMA32(k0[s2], dsf[s2].v, dq[d]);                                     // dQ^T = K^T . dS^T
+                if (d + 1 < NDB) dq[d + 1] = MFMA32(k1[s2], dsf[s2].v, dq[d + 1]);
+            }
+        }
         if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
         __syncthreads();
     }
@@ -982,11 +1047,19 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
             }
         f32x16 dq[NDB];
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) {
+        for (int d = 0; d < NDB; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) dq[d] = MFMA32(gather_frag<HD>(ldsK, s2, h2, d * 32 + l31), dsf[s2].v, dq[d]);
+        for (int d = 0; d < NDB; d += 2) {
+            bf16x8 k0f[2], k1f[2];
+            if (d + 1 < NDB) gather_frag_2x2<HD>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0f, k1f);
+            else gather_frag_s2<HD>(ldsK, h2, d * 32 + l31, k0f);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dq[d] = MFMA32(k0f[s2], dsf[s2].v, dq[d]);
+                if (d + 1 < NDB) dq[d + 1] = MFMA32(k1f[s2], dsf[s2].v, dq[d + 1]);
+            }
         }
         if (active && tok_ok) {
             const long orow = tokrow * p.lddq + h * HD;
@@ -1032,10 +1105,12 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
         for (int d = 0; d < NDB; ++d) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+            bf16x8 fo[2], fq[2];
+            gather_frag_2x2<HD>(ldsDO, d * 32 + l31, ldsQ, d * 32 + l31, h2, fo, fq);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                dv[d] = MFMA32(gather_frag<HD>(ldsDO, s2, h2, d * 32 + l31), pf[s2].v, dv[d]);
-                dk[d] = MFMA32(gather_frag<HD>(ldsQ, s2, h2, d * 32 + l31), dsf[s2].v, dk[d]);
+                dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);
+                dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);
             }
         }
         if (active && tok_ok) {
