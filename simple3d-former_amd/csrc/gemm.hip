@@ -884,6 +884,83 @@ __device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int col
     return u.v;
 }
 
+// NF fragments (columns col16, col16 + 16, ..) of one k-major tile -- or of an A and a B tile -- with ONE wait: all transpose
+// reads of a k-step are in flight together.  frag_kmajor waits per fragment: FM + FN exposed LDS round trips for FM * FN MFMAs.
+template <int COLS>
+__device__ __forceinline__ unsigned kmajor_addr(const unsigned char* tile, int col16, int kq8, int lane) {
+    const int t = lane & 15;
+    const int row = kq8 + (t >> 2), col = col16 + 4 * (t & 3);
+    const int slot = (col >> 3) ^ kmajor_swz<COLS>(row);
+    return (unsigned)(uintptr_t)(tile + row * (COLS * 2) + slot * 16 + (col & 7) * 2);
+}
+__device__ __forceinline__ bf16x8 tr_pack(const u32x2 lo, const u32x2 hi) {
+    U128 u;
+    u.u = u32x4{lo[0], lo[1], hi[0], hi[1]};
+    return u.v;
+}
+template <int COLS, int NF>
+__device__ __forceinline__ void frags_kmajor(const unsigned char* tile, int col16, int kq8, int lane, bf16x8 (&out)[NF]) {
+    static_assert(NF == 2 || NF == 4, "two or four fragments per call");
+    unsigned ad[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) ad[i] = kmajor_addr<COLS>(tile, col16 + 16 * i, kq8, lane);
+    u32x2 l[NF], h[NF];
+    if constexpr (NF == 2) {
+        asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:%6\n\t"
+                     "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:%6\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1])
+                     : "v"(ad[0]), "v"(ad[1]), "n"(4 * COLS * 2)
+                     : "memory");
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(l[0]), "=&v"(h[0]), "=&v"(l[1]), "=&v"(h[1]), "=&v"(l[2]), "=&v"(h[2]), "=&v"(l[3]), "=&v"(h[3])
+                     : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "n"(4 * COLS * 2)
+                     : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) out[i] = tr_pack(l[i], h[i]);
+}
+// A and B tiles of a wgrad k-step together (2 * NF fragments, one wait)
+template <int COLS, int NF>
+__device__ __forceinline__ void frags_kmajor_ab(const unsigned char* tA, int colA, const unsigned char* tB, int colB, int kq8, int lane,
+                                                bf16x8 (&fa)[NF], bf16x8 (&fb)[NF]) {
+    static_assert(NF == 2 || NF == 4, "two or four fragments per operand");
+    unsigned aa[NF], ab[NF];
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        aa[i] = kmajor_addr<COLS>(tA, colA + 16 * i, kq8, lane);
+        ab[i] = kmajor_addr<COLS>(tB, colB + 16 * i, kq8, lane);
+    }
+    u32x2 la[NF], ha[NF], lb[NF], hb[NF];
+    if constexpr (NF == 2) {
+        asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %9 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %10 offset:%12\n\t"
+                     "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %11 offset:%12\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(la[0]), "=&v"(ha[0]), "=&v"(la[1]), "=&v"(ha[1]), "=&v"(lb[0]), "=&v"(hb[0]), "=&v"(lb[1]), "=&v"(hb[1])
+                     : "v"(aa[0]), "v"(aa[1]), "v"(ab[0]), "v"(ab[1]), "n"(4 * COLS * 2)
+                     : "memory");
+    } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %20 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %10, %21\n\tds_read_b64_tr_b16 %11, %21 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %12, %22\n\tds_read_b64_tr_b16 %13, %22 offset:%24\n\t"
+                     "ds_read_b64_tr_b16 %14, %23\n\tds_read_b64_tr_b16 %15, %23 offset:%24\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(la[0]), "=&v"(ha[0]), "=&v"(la[1]), "=&v"(ha[1]), "=&v"(la[2]), "=&v"(ha[2]), "=&v"(la[3]), "=&v"(ha[3]),
+                       "=&v"(lb[0]), "=&v"(hb[0]), "=&v"(lb[1]), "=&v"(hb[1]), "=&v"(lb[2]), "=&v"(hb[2]), "=&v"(lb[3]), "=&v"(hb[3])
+                     : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(ab[0]), "v"(ab[1]), "v"(ab[2]), "v"(ab[3]), "n"(4 * COLS * 2)
+                     : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < NF; ++i) { fa[i] = tr_pack(la[i], ha[i]); fb[i] = tr_pack(lb[i], hb[i]); }
+}
+
 // KTAIL: instantiation that accepts a partial last k-tile (kept apart: its extra per-piece state costs the cfg-2 pair launches 1.5 %)
 template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false>
 __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
@@ -977,15 +1054,18 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a_hi[FM], b_hi[FN];
+            const int kq8 = ks * 32 + (lane >> 4) * 8;
+            if constexpr (TA && TB) {
+                frags_kmajor_ab<BM, FM>(sA, wm * (BM / 2), sB, wn * (BN / 2), kq8, lane, a_hi, b_hi);
+            } else {
 #pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                if constexpr (TA) a_hi[i] = frag_kmajor<BM>(sA, wm * (BM / 2) + i * 16, ks * 32 + (lane >> 4) * 8, lane);
-                else a_hi[i] = read_frag_dma(sA, wm * (BM / 2) + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
-            }
+                for (int i = 0; i < FM; ++i)
+                    if constexpr (!TA) a_hi[i] = read_frag_dma(sA, wm * (BM / 2) + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                if constexpr (TB) b_hi[j] = frag_kmajor<BN>(sB, wn * (BN / 2) + j * 16, ks * 32 + (lane >> 4) * 8, lane);
-                else b_hi[j] = read_frag_dma(sB, wn * (BN / 2) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                for (int j = 0; j < FN; ++j)
+                    if constexpr (!TB) b_hi[j] = read_frag_dma(sB, wn * (BN / 2) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                if constexpr (TA) frags_kmajor<BM, FM>(sA, wm * (BM / 2), kq8, lane, a_hi);
+                if constexpr (TB) frags_kmajor<BN, FN>(sB, wn * (BN / 2), kq8, lane, b_hi);
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
