@@ -207,15 +207,30 @@ template <int W> __device__ __forceinline__ void ld_bf(BfVec<W>& v, const bf16_t
 
 // One lane's share of a vector epilogue: row m, W consecutive columns n .. n+W-1 (accumulators v).  N % W == 0, so the
 // group is all-in or all-out.
+// What an epilogue READS from memory for its W outputs (bias, residual, saved pre-activation), apart from the accumulators.  The
+// staged tile epilogues fetch these for all of a thread's outputs BEFORE the accumulators go through LDS: a load issued next to
+// its use costs its whole latency (0.5 - 2 us from L2 / HBM) once per output group -- eight times per thread on a 128x128 tile
+// (timeline at M = 32 768: 25 - 27 k cycles for the residual epilogue of proj, a quarter of the workgroup's lifetime).
+template <int W> struct EpiPre {
+    float bq[W], rr[W];
+    BfVec<W> ax;
+};
 template <int EPI, int W>
-__device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, const int n, const float (&v)[W]) {
-    if (m >= p.M || n >= p.N) return;
-    float bq[W];
+__device__ __forceinline__ void epi_prefetch(const GemmArgs& p, const int m, const int n, EpiPre<W>& q, const bool with_bias = true) {
 #pragma unroll
-    for (int r = 0; r < W; ++r) bq[r] = 0.f;
+    for (int r = 0; r < W; ++r) { q.bq[r] = 0.f; q.rr[r] = 0.f; }
+    if (m >= p.M || n >= p.N) return;
     if constexpr (EPI != EPI_ATOMIC && EPI != EPI_DGELU && EPI != EPI_DRELU) {
-        if (p.bias) ld_f32<W>(bq, p.bias + n);
+        if (with_bias && p.bias) ld_f32<W>(q.bq, p.bias + n);
     }
+    if constexpr (EPI == EPI_RESID) ld_f32<W>(q.rr, p.R + (long)m * p.ldr + n);
+    if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) ld_bf<W>(q.ax, p.aux + (long)m * p.ldaux + n);
+}
+
+template <int EPI, int W>
+__device__ __forceinline__ void epilogue_core(const GemmArgs& p, const int m, const int n, const float (&v)[W], const float (&bq)[W],
+                                              const float (&rr)[W], const BfVec<W>& ax_in) {
+    if (m >= p.M || n >= p.N) return;
     BfVec<W> hi, lo, ax;
     float dm[W];                                        // dropout multipliers (RESID / RELU / DRELU only)
 #pragma unroll
@@ -250,8 +265,7 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, con
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
         if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
     } else if constexpr (EPI == EPI_RESID) {
-        float rr[W], o[W];
-        ld_f32<W>(rr, p.R + (long)m * p.ldr + n);
+        float o[W];
 #pragma unroll
         for (int r = 0; r < W; ++r) o[r] = (v[r] + bq[r]) * dm[r] + rr[r];
         if (p.ln_tickets) st_f32_wt<W>(p.C + (long)m * p.ldc + n, o);     // block-uniform: another workgroup of THIS launch reads it
@@ -275,15 +289,49 @@ __device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, con
         for (int r = 0; r < W; ++r) o[r] = v[r] * p.alpha + bq[r];
         st_f32<W>(p.C + (long)m * p.ldc + n, o);
     } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
-        ld_bf<W>(ax, p.aux + (long)m * p.ldaux + n);
 #pragma unroll
         for (int r = 0; r < W; ++r) {
-            const float pre = bf2f(ax.h[r]);
+            const float pre = bf2f(ax_in.h[r]);
             hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
         }
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
     }
 }
+
+template <int EPI, int W>
+__device__ __forceinline__ void epilogue_vec(const GemmArgs& p, const int m, const int n, const float (&v)[W]) {
+    EpiPre<W> q;
+    epi_prefetch<EPI, W>(p, m, n, q);
+    epilogue_core<EPI, W>(p, m, n, v, q.bq, q.rr, q.ax);
+}
+
+// Epilogue of a tile staged through LDS as fp32 [BM][BN + 4]: thread `tid` owns the 8-column groups c = tid, tid + NTHR, ...
+// prefetch() before the accumulators are parked (its loads fly during the two barriers and the LDS pass), run() after.
+template <int EPI, int BM, int BN, int NTHR>
+struct StagedEpilogue {
+    static constexpr int LDC = BN + 4, CPR = BN / 8, TOT = BM * CPR, ITER = (TOT + NTHR - 1) / NTHR;
+    static constexpr bool ONE_COL = (NTHR % CPR) == 0;                  // a thread's groups all sit in the same 8 columns
+    EpiPre<8> q[ITER];
+    __device__ __forceinline__ void prefetch(const GemmArgs& p, const int m0, const int n0, const int tid) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tid + it * NTHR;
+            const int row = c / CPR, col = (c % CPR) * 8;
+            epi_prefetch<EPI, 8>(p, c < TOT ? m0 + row : p.M, n0 + col, q[it], !ONE_COL || it == 0);
+        }
+    }
+    __device__ __forceinline__ void run(const GemmArgs& p, const float* ct, const int m0, const int n0, const int tid) {
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int c = tid + it * NTHR;
+            if (c >= TOT) break;
+            const int row = c / CPR, col = (c % CPR) * 8;
+            float v[8];
+            ld_f32<8>(v, ct + row * LDC + col);
+            epilogue_core<EPI, 8>(p, m0 + row, n0 + col, v, ONE_COL ? q[0].bq : q[it].bq, q[it].rr, q[it].ax);
+        }
+    }
+};
 
 // PD = register prefetch distance (tiles of global loads in flight per thread).  These GEMMs are small (M = 1664
 // rows at cfg-2) and latency-bound: bytes in flight per CU / memory latency sets the rate, so the loads of tile
@@ -467,8 +515,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
         // the epilogue is store-ISSUE-bound (~7 B/clk/CU) and cost 3-6 us of the 10-18 us these GEMMs take.  The tile goes
         // through LDS (fp32, rows padded by 16 bytes) instead, and every thread finishes 8 consecutive columns of one row:
         // 16-byte stores, 8 lanes per 128-byte line of a bf16 output.
-        constexpr int LDC = BN + 4, CPR = BN / 8;
+        constexpr int LDC = BN + 4;
         float* ct = reinterpret_cast<float*>(smem);
+        StagedEpilogue<EPI, BM, BN, 256> se;
+        se.prefetch(p, m0, n0, tid);
         __syncthreads();                                // every wave is done reading the operand stages
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -477,13 +527,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                 *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) =
                     acc[i][j];
         __syncthreads();
-#pragma unroll
-        for (int c = tid; c < BM * CPR; c += 256) {
-            const int row = c / CPR, col = (c % CPR) * 8;
-            float v[8];
-            ld_f32<8>(v, ct + row * LDC + col);
-            epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
-        }
+        se.run(p, ct, m0, n0, tid);
     } else {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -819,8 +863,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         }
     }
     // staged epilogue (see gemm_body)
-    constexpr int LDC = BN + 4, CPR = BN / 8;
+    constexpr int LDC = BN + 4;
     float* ct = reinterpret_cast<float*>(smem);
+    StagedEpilogue<EPI, BM, BN, NTHR> se;
+    se.prefetch(p, m0, n0, tid);
     __syncthreads();
     TL_STAMP(4);                                                       // mainloop done
 #pragma unroll
@@ -829,13 +875,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         for (int j = 0; j < FN; ++j)
             *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
     __syncthreads();
-#pragma unroll
-    for (int c = tid; c < BM * CPR; c += NTHR) {
-        const int row = c / CPR, col = (c % CPR) * 8;
-        float v[8];
-        ld_f32<8>(v, ct + row * LDC + col);
-        epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
-    }
+    se.run(p, ct, m0, n0, tid);
     if constexpr (EPI == EPI_RESID) {
         if (p.ln_tickets) {                                            // block-uniform
             __syncthreads();                                           // the staged tile in LDS has been consumed: reuse a word of it
@@ -1102,8 +1142,10 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
                 }
         }
     } else {
-        constexpr int LDC = BN + 4, CPR = BN / 8;
+        constexpr int LDC = BN + 4;
         float* ct = reinterpret_cast<float*>(smem);
+        StagedEpilogue<EPI, BM, BN, 256> se;
+        se.prefetch(p, m0, n0, tid);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -1111,13 +1153,7 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
             for (int j = 0; j < FN; ++j)
                 *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) = acc[i][j];
         __syncthreads();
-#pragma unroll
-        for (int c = tid; c < BM * CPR; c += 256) {
-            const int row = c / CPR, col = (c % CPR) * 8;
-            float v[8];
-            ld_f32<8>(v, ct + row * LDC + col);
-            epilogue_vec<EPI, 8>(p, m0 + row, n0 + col, v);
-        }
+        se.run(p, ct, m0, n0, tid);
     }
 }
 

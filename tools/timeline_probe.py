@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simple3d_former_amd import _lib as L, ops  # noqa: E402
 
 SLOTS = 40
-M, D = 1664, 384
+M, D = int(os.environ.get('TL_M', '1664')), int(os.environ.get('TL_D', '384'))      # TL_M=32768 TL_D=768 TL_BK=32 S3D_GEMM_NT_TILE=2: cfg-3
 DEV = 'cuda'
 TILES = {0: (32, 64), 1: (64, 64), 3: (32, 32), 2: (128, 128), 4: (128, 96), 5: (64, 128), 6: (64, 64), 7: (128, 128), 8: (64, 96), 9: (32, 64), 10: (32, 32), 11: (128, 128), 12: (64, 64), 13: (32, 64), 14: (128, 128), 15: (64, 192), 16: (128, 128), 17: (128, 96), 18: (64, 64), 19: (32, 64)}
 
