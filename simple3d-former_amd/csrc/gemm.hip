@@ -679,7 +679,9 @@ constexpr int TL_SLOTS = 40;
 // LDS-read phase (~500 cycles for a 128x128 split tile) and the MFMA phase (~800) add up (measured 1.7 k cycles per k = 32 step).
 // Here the fragments of sub-step s+1 are requested BEFORE the MFMAs of sub-step s are issued (two register sets), across the
 // stage boundary too: [stage t+1 landed: counted vmcnt + barrier] -> refill the ring -> read fragments(t+1) -> MFMAs(t).
-template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2, int MODE = 0>
+// LNF: instantiation that carries the fused-LayerNorm tail (opt-in).  Kept apart: the tail's row batches took the RESID kernels from
+// ~50 - 76 to 144 - 150 registers, i.e. from five to three workgroups per CU on the cfg-2 tiles, whether or not the tail ever ran.
+template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2, int MODE = 0, bool LNF = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArgs p) {
     constexpr bool ILV = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -746,6 +748,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
     for (int u = 0; u < NS - 1; ++u)
         if (u < ntiles) issue(u);
     TL_STAMP(3);
+    // small tiles (one or two output groups per thread): what the epilogue reads is requested right behind the first operand
+    // stages, a whole k-loop ahead of its use (the counted vmcnt waits below only ever wait for MORE than they need because of it)
+    using SE = StagedEpilogue<EPI, BM, BN, NTHR>;
+    SE se;
+    constexpr bool EARLY_EPI = SE::ITER <= 2;
+    if constexpr (EARLY_EPI) se.prefetch(p, m0, n0, tid);
     if constexpr (MODE == 2) {
         static_assert(MODE != 2 || NS >= 3, "the pipelined loop refills the buffer of stage t-1 while stage t is being consumed");
         constexpr int KS = BK / 32;
@@ -865,8 +873,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
     // staged epilogue (see gemm_body)
     constexpr int LDC = BN + 4;
     float* ct = reinterpret_cast<float*>(smem);
-    StagedEpilogue<EPI, BM, BN, NTHR> se;
-    se.prefetch(p, m0, n0, tid);
+    if constexpr (!EARLY_EPI) se.prefetch(p, m0, n0, tid);
     __syncthreads();
     TL_STAMP(4);                                                       // mainloop done
 #pragma unroll
@@ -876,7 +883,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
             *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
     __syncthreads();
     se.run(p, ct, m0, n0, tid);
-    if constexpr (EPI == EPI_RESID) {
+    if constexpr (EPI == EPI_RESID && LNF) {
         if (p.ln_tickets) {                                            // block-uniform
             __syncthreads();                                           // the staged tile in LDS has been consumed: reuse a word of it
             ln_band_tail<NW>(p, m0, BM, m0 / BM, ntx, reinterpret_cast<int*>(smem), tid);
@@ -1084,6 +1091,10 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < ntiles) issue(u);
+    using SE = StagedEpilogue<EPI, BM, BN, 256>;
+    SE se;
+    constexpr bool EARLY_EPI = EPI != EPI_ATOMIC && SE::ITER <= 2;      // see gemm_nt_dma_kernel
+    if constexpr (EARLY_EPI) se.prefetch(p, m0, n0, tid);
     for (int t = 0; t < ntiles; ++t) {
         if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1144,8 +1155,7 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
     } else {
         constexpr int LDC = BN + 4;
         float* ct = reinterpret_cast<float*>(smem);
-        StagedEpilogue<EPI, BM, BN, 256> se;
-        se.prefetch(p, m0, n0, tid);
+        if constexpr (!EARLY_EPI) se.prefetch(p, m0, n0, tid);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -1264,11 +1274,17 @@ int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (SPLIT ? 2 : 1) * (BM + BN) * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, BM * (BN + 4) * 4);
     static_assert(LDS <= 160 * 1024, "stage ring exceeds the CU's LDS");
-    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV>;
+    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, false>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if constexpr (EPI == EPI_RESID)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
+    }
+    if constexpr (EPI == EPI_RESID) {
+        if (a.ln_tickets) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, true>;
     }
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
     constexpr long long KEY = 300000000000LL + BM * 100000000LL + BN * 100000LL + (SPLIT ? 100 : 0) + EPI;
@@ -1302,10 +1318,16 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (SPLIT ? 2 : 1) * 256 * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, 128 * 132 * 4);
     static bool attr_set = false;
-    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK>;
+    auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if constexpr (EPI == EPI_RESID)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
+    }
+    if constexpr (EPI == EPI_RESID) {
+        if (a.ln_tickets) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>;
     }
     dim3 grid((a.N + 127) / 128, (a.M + 127) / 128, 1);
     constexpr long long KEY = 300000000000LL + 128 * 100000000LL + 128 * 100000LL + (SPLIT ? 100 : 0) + EPI;
