@@ -909,11 +909,16 @@ extern "C" int s3d_debug_timeline_set(void* buf) {
 // piece) and the MFMA fragments (8 consecutive k of one column) come from gfx950's LDS TRANSPOSE read: per 16-lane group,
 // lane t passes the address of row t>>2, columns 4(t&3)..+3 of a [4 k][16 columns] block and receives column t (two reads per
 // fragment, see attention.hip).  The four rows of a block are 256 bytes apart = the same banks, so 16-byte slot c of row r is
-// stored at slot c ^ ((r & 3) << 1) -- applied, as always with DMA, to the SOURCE address.  No register transposes, no
-// ds_write at all.  k must tile by 64 (zero-fill is impossible without registers); the launcher falls back otherwise.
+// stored at slot c ^ kmajor_swz(r) -- applied, as always with DMA, to the SOURCE address.  No register transposes, no
+// ds_write at all.  A partial last k-tile takes its missing rows from a block of zeros (KTAIL).
 // slot swizzle of a k-major tile row: 256-byte rows (128 columns) put all four rows of a transpose-read block on the same banks
-// -> xor (r & 3) << 1; 128-byte rows (64 columns) alias rows two apart -> xor ((r >> 1) & 1) << 1
-template <int COLS> __device__ __forceinline__ int kmajor_swz(int r) { return COLS == 128 ? ((r & 3) << 1) : (((r >> 1) & 1) << 1); }
+// -> xor (r & 3) << 1; 128-byte rows (64 columns) alias rows two apart -> xor ((r >> 1) & 1) << 1.
+// A transpose read is served 32 lanes at a time (MI355X_MICROARCH.md, LDS table): lanes 0-15 take rows kq..kq+3 and lanes 16-31 rows
+// kq+8..kq+11 of the same columns, so rows 8 apart must not share banks either (PMC round 2: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
+// 0.50 on the TN wgrads with the round-1 function, which only separated the four rows of one block) -> one more slot bit from r >> 3.
+template <int COLS> __device__ __forceinline__ int kmajor_swz(int r) {
+    return COLS == 128 ? (((r & 3) << 1) | (((r >> 3) & 1) << 3)) : ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2));
+}
 
 template <int COLS = 128>
 __device__ __forceinline__ bf16x8 frag_kmajor(const unsigned char* tile, int col16, int kq8, int lane) {
