@@ -917,7 +917,7 @@ extern "C" int s3d_debug_timeline_set(void* buf) {
 // kq+8..kq+11 of the same columns, so rows 8 apart must not share banks either (PMC round 2: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE =
 // 0.50 on the TN wgrads with the round-1 function, which only separated the four rows of one block) -> one more slot bit from r >> 3.
 template <int COLS> __device__ __forceinline__ int kmajor_swz(int r) {
-    return COLS == 128 ? (((r & 3) << 1) | (((r >> 3) & 1) << 3)) : ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2));
+    return COLS >= 128 ? (((r & 3) << 1) | (((r >> 3) & 1) << 3)) : ((((r >> 1) & 1) << 1) | (((r >> 3) & 1) << 2));   // 512-byte rows alias like 256-byte ones
 }
 
 template <int COLS = 128>
@@ -1014,16 +1014,24 @@ __device__ __forceinline__ void frags_kmajor_ab(const unsigned char* tA, int col
 }
 
 // KTAIL: instantiation that accepts a partial last k-tile (kept apart: its extra per-piece state costs the cfg-2 pair launches 1.5 %)
-template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false>
+// WM x WN waves, each on a (BM / WM) x (BN / WN) sub-tile of 64x64 or 32x32 (the per-wave code is the same for every tile size).  The
+// plain-bf16 k-loop of a 128x128 tile is bound by the rate at which the CU pulls operand bytes out of L2 (two workgroups = 64 KB per
+// k = 64 step at ~30 - 39 B/clk/CU vs 1.1 k cycles of MFMA per SIMD): 256x128 (8 waves) moves 25 % and 256x256 (16 waves) 50 % fewer
+// bytes per flop through the same pipe.
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
                                                const int bz) {
     constexpr int BK = 64;
-    static_assert(BM == BN && (BM == 128 || BM == 64), "square 128 / 64 tiles");
+    static_assert((BM == 64 || BM == 128 || BM == 256) && (BN == 64 || BN == 128 || BN == 256), "tile edges of 64 / 128 / 256");
+    constexpr int NW = WM * WN, NTHR = 64 * NW;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    static_assert(TM == TN && (TM == 64 || TM == 32), "wave sub-tiles of 64x64 or 32x32");
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    constexpr int PPW = STAGE / 1024 / 4;
-    constexpr int FM = BM / 32, FN = BN / 32;
+    static_assert((STAGE / 1024) % NW == 0, "every wave issues the same number of DMA pieces");
+    constexpr int PPW = STAGE / 1024 / NW;
+    constexpr int FM = TM / 16, FN = TN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     {
         const int ntile = ntx * nty;
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
@@ -1048,9 +1056,9 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
         const long ld = isB ? p.ldb : p.lda;
         const int R = isB ? p.N : p.M, r0 = isB ? n0 : m0;
         if (kmajor) {                                                  // piece = 1 KB of k rows: 4 rows x 16 slots (8 x 8 at 64 columns)
-            constexpr int SPR = BM / 8;                                // 16-byte slots per row
+            const int SPR = (isB ? BN : BM) / 8;                       // 16-byte slots per row
             const int r = q * (64 / SPR) + lane / SPR, c = lane % SPR;
-            const int cg = c ^ kmajor_swz<BM>(r);
+            const int cg = c ^ (isB ? kmajor_swz<BN>(r) : kmajor_swz<BM>(r));
             gp[j] = base + (long)(kbeg + r) * ld + min(r0 + cg * 8, R - 8);
             gstep[j] = 64 * ld;
             if constexpr (KTAIL) gk[j] = r;                            // one k row
@@ -1096,7 +1104,7 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < ntiles) issue(u);
-    using SE = StagedEpilogue<EPI, BM, BN, 256>;
+    using SE = StagedEpilogue<EPI, BM, BN, NTHR>;
     SE se;
     constexpr bool EARLY_EPI = EPI != EPI_ATOMIC && SE::ITER <= 2;      // see gemm_nt_dma_kernel
     if constexpr (EARLY_EPI) se.prefetch(p, m0, n0, tid);
@@ -1111,17 +1119,17 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a_hi[FM], b_hi[FN];
             const int kq8 = ks * 32 + (lane >> 4) * 8;
-            if constexpr (TA && TB) {
-                frags_kmajor_ab<BM, FM>(sA, wm * (BM / 2), sB, wn * (BN / 2), kq8, lane, a_hi, b_hi);
+            if constexpr (TA && TB && BM == BN) {
+                frags_kmajor_ab<BM, FM>(sA, wm * TM, sB, wn * TN, kq8, lane, a_hi, b_hi);
             } else {
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    if constexpr (!TA) a_hi[i] = read_frag_dma(sA, wm * (BM / 2) + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                    if constexpr (!TA) a_hi[i] = read_frag_dma(sA, wm * TM + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    if constexpr (!TB) b_hi[j] = read_frag_dma(sB, wn * (BN / 2) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
-                if constexpr (TA) frags_kmajor<BM, FM>(sA, wm * (BM / 2), kq8, lane, a_hi);
-                if constexpr (TB) frags_kmajor<BN, FN>(sB, wn * (BN / 2), kq8, lane, b_hi);
+                    if constexpr (!TB) b_hi[j] = read_frag_dma(sB, wn * TN + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+                if constexpr (TA) frags_kmajor<BM, FM>(sA, wm * TM, kq8, lane, a_hi);
+                if constexpr (TB) frags_kmajor<BN, FN>(sB, wn * TN, kq8, lane, b_hi);
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -1141,10 +1149,10 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+                const int n = n0 + wn * TN + j * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    const int m = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
                     if (m < p.M && n < p.N) atomic_add_f32(&p.C[(long)m * p.ldc + n], acc[i][j][r] * p.alpha);
                 }
             }
@@ -1153,7 +1161,7 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                    const int m = m0 + wm * TM + i * 16 + (lane >> 4) * 4 + r;
                     if (m < p.M) atomic_add_f32(&p.bias_grad[m], bacc[i][r] * p.alpha);
                 }
         }
@@ -1166,16 +1174,16 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                *reinterpret_cast<f32x4*>(ct + (wm * (BM / 2) + i * 16 + (lane & 15)) * LDC + wn * (BN / 2) + j * 16 + (lane >> 4) * 4) = acc[i][j];
+                *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
         __syncthreads();
         se.run(p, ct, m0, n0, tid);
     }
 }
 
-template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false>
-__global__ __launch_bounds__(256) void gemm_dmat_kernel(const GemmArgs p) {
+template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_dmat_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemm_dmat_body<TA, TB, EPI, NS, BM, BN, KTAIL>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+    gemm_dmat_body<TA, TB, EPI, NS, BM, BN, KTAIL, WM, WN>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
 }
 
 // dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
@@ -1353,21 +1361,23 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
-template <bool TA, bool TB, int EPI, int BT = 128, bool KTAIL = false>
+template <bool TA, bool TB, int EPI, int BT = 128, bool KTAIL = false, int BTN = BT>
 int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
     if constexpr (!KTAIL) {
-        if ((a.K & 63) != 0) return launch_dmat<TA, TB, EPI, BT, true>(a, splitk, stream);      // partial last k-tile
+        if ((a.K & 63) != 0) return launch_dmat<TA, TB, EPI, BT, true, BTN>(a, splitk, stream);      // partial last k-tile
     }
-    constexpr int NS = BT == 128 ? 2 : 3, STAGE = 2 * BT * 64 * 2;
-    constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : BT * (BT + 4) * 4);
+    constexpr int WM = BT >= 128 ? BT / 64 : 2, WN = BTN >= 128 ? BTN / 64 : 2;          // 64x64 wave sub-tiles (32x32 on the 64x64 tile)
+    constexpr int NS = (BT == 64 || (BT == 256 && BTN == 128)) ? 3 : 2, STAGE = (BT + BTN) * 64 * 2;   // 256x128: three 48 KB stages = one fat workgroup per CU
+    constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : BT * (BTN + 4) * 4);
+    static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
     static bool attr_set = false;
-    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS, BT, BT, KTAIL>;
+    auto kern = gemm_dmat_kernel<TA, TB, EPI, NS, BT, BTN, KTAIL, WM, WN>;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    dim3 grid((a.N + BT - 1) / BT, (a.M + BT - 1) / BT, splitk);
-    constexpr long long KEY = 400000000000LL + BT * 100000000LL + BT * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + EPI;
+    dim3 grid((a.N + BTN - 1) / BTN, (a.M + BT - 1) / BT, splitk);
+    constexpr long long KEY = 400000000000LL + BT * 100000000LL + BTN * 100000LL + (TA ? 10000 : 0) + (TB ? 1000 : 0) + EPI;
     if (g_skip_key == KEY) return 0;
     if (g_prof_on) {
         ProfSlot sl;
@@ -1375,11 +1385,11 @@ int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
         sl.flops = 2.0 * a.M * a.N * a.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
         (void)hipEventRecord(sl.e1, stream);
         g_prof.push_back(sl);
     } else {
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
     }
     S3D_CHECK_LAUNCH("gemm_dmat");
     return 0;
@@ -1617,6 +1627,23 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
         S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");
         int kchunk = 0;
+        {
+            // Long reductions onto a weight matrix with <= 1024 output rows (cfg-3: proj, fc2): 256x128 tiles, eight waves, three
+            // 48 KB stages -- one fat workgroup per CU moves 25 % fewer operand bytes per flop.  Measured at k = 188 160 rows:
+            // fc2 1302 -> 1082 us, proj 356 -> 322 us; the wide-output wgrads (qkv, fc1) lose 2 - 3 % and stay on 128x128.
+            static const int fat = env_int("S3D_WGRAD_FAT");            // -1 (unset): as above; 0: never; 1: every long wgrad
+            static const int dmat_on = env_int("S3D_GEMM_DMAT"), forced_sk = env_int("S3D_GEMM_SPLITK");
+            const bool shape_ok = a.K >= 16384 && a.M >= 256 && a.N >= 256 && (a.K & 7) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0;
+            if (fat != 0 && dmat_on != 0 && splitk <= 0 && forced_sk <= 0 && !s3d_deterministic() && shape_ok && (fat == 1 || a.M <= 1024)) {
+                const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
+                int sk = (int)((512 + tiles / 2) / tiles);               // about two workgroups per CU over the launch
+                sk = sk < 1 ? 1 : sk;
+                if (sk > a.K / 2048) sk = a.K / 2048;
+                a.kchunk = ((a.K + sk - 1) / sk + 63) / 64 * 64;
+                sk = (a.K + a.kchunk - 1) / a.kchunk;
+                return launch_dmat<true, true, EPI_ATOMIC, 256, false, 128>(a, sk, stream);
+            }
+        }
         wgrad_split(a, splitk, kchunk);
         a.kchunk = kchunk;
         const int tile = s3d_gemm_pick_tile(a.M, a.N, splitk, false);
@@ -1644,6 +1671,17 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
                 case EPI_F32: return launch_dmat<false, true, EPI_F32, 64>(a, 1, stream);
                 case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 64>(a, 1, stream);
                 case EPI_BF16_BIAS: return launch_dmat<false, true, EPI_BF16_BIAS, 64>(a, 1, stream);
+                default: break;
+            }
+        }
+        // long dgrads with a short reduction (k = output width <= 1024: cfg-3 proj, fc2): 256x128 tiles as for the wgrads above
+        // (fc2 1479 -> 1327 us, proj 372 -> 358 us at 188 160 rows; neutral for k = 2304 / 3072)
+        static const int dfat = env_int("S3D_DGRAD_FAT");               // -1 (unset): as above; 0: never; 1: every long dgrad
+        if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= 16384 && a.N >= 256 && (dfat == 1 || (a.K >= 512 && a.K <= 1024))) {
+            switch (epi) {
+                case EPI_F32: return launch_dmat<false, true, EPI_F32, 256, false, 128>(a, 1, stream);
+                case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 256, false, 128>(a, 1, stream);
+                case EPI_BF16_BIAS: return launch_dmat<false, true, EPI_BF16_BIAS, 256, false, 128>(a, 1, stream);
                 default: break;
             }
         }
