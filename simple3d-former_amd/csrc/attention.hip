@@ -968,6 +968,10 @@ template <int HD, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
+    // hd = 192 / 256 (cfg-3's 15-token groups, 37 632 of them per block): the row fragments alone are 192 - 256 registers, so the
+    // gradients are accumulated two d-blocks at a time; three waves (49 KB of tiles each) share a CU
+    constexpr int NDBC = NDB <= 3 ? NDB : 2;
+    static_assert(NDB % NDBC == 0, "d-blocks split evenly");
     constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;                    // K | Q | dO tiles (bf16) + delta / lse (fp32)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -1045,35 +1049,38 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
                     dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
                 dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
             }
-        f32x16 dq[NDB];
+        const long orow = tokrow * p.lddq + h * HD;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d)
+        for (int d0 = 0; d0 < NDB; d0 += NDBC) {                       // NDBC d-blocks of dQ at a time (all of them for hd <= 96)
+            f32x16 dq[NDBC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+            for (int d = 0; d < NDBC; ++d)
 #pragma unroll
-        for (int d = 0; d < NDB; d += 2) {
-            bf16x8 k0f[2], k1f[2];
-            if (d + 1 < NDB) gather_frag_2x2<HD>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0f, k1f);
-            else gather_frag_s2<HD>(ldsK, h2, d * 32 + l31, k0f);
+                for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dq[d] = MFMA32(k0f[s2], dsf[s2].v, dq[d]);
-                if (d + 1 < NDB) dq[d + 1] = MFMA32(k1f[s2], dsf[s2].v, dq[d + 1]);
-            }
-        }
-        if (active && tok_ok) {
-            const long orow = tokrow * p.lddq + h * HD;
+            for (int d = 0; d < NDBC; d += 2) {
+                bf16x8 k0f[2], k1f[2];
+                if (d + 1 < NDBC) gather_frag_2x2<HD>(ldsK, (d0 + d) * 32 + l31, ldsK, (d0 + d + 1) * 32 + l31, h2, k0f, k1f);
+                else gather_frag_s2<HD>(ldsK, h2, (d0 + d) * 32 + l31, k0f);
 #pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    union { uint2 u; bf16_t h[4]; } v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
-                    const int dcol = d * 32 + 8 * c + 4 * h2;
-                    if (HD % 32 != 0 && dcol >= HD) continue;
-                    *reinterpret_cast<uint2*>(p.dqkv + orow + dcol) = v.u;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dq[d] = MFMA32(k0f[s2], dsf[s2].v, dq[d]);
+                    if (d + 1 < NDBC) dq[d + 1] = MFMA32(k1f[s2], dsf[s2].v, dq[d + 1]);
                 }
+            }
+            if (active && tok_ok) {
+#pragma unroll
+                for (int d = 0; d < NDBC; ++d)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        union { uint2 u; bf16_t h[4]; } v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v.h[i] = f2bf(dq[d][4 * c + i]);
+                        const int dcol = (d0 + d) * 32 + 8 * c + 4 * h2;
+                        if (HD % 32 != 0 && dcol >= HD) continue;
+                        *reinterpret_cast<uint2*>(p.dqkv + orow + dcol) = v.u;
+                    }
+            }
         }
     }
     // ---- phase B: lane = key.  S = Q . K^T, dP = dO . V^T, dV^T = dO^T . P, dK^T = Q^T . dS
@@ -1100,34 +1107,37 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
                 pf[s2].h[j] = f2bf(pr * dm);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[qc]) * p.scale);
             }
-        f32x16 dk[NDB], dv[NDB];
+        const long orow = tokrow * p.lddq + h * HD;
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) {
+        for (int d0 = 0; d0 < NDB; d0 += NDBC) {
+            f32x16 dk[NDBC], dv[NDBC];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
-            bf16x8 fo[2], fq[2];
-            gather_frag_2x2<HD>(ldsDO, d * 32 + l31, ldsQ, d * 32 + l31, h2, fo, fq);
+            for (int d = 0; d < NDBC; ++d) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);
-                dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);
-            }
-        }
-        if (active && tok_ok) {
-            const long orow = tokrow * p.lddq + h * HD;
+                for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+                bf16x8 fo[2], fq[2];
+                gather_frag_2x2<HD>(ldsDO, (d0 + d) * 32 + l31, ldsQ, (d0 + d) * 32 + l31, h2, fo, fq);
 #pragma unroll
-            for (int d = 0; d < NDB; ++d)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    union { uint2 u; bf16_t h[4]; } a, v;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
-                    const int dcol = d * 32 + 8 * c + 4 * h2;
-                    if (HD % 32 != 0 && dcol >= HD) continue;
-                    const long off = orow + dcol;
-                    *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
-                    *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);
+                    dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);
                 }
+            }
+            if (active && tok_ok) {
+#pragma unroll
+                for (int d = 0; d < NDBC; ++d)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        union { uint2 u; bf16_t h[4]; } a, v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { a.h[i] = f2bf(dk[d][4 * c + i]); v.h[i] = f2bf(dv[d][4 * c + i]); }
+                        const int dcol = (d0 + d) * 32 + 8 * c + 4 * h2;
+                        if (HD % 32 != 0 && dcol >= HD) continue;
+                        const long off = orow + dcol;
+                        *reinterpret_cast<uint2*>(p.dqkv + off + p.D) = a.u;
+                        *reinterpret_cast<uint2*>(p.dqkv + off + 2 * p.D) = v.u;
+                    }
+            }
         }
     }
 }
@@ -1234,14 +1244,18 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
-    if constexpr (HD <= 96) {
+    {
         static const bool no_small = getenv("S3D_ATTN_NO_SMALL") != nullptr;
-        if (a.N <= 32 && !no_small) {
-            const int lds = wpb * (3 * 32 * HD * 2 + 256);
-            set_lds(attn_bwd_small_kernel<HD>, 4 * (3 * 32 * HD * 2 + 256));
-            set_lds(attn_bwd_small_kernel<HD, true>, 4 * (3 * 32 * HD * 2 + 256));
-            if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
-            else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
+        static const bool no_small_big = getenv("S3D_ATTN_NO_SMALL_BIG") != nullptr;       // hd > 96: back to the two-kernel path
+        if (a.N <= 32 && !no_small && (HD <= 96 || !no_small_big)) {
+            constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;
+            constexpr int MAXW = (160 * 1024) / WAVE_LDS >= 4 ? 4 : (160 * 1024) / WAVE_LDS;      // 3 waves per workgroup at hd = 256
+            const int w = wpb < MAXW ? wpb : MAXW;
+            dim3 gs((unsigned)((W + w - 1) / w));
+            set_lds(attn_bwd_small_kernel<HD>, MAXW * WAVE_LDS);
+            set_lds(attn_bwd_small_kernel<HD, true>, MAXW * WAVE_LDS);
+            if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
+            else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
             S3D_CHECK_LAUNCH("attention_bwd_small");
             return 0;
         }
