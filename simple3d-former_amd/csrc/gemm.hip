@@ -168,6 +168,11 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int r, int
 // function on the SOURCE side (it writes lane-linear).
 __device__ __forceinline__ int dma_swz64(int r) { return ((r >> 1) & 7) ^ (((r >> 2) ^ (r >> 3)) & 1); }
 __device__ __forceinline__ int dma_swz32(int r) { return ((r >> 2) & 3) ^ (((r >> 2) ^ (r >> 3)) & 1); }
+// 32x32x16 fragments: lanes 0-31 read rows 0-31 at one k-chunk (lanes 32-63 the next chunk), so a 16-lane group holds rows
+// {0-3, 12-15, 20-27} or {4-11, 16-19, 28-31} of ONE chunk: rows that share banks (r, r + 4, .. at 64-byte rows; r, r + 2, .. at 128)
+// need distinct slots within each of those two row sets -> (r >> 3) & 3 resp. (r >> 1) & 7 (checked by enumeration).
+__device__ __forceinline__ int dma_swz64_m32(int r) { return (r >> 1) & 7; }
+__device__ __forceinline__ int dma_swz32_m32(int r) { return (r >> 3) & 3; }
 __device__ __forceinline__ bf16x8 read_frag_dma(const unsigned char* lds, int r, int kc) {      // 128-byte rows
     return *reinterpret_cast<const bf16x8*>(lds + r * 128 + ((kc ^ dma_swz64(r)) << 4));
 }
@@ -681,9 +686,14 @@ constexpr int TL_SLOTS = 40;
 // stage boundary too: [stage t+1 landed: counted vmcnt + barrier] -> refill the ring -> read fragments(t+1) -> MFMAs(t).
 // LNF: instantiation that carries the fused-LayerNorm tail (opt-in).  Kept apart: the tail's row batches took the RESID kernels from
 // ~50 - 76 to 144 - 150 registers, i.e. from five to three workgroups per CU on the cfg-2 tiles, whether or not the tail ever ran.
-template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2, int MODE = 0, bool LNF = false>
+// M32: the wave's sub-tile is built from 32x32x16 MFMAs instead of 16x16x32 ones (sub-tiles of 32 / 64 rows and columns; plain loop
+// only).  The 32x32 instruction issues at its full rate (~8 cycles per CU for twice the flops of a 16x16x32 at ~5, MI355X_MICROARCH.md),
+// and a fragment row is then lane & 31 with the k-chunk in lane >> 5, which needs its own slot swizzle (dma_swz*_m32).
+template <bool SPLIT, int EPI, int NS, int BK, int BM = 128, int BN = 128, int WM = 2, int WN = 2, int MODE = 0, bool LNF = false,
+          bool M32 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArgs p) {
     constexpr bool ILV = MODE == 1;
+    static_assert(!M32 || MODE == 0, "32x32 MFMAs: plain loop only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NPL = SPLIT ? 2 : 1;
     static_assert((NPL * (BM + BN) * BK * 2) % 4096 == 0, "a stage must split into whole 1 KB pieces per wave");
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
     const int ntiles = p.K / BK;                                       // K % BK == 0 (checked by the launcher)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     // 16-byte slot swizzle: 128-byte rows as in gemm_body; 64-byte rows (16 banks) repeat every 4 rows -> xor with (r >> 2) & 3
-    auto swz = [](int r) { return BK == 64 ? dma_swz64(r) : dma_swz32(r); };
+    auto swz = [](int r) { return M32 ? (BK == 64 ? dma_swz64_m32(r) : dma_swz32_m32(r)) : (BK == 64 ? dma_swz64(r) : dma_swz32(r)); };
     auto frag = [&](const unsigned char* lds, int r, int kc) {
         return *reinterpret_cast<const bf16x8*>(lds + r * ROWB + ((kc ^ swz(r)) << 4));
     };
@@ -737,11 +747,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         for (int j = 0; j < PPW; ++j) glds16(gp[j] + (long)t * BK, dst + j * 1024);
     };
 
-    f32x4 acc[FM][FN];
+    f32x4 acc[M32 ? 1 : FM][M32 ? 1 : FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < (M32 ? 1 : FM); ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < (M32 ? 1 : FN); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int GM = M32 ? TM / 32 : 1, GN = M32 ? TN / 32 : 1;      // 32x32 blocks of the wave's sub-tile (M32)
+    static_assert(!M32 || (TM % 32 == 0 && TN % 32 == 0), "32x32 MFMAs need sub-tiles of 32 / 64");
+    f32x16 acc32[GM][GN];
+#pragma unroll
+    for (int i = 0; i < GM; ++i)
+#pragma unroll
+        for (int j = 0; j < GN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
 
     TL_REAL(0); TL_HWID(1); TL_STAMP(2);
 #pragma unroll
@@ -835,6 +854,35 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         constexpr int GROUPS = (BK / 32) * FM * FN;                    // MFMA groups (one output block each) per k-tile
         const unsigned char* sA = smem + (t % NS) * STAGE;
         const unsigned char* sB = sA + NPL * A_BYTES;
+        if constexpr (M32) {
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int kc = ks * 2 + (lane >> 5);
+                bf16x8 a_hi[GM], b_hi[GN], a_lo[SPLIT ? GM : 1], b_lo[SPLIT ? GN : 1];
+#pragma unroll
+                for (int i = 0; i < GM; ++i) {
+                    const int r = wm * TM + i * 32 + (lane & 31);
+                    a_hi[i] = frag(sA, r, kc);
+                    if constexpr (SPLIT) a_lo[i] = frag(sA + A_BYTES, r, kc);
+                }
+#pragma unroll
+                for (int j = 0; j < GN; ++j) {
+                    const int r = wn * TN + j * 32 + (lane & 31);
+                    b_hi[j] = frag(sB, r, kc);
+                    if constexpr (SPLIT) b_lo[j] = frag(sB + B_BYTES, r, kc);
+                }
+#pragma unroll
+                for (int i = 0; i < GM; ++i)
+#pragma unroll
+                    for (int j = 0; j < GN; ++j) {
+                        if constexpr (SPLIT) {
+                            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi[j], a_lo[i], acc32[i][j], 0, 0, 0);
+                            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_lo[j], a_hi[i], acc32[i][j], 0, 0, 0);
+                        }
+                        acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi[j], a_hi[i], acc32[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int kc = ks * 4 + (lane >> 4);
@@ -869,6 +917,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
                     }
                 }
         }
+        }
     }
     // staged epilogue (see gemm_body)
     constexpr int LDC = BN + 4;
@@ -876,11 +925,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
     if constexpr (!EARLY_EPI) se.prefetch(p, m0, n0, tid);
     __syncthreads();
     TL_STAMP(4);                                                       // mainloop done
+    if constexpr (M32) {
+        // D[n][m] of a 32x32 block: this lane holds output row m = lane & 31 and, per group g of four registers, columns
+        // n = 8 g + 4 (lane >> 5) .. + 3
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < GM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j)
-            *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
+            for (int j = 0; j < GN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 32 + (lane & 31)) * LDC + wn * TN + j * 32 + 8 * g + 4 * (lane >> 5)) =
+                        f32x4{acc32[i][j][4 * g], acc32[i][j][4 * g + 1], acc32[i][j][4 * g + 2], acc32[i][j][4 * g + 3]};
+    } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                *reinterpret_cast<f32x4*>(ct + (wm * TM + i * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[i][j];
+    }
     __syncthreads();
     se.run(p, ct, m0, n0, tid);
     if constexpr (EPI == EPI_RESID && LNF) {
@@ -1332,13 +1394,17 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = cmax(NS * STAGE, 128 * 132 * 4);
     static bool attr_set = false;
     auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false>;
+    static const int m32 = env_int("S3D_GEMM_M32");                   // 1: 32x32x16 MFMAs in the 128x128 forward kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if constexpr (EPI == EPI_RESID)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
+    if (m32 == 1) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false, true>;
     if constexpr (EPI == EPI_RESID) {
         if (a.ln_tickets) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>;
     }
