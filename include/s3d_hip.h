@@ -65,12 +65,19 @@ typedef struct S3dGemmArgs {
     const float* ln_gamma; const float* ln_beta; float ln_eps;
     uint16_t* ln_hi; uint16_t* ln_lo; long ld_ln;
     float* ln_mean; float* ln_rstd;
+    /* optional (forward NT GEMM, epilogue F32, N % 8 == 0): col_sums[0 .. N) += column sums of the output, col_sums[N .. 2N) += column
+     * sums of its squares over the M rows (fp64 atomics; the caller zeroes it).  They are the batch statistics of the train-mode
+     * BatchNorm that follows a point-path convolution (S3dBnArgs::have_sums), so that tensor is not read a second time to get them. */
+    double* col_sums;
 } S3dGemmArgs;
 /* ta / tb: operand stored k-major.  (0,0) forward "x @ W^T"; (0,1) dgrad "dy @ W"; (1,1) wgrad "dy^T @ x" (split-K,
  * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
 /* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
+/* 1 if a forward (0,0) F32-epilogue launch of this shape accumulates S3dGemmArgs::col_sums (128x128 tiles, N % 8 == 0); the caller
+ * otherwise leaves col_sums NULL and lets s3d_batchnorm_fwd compute its own statistics. */
+int s3d_gemm_col_sums_ok(int split, int M, int N);
 
 /* Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
  * launch stream.  s3d_prof_collect synchronises those events and fills rows of 4 doubles

@@ -378,6 +378,11 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int split
     S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");
     return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));
 }
+int s3d_gemm_col_sums_ok(int split, int M, int N) {
+    static const bool forced = getenv("S3D_GEMM_NT_TILE") != nullptr && atoi(getenv("S3D_GEMM_NT_TILE")) >= 0;
+    static const bool off = getenv("S3D_GEMM_COL_SUMS") != nullptr && atoi(getenv("S3D_GEMM_COL_SUMS")) == 0;
+    return (!forced && !off && M > 0 && N > 0 && (N & 7) == 0 && s3d_gemm_pick_tile(M, N, 1, split != 0) == 2) ? 1 : 0;
+}
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* a) { return (a != nullptr && s3d_gemm_ln_fusable(split != 0, *a)) ? 1 : 0; }
 int s3d_layernorm_fwd(const S3dLnArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_layernorm_fwd: null args");

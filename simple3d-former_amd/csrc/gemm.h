@@ -22,6 +22,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a, in
 
 // forward NT RESID launch that would run the fused LayerNorm epilogue (GemmArgs::ln_tickets), see gemm.hip
 bool s3d_gemm_ln_fusable(bool split, const GemmArgs& a);
+int s3d_gemm_pick_tile(int M, int N, int splitk, bool split);
 
 // dgrad (k-major B, epilogue epi_a) and the wgrad that consumes the same dy, fused into one launch (see gemm.hip)
 int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad, hipStream_t stream);

@@ -325,7 +325,10 @@ struct StagedEpilogue {
             epi_prefetch<EPI, 8>(p, c < TOT ? m0 + row : p.M, n0 + col, q[it], !ONE_COL || it == 0);
         }
     }
-    __device__ __forceinline__ void run(const GemmArgs& p, const float* ct, const int m0, const int n0, const int tid) {
+    __device__ __forceinline__ void run(const GemmArgs& p, float* ct, const int m0, const int n0, const int tid) {
+        float cs[8], cq[8];                                             // column sums / sums of squares of this thread's rows (col_sums)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cs[r] = cq[r] = 0.f;
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
             const int c = tid + it * NTHR;
@@ -334,6 +337,35 @@ struct StagedEpilogue {
             float v[8];
             ld_f32<8>(v, ct + row * LDC + col);
             epilogue_core<EPI, 8>(p, m0 + row, n0 + col, v, ONE_COL ? q[0].bq : q[it].bq, q[it].rr, q[it].ax);
+            if constexpr (EPI == EPI_F32 && ONE_COL) {
+                if (p.col_sums && m0 + row < p.M) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float o = v[r] * p.alpha + q[0].bq[r];   // the value epilogue_core stored
+                        cs[r] += o; cq[r] += o * o;
+                    }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_F32 && ONE_COL) {
+            if (p.col_sums) {                                           // block-uniform
+                // NTHR / CPR threads hold partials of the same 8 columns: fold them through the (consumed) staging tile, then one
+                // fp64 atomic per column and statistic per workgroup
+                constexpr int RG = NTHR / CPR;
+                __syncthreads();
+                float* red = ct;                                        // [2][RG][BN]
+                const int col = (tid % CPR) * 8, rg = tid / CPR;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { red[rg * BN + col + r] = cs[r]; red[(RG + rg) * BN + col + r] = cq[r]; }
+                __syncthreads();
+                for (int i = tid; i < 2 * BN; i += NTHR) {
+                    const int which = i / BN, cc = i % BN;
+                    float s = 0.f;
+#pragma unroll 4
+                    for (int g = 0; g < RG; ++g) s += red[(which * RG + g) * BN + cc];
+                    if (n0 + cc < p.N) unsafeAtomicAdd(p.col_sums + (long)which * p.N + n0 + cc, (double)s);
+                }
+            }
         }
     }
 };
@@ -1689,6 +1721,9 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     if (ta) S3D_REQUIRE((a.M % 8) == 0, "gemm: M=%d must be a multiple of 8 for a k-major A", a.M);
     if (tb) S3D_REQUIRE((a.N % 8) == 0, "gemm: N=%d must be a multiple of 8 for a k-major B", a.N);
     if (split) S3D_REQUIRE(a.A_lo && a.B_lo, "gemm: split mode needs lo planes");
+    if (a.col_sums)
+        S3D_REQUIRE(!ta && !tb && epi == EPI_F32 && s3d_gemm_col_sums_ok(split ? 1 : 0, a.M, a.N),
+                    "gemm: col_sums needs the forward F32 epilogue on 128x128 tiles (M=%d N=%d; ask s3d_gemm_col_sums_ok)", a.M, a.N);
 
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
         S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");

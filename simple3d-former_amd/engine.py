@@ -175,7 +175,16 @@ LN_FUSE = os.environ.get('S3D_LN_FUSE', '0') == '1'
 # backward run on those rows alone (S3dBlockShape::cls_only_block).  S3D_CLS_ONLY=0: dense, as the reference computes it.
 CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
-LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '208'))    # 0: LayerNorm backward uses atomics
+LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
+
+
+def ln_partial_blocks(rows):
+    """Workgroups (= rows of column-sum partials) of a LayerNorm backward over `rows` rows: 208 at cfg-2's 1664 rows (two rows per
+    wave); 416 for the 16 k - 190 k-row passes of the point path / cfg-3, where 208 four-wave workgroups leave every SIMD with one
+    wave and the narrow (D = 192) rows with too few bytes in flight (cfg-4: 16.54 -> 16.32 ms; cfg-3 / cfg-5 unchanged)."""
+    if LN_PARTIAL_BLOCKS >= 0:
+        return LN_PARTIAL_BLOCKS
+    return 208 if rows <= 8192 else 416
 
 
 class _BlockScratch:
@@ -198,10 +207,11 @@ class _BlockScratch:
         L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
                dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
         self.M, self.D = M, D
-        if depth > 0 and LN_PARTIAL_BLOCKS > 0:
+        nblk = ln_partial_blocks(M)
+        if depth > 0 and nblk > 0:
             # column-sum partials of the 2*depth LayerNorms of one s3d_blocks_bwd call (S3dBlockScratch::ln_partial)
-            self.ln_partial = torch.empty(2 * depth, LN_PARTIAL_BLOCKS, 2, D, **f32)
-            L.fill(self.c, ln_partial=self.ln_partial, ln_partial_blocks=LN_PARTIAL_BLOCKS)
+            self.ln_partial = torch.empty(2 * depth, nblk, 2, D, **f32)
+            L.fill(self.c, ln_partial=self.ln_partial, ln_partial_blocks=nblk)
 
 
 def _cls_scratch(base, rows, D, device):

@@ -452,6 +452,18 @@ class PointEngine:
         return ws
 
     # ------------------------------------------------------------------ small helpers
+    def _conv_bn(self, conv, bn, planes, rows, x, ch, **bn_kw):
+        """1x1 convolution (GEMM, fp32 output x) + train-mode BatchNorm.  Where the GEMM runs on the 128x128 staged-epilogue kernels
+        its epilogue also accumulates the column sums / sums of squares of x (S3dGemmArgs::col_sums), so the BatchNorm skips its
+        own statistics pass over x (0.5 - 0.8 GB per level-0 tensor)."""
+        fused = self.training and conv.opad == ch and bool(self.lib.s3d_gemm_col_sums_ok(1 if self.split else 0, int(rows), int(conv.opad)))
+        if fused:
+            bn.sums.zero_()
+            conv.fwd(planes[0], planes[1], rows, 4, C=x, ldc=ch, col_sums=bn.sums)
+        else:
+            conv.fwd(planes[0], planes[1], rows, 4, C=x, ldc=ch)
+        bn.fwd(x, rows, have_sums=1 if fused else 0, **bn_kw)
+
     def _pack(self, x, C, ldx, rows, planes, lo=True):
         L.check(self.lib.s3d_pack_rows(L.ptr(x), C, ldx, ctypes.c_long(rows), L.ptr(planes[0]), L.ptr(planes[1]) if lo else None,
                                        planes.shape[-1], L.current_stream()), 'pack_rows')
@@ -575,8 +587,7 @@ class PointEngine:
             L.check(lib.s3d_group_project_fwd(ctypes.byref(gp.args(t, xyz_in, B, Pf=t.Pf, x=t.x1, ldx=ch,
                                                                    sums=lay['b0'].sums if fused else None)), s), 'group_project_fwd')
             lay['b0'].fwd(t.x1, t.R, y_hi=t.y1[0], y_lo=t.y1[1], ldo=ch, have_sums=1 if fused else 0)
-            lay['c1'].fwd(t.y1[0], t.y1[1], t.R, 4, C=t.x2, ldc=ch)
-            lay['b1'].fwd(t.x2, t.R, K=KNN, y=t.out, arg=t.arg)
+            self._conv_bn(lay['c1'], lay['b1'], t.y1, t.R, t.x2, ch, K=KNN, y=t.out, arg=t.arg)
             feats, cin_feats = t.out, ch
         # tokens -> blocks -> norm -> drop cls
         S1 = ws.S1
@@ -599,11 +610,9 @@ class PointEngine:
         for j in range(nl):
             u, lay = ws.tu[j], self.tu[j]
             ch = u.ch
-            lay['l1'].fwd(coarse_planes[0], coarse_planes[1], B * u.Sc, 4, C=u.u1, ldc=ch)
-            lay['b1'].fwd(u.u1, B * u.Sc, y=u.f1, ldo=ch)
+            self._conv_bn(lay['l1'], lay['b1'], coarse_planes, B * u.Sc, u.u1, ch, y=u.f1, ldo=ch)
             self._pack(fine_feats[j], ch, ch, B * u.Sf, u.inp2)
-            lay['l2'].fwd(u.inp2[0], u.inp2[1], B * u.Sf, 4, C=u.u2, ldc=ch)
-            lay['b2'].fwd(u.u2, B * u.Sf, y=u.f2, ldo=ch)
+            self._conv_bn(lay['l2'], lay['b2'], u.inp2, B * u.Sf, u.u2, ch, y=u.f2, ldo=ch)
             L.check(lib.s3d_interp3(L.ptr(u.f1), u.Sc, L.ptr(u.f2), L.ptr(u.idx), L.ptr(u.w), B, u.Sf, ch, L.ptr(u.out), s), 'interp3')
             if j + 1 < nl:
                 self._pack(u.out, ch, ch, B * u.Sf, ws.tu[j + 1].inp1)
