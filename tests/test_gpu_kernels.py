@@ -69,7 +69,8 @@ def test_gemm_catches_transposes():
 
 
 @pytest.mark.parametrize('M,N,K', [(78, 192, 576), (1664, 1536, 384), (1664, 384, 1152), (4096, 768, 3072),
-                                   (70000, 96, 96), (66000, 192, 192), (33001, 48, 96), (131072, 56, 96)])      # point path: k = 96 stays register-staged
+                                   (70000, 96, 96), (66000, 192, 192), (33001, 48, 96), (131072, 56, 96),       # point path: k = 96 stays register-staged
+                                   (20000, 768, 768), (16500, 3072, 768)])                                    # long + short reduction: 256x128 tiles, 8 waves
 def test_gemm_dgrad_nn(M, N, K):
     """dx[m][i] = sum_o dy[m][o] W[o][i]: W is stored [K=o][N=i] (k-major B operand)."""
     g = torch.Generator().manual_seed(2)
@@ -85,7 +86,8 @@ def test_gemm_dgrad_nn(M, N, K):
 
 
 @pytest.mark.parametrize('rows,O,I', [(30, 64, 192), (78, 576, 192), (1664, 1536, 384), (1664, 384, 1536), (1664, 384, 216),
-                                      (70016, 96, 96), (131072, 96, 48), (188160, 768, 768), (33000, 192, 96)])   # long reductions
+                                      (70016, 96, 96), (131072, 96, 48), (188160, 768, 768), (33000, 192, 96),    # long reductions
+                                      (20032, 768, 3072), (16488, 512, 256)])                                     # 256x128 tiles (output rows <= 1024), partial last k-tile
 def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     """dW[o][i] += sum_m dy[m][o] x[m][i]; db[o] += sum_m dy[m][o] (split-K fp32 atomics)."""
     g = torch.Generator().manual_seed(3)
@@ -101,6 +103,27 @@ def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     # accumulation semantics: a second call adds
     ops.gemm(1, 1, 0, 'ATOMIC', splitk=0, A_hi=dyh, lda=O, B_hi=xh, ldb=I, M=O, N=I, K=rows, C=dW, ldc=I, bias_grad=db)
     assert rel_err(dW, 2 * (dyh.double().t() @ xh.double())) < 2e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40)])   # k = 40: register-staged kernel
+def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
+    """S3dGemmArgs::col_sums: the F32 epilogue of a point-path convolution also accumulates sum(y) and sum(y^2) per output channel
+    (fp64 atomics), i.e. the batch statistics of the BatchNorm that follows; the GEMM output itself is unchanged."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    xh, xl = ops.split_bf16(x); wh, wl = ops.split_bf16(w)
+    assert L.lib().s3d_gemm_col_sums_ok(1, M, N) == 1
+    y0 = torch.empty(M, N, device=DEV); y1 = torch.empty(M, N, device=DEV)
+    sums = torch.zeros(2 * N, dtype=torch.float64, device=DEV)
+    ops.gemm(0, 0, 1, 'F32', A_hi=xh, A_lo=xl, lda=K, B_hi=wh, B_lo=wl, ldb=K, M=M, N=N, K=K, bias=b, C=y0, ldc=N)
+    ops.gemm(0, 0, 1, 'F32', A_hi=xh, A_lo=xl, lda=K, B_hi=wh, B_lo=wl, ldb=K, M=M, N=N, K=K, bias=b, C=y1, ldc=N, col_sums=sums)
+    assert torch.equal(y0, y1)
+    yd = y1.double()
+    assert rel_err(sums[:N], yd.sum(0)) < 1e-6 and rel_err(sums[N:], (yd * yd).sum(0)) < 1e-6
+    # small problems do not take the 128x128 kernels: the library says so instead of silently skipping the sums
+    assert L.lib().s3d_gemm_col_sums_ok(1, 1664, 384) == 0
 
 
 def test_gemm_wgrad_into_a_sub_matrix():
@@ -199,7 +222,9 @@ def _attn_ref(q, k, v):
                                                 (5, 4, 100, 192, True), (2, 3, 257, 64, False), (64, 6, 26, 64, False),
                                                 (3, 4, 20, 96, True), (5, 4, 32, 48, False), (3, 2, 7, 64, False), (2, 2, 2, 64, False),
                                                 # even batch, N <= 16, contiguous: two sequences share one 32-row tile (pack_pairs)
-                                                (392, 3, 15, 256, False), (6, 6, 10, 64, False), (4, 4, 16, 48, False), (8, 3, 15, 192, False)])
+                                                (392, 3, 15, 256, False), (6, 6, 10, 64, False), (4, 4, 16, 48, False), (8, 3, 15, 192, False),
+                                                # N <= 32 at hd = 192 / 256: the one-launch backward, gradients two d-blocks at a time
+                                                (3, 4, 20, 192, True), (5, 3, 32, 256, False), (7, 3, 29, 256, False)])
 def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     g = torch.Generator().manual_seed(6)
     D = H * hd
@@ -238,7 +263,8 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
 
 
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(3, 4, 300, 192, True),      # cooperative long-sequence kernels (>= 6 query tiles)
-                                                (2, 3, 197, 256, False), (4, 6, 26, 64, False), (3, 4, 100, 192, True)])
+                                                (2, 3, 197, 256, False), (4, 6, 26, 64, False), (3, 4, 100, 192, True),
+                                                (3, 3, 27, 256, False), (2, 4, 30, 192, True)])     # single-launch backward at hd = 192 / 256
 def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first):
     """Dropout on the attention weights (site 0 of nn.TransformerEncoderLayer): P' = softmax(S) * keep / (1 - p) with the
     counter-based mask of oracle.voxel_oracle.hash_keep_mask over the [Bb*H, N, N] index space -- forward and backward of every
