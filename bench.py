@@ -504,7 +504,7 @@ def main():
     eng.load_state_dict(sd)
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
     x, y = x_cpu.to(dev), y_cpu.to(dev)
-    if conf.get('dropout'):
+    if conf.get('dropout') and os.environ.get('S3D_BENCH_NO_DROPOUT') != '1':          # (tuning aid: the cost of the dropout masks)
         eng.set_dropout(conf['dropout'], seed=9)                # model.train(): nn.TransformerEncoderLayer(dropout=0.1)
     wire = ('bf16' if world > 1 else 'fp32') if args.wire == 'auto' else args.wire
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
