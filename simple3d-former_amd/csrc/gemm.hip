@@ -1507,12 +1507,27 @@ template <bool SPLIT, int EPI>
 int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
     static const int dma = env_int("S3D_GEMM_DMA");                  // S3D_GEMM_DMA=0: register-staged 128x128 kernel instead
     // the 128x128 kernel steps k by 32 in split mode (64 in plain bf16): k = 96 / 160 ... (point-path channel widths) qualify too
+    if constexpr (SPLIT) {
+        // Long forward GEMMs (cfg-3: 32 k - 188 k token rows, k >= 512): 128x256 tiles, eight waves, three 48 KB stages of k = 32.  One
+        // fat workgroup per CU moves 25 % fewer operand bytes per flop than two 128x128 ones and keeps 96 KB in flight; measured at
+        // M = 65 536 (us): qkv 761 -> 692, proj 301 -> 276, fc1 1151 -> 1038, fc2 957 -> 832 (two stages: no gain; 64x128 / 64x96 /
+        // 64x64 tiles with three workgroups per CU: 20 - 40 % slower -- bytes per flop decide, not occupancy).
+        static const int fat = env_int("S3D_GEMM_NT_FAT");                  // 0: never
+        if (fat != 0 && dma != 0 && tile == 2 && a.M >= 16384 && a.K >= 512 && (a.K & 31) == 0 && (a.N & 255) == 0 &&
+            (long)((a.M + 127) / 128) * (a.N / 256) >= 512)
+            return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 4, 0, 32>(a, s);
+    }
     if (dma != 0 && tile == 2 && (a.K & (SPLIT ? 31 : 63)) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
     if constexpr (SPLIT) {
         // small forward tiles on the same DMA pipeline with two k = 64 stages (S3D_GEMM_DMA_SMALL=0: register-staged kernel).
         // cfg-2, us: qkv 12.1 -> 9.7, proj 7.8 -> 6.4, fc1 18.8 -> 16.2, fc2 19.8 -> 14.6; three stages or k = 32 stages were neutral.
         static const int dma_small = env_int("S3D_GEMM_DMA_SMALL");
         if (dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+            if (tile == 24) return launch_nt_dma_small<SPLIT, EPI, 256, 128, 2, 4, 2, 0, 32>(a, s);  // fat tile, eight waves, 96 KB ring (135 KB with the staged epilogue)
+            if (tile == 25) return launch_nt_dma_small<SPLIT, EPI, 256, 128, 3, 4, 2, 0, 32>(a, s);  // ... three stages (144 KB)
+            if (tile == 26) return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 4, 0, 32>(a, s);  // the wide way round
+            if (tile == 27) return launch_nt_dma_small<SPLIT, EPI, 256, 128, 3, 4, 4, 0, 32>(a, s);  // sixteen waves (64x32 sub-tiles)
+            if (tile == 28) return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 8, 0, 32>(a, s);
             if (tile == 4) return launch_nt_dma_small<SPLIT, EPI, 128, 96, 4, 2, 2, 1, 32>(a, s);   // deep ring of k = 32 stages
             if (tile == 5) return launch_nt_dma_small<SPLIT, EPI, 64, 128, 4, 2, 4, 1, 32>(a, s);
             if (tile == 11) return launch_nt_dma_small<SPLIT, EPI, 128, 128, 4, 4, 2, 1, 32>(a, s);

@@ -2,7 +2,7 @@
 # forward-GEMM tile variants on the cfg-3 shapes (one process per tile id: the override is read once)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r2
-for t in -1 11 16 14 7 17 4; do
+for t in ${TILES:--1 11 16 14 7 17 4}; do
   echo "== S3D_GEMM_NT_TILE=$t"
   S3D_GEMM_NT_TILE=$t M=${M:-65536} timeout 300 python tools/gemm_big_bench.py 2>&1 | grep -E "split=1|Error|error" 
 done > gpurun_out/r2/gemm_tiles_big.txt 2>&1
