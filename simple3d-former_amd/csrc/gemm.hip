@@ -1465,7 +1465,7 @@ int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
         if ((a.K & 63) != 0) return launch_dmat<TA, TB, EPI, BT, true, BTN>(a, splitk, stream);      // partial last k-tile
     }
     constexpr int WM = BT >= 128 ? BT / 64 : 2, WN = BTN >= 128 ? BTN / 64 : 2;          // 64x64 wave sub-tiles (32x32 on the 64x64 tile)
-    constexpr int NS = (BT == 64 || (BT == 256 && BTN == 128)) ? 3 : 2, STAGE = (BT + BTN) * 64 * 2;   // 256x128: three 48 KB stages = one fat workgroup per CU
+    constexpr int NS = (BT == 64 || BT + BTN == 384) ? 3 : 2, STAGE = (BT + BTN) * 64 * 2;   // 256x128: three 48 KB stages = one fat workgroup per CU
     constexpr int LDS = cmax(NS * STAGE, EPI == EPI_ATOMIC ? 0 : BT * (BTN + 4) * 4);
     static_assert(LDS <= 160 * 1024, "tile does not fit the CU's LDS");
     static bool attr_set = false;
@@ -1513,7 +1513,8 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // M = 65 536 (us): qkv 761 -> 692, proj 301 -> 276, fc1 1151 -> 1038, fc2 957 -> 832 (two stages: no gain; 64x128 / 64x96 /
         // 64x64 tiles with three workgroups per CU: 20 - 40 % slower -- bytes per flop decide, not occupancy).
         static const int fat = env_int("S3D_GEMM_NT_FAT");                  // 0: never
-        if (fat != 0 && dma != 0 && tile == 2 && a.M >= 16384 && a.K >= 512 && (a.K & 31) == 0 && (a.N & 255) == 0 &&
+        static const int fat_mink = env_int("S3D_GEMM_NT_FAT_MINK") > 0 ? env_int("S3D_GEMM_NT_FAT_MINK") : 512;
+        if (fat != 0 && dma != 0 && tile == 2 && a.M >= 16384 && a.K >= fat_mink && (a.K & 31) == 0 && (a.N & 255) == 0 &&
             (long)((a.M + 127) / 128) * (a.N / 256) >= 512)
             return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 4, 0, 32>(a, s);
     }
@@ -1750,13 +1751,22 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
             static const int fat = env_int("S3D_WGRAD_FAT");            // -1 (unset): as above; 0: never; 1: every long wgrad
             static const int dmat_on = env_int("S3D_GEMM_DMAT"), forced_sk = env_int("S3D_GEMM_SPLITK");
             const bool shape_ok = a.K >= 16384 && a.M >= 256 && a.N >= 256 && (a.K & 7) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0;
-            if (fat != 0 && dmat_on != 0 && splitk <= 0 && forced_sk <= 0 && !s3d_deterministic() && shape_ok && (fat == 1 || a.M <= 1024)) {
+            if (fat != 0 && dmat_on != 0 && splitk <= 0 && forced_sk <= 0 && !s3d_deterministic() && shape_ok && (fat == 1 || fat == 3 || a.M <= 1024)) {
                 const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
                 int sk = (int)((512 + tiles / 2) / tiles);               // about two workgroups per CU over the launch
                 sk = sk < 1 ? 1 : sk;
                 if (sk > a.K / 2048) sk = a.K / 2048;
                 a.kchunk = ((a.K + sk - 1) / sk + 63) / 64 * 64;
                 sk = (a.K + a.kchunk - 1) / a.kchunk;
+                if (fat == 3) {                                        // experiment: the wide way round (all long wgrads)
+                    const long tiles2 = (long)((a.M + 127) / 128) * ((a.N + 255) / 256);
+                    int s2 = (int)((512 + tiles2 / 2) / tiles2);
+                    s2 = s2 < 1 ? 1 : s2;
+                    if (s2 > a.K / 2048) s2 = a.K / 2048;
+                    a.kchunk = ((a.K + s2 - 1) / s2 + 63) / 64 * 64;
+                    s2 = (a.K + a.kchunk - 1) / a.kchunk;
+                    return launch_dmat<true, true, EPI_ATOMIC, 128, false, 256>(a, s2, stream);
+                }
                 return launch_dmat<true, true, EPI_ATOMIC, 256, false, 128>(a, sk, stream);
             }
         }
@@ -1793,7 +1803,15 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         // long dgrads with a short reduction (k = output width <= 1024: cfg-3 proj, fc2): 256x128 tiles as for the wgrads above
         // (fc2 1479 -> 1327 us, proj 372 -> 358 us at 188 160 rows; neutral for k = 2304 / 3072)
         static const int dfat = env_int("S3D_DGRAD_FAT");               // -1 (unset): as above; 0: never; 1: every long dgrad
-        if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= 16384 && a.N >= 256 && (dfat == 1 || (a.K >= 512 && a.K <= 1024))) {
+        if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= 16384 && a.N >= 256 && (dfat == 1 || dfat == 3 || (a.K >= 512 && a.K <= 1024))) {
+            if (dfat == 3 && (a.N & 255) == 0) {                       // experiment: 128x256
+                switch (epi) {
+                    case EPI_F32: return launch_dmat<false, true, EPI_F32, 128, false, 256>(a, 1, stream);
+                    case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 128, false, 256>(a, 1, stream);
+                    case EPI_BF16_BIAS: return launch_dmat<false, true, EPI_BF16_BIAS, 128, false, 256>(a, 1, stream);
+                    default: break;
+                }
+            }
             switch (epi) {
                 case EPI_F32: return launch_dmat<false, true, EPI_F32, 256, false, 128>(a, 1, stream);
                 case EPI_DGELU: return launch_dmat<false, true, EPI_DGELU, 256, false, 128>(a, 1, stream);
