@@ -46,7 +46,9 @@ def test_split_bf16_reconstructs_fp32():
 
 @pytest.mark.parametrize('M,N,K', [(64, 40, 384), (100, 384, 216), (1664, 1152, 384), (1664, 384, 1536), (4096, 3072, 768),
                                    # point-path shapes: many rows, narrow n, k = 96 / 64 / 192 (k % 32 on the 128x128 LDS-DMA kernel), ragged M
-                                   (70000, 96, 96), (65537, 96, 64), (33000, 192, 192), (66000, 48, 48)])
+                                   (70000, 96, 96), (65537, 96, 64), (33000, 192, 192), (66000, 48, 48),
+                                   # long cfg-3 shapes: 128x256 tiles, sixteen waves, three stages (ragged last row tile)
+                                   (33001, 768, 768), (66000, 256, 1024), (22000, 2304, 512)])
 @pytest.mark.parametrize('split', [True, False])
 def test_gemm_forward_nt(M, N, K, split):
     g = torch.Generator().manual_seed(1)
@@ -137,9 +139,10 @@ def test_gemm_wgrad_into_a_sub_matrix():
     assert rel_err(dW[:, 3:], dyh.double().t() @ xh.double()) < 2e-5 and float(dW[:, :3].abs().max()) == 0.0
 
 
-def test_gemm_epilogues_gelu_resid_token_dgelu():
+@pytest.mark.parametrize('M,N,K', [(130, 192, 128),
+                                   (33003, 768, 512)])      # 128x256 sixteen-wave forward tiles / 256x128 eight-wave dgrad tiles
+def test_gemm_epilogues_gelu_resid_token_dgelu(M, N, K):
     g = torch.Generator().manual_seed(4)
-    M, N, K = 130, 192, 128
     x = torch.randn(M, K, generator=g).to(DEV)
     w = (torch.randn(N, K, generator=g) * 0.1).to(DEV)
     b = torch.randn(N, generator=g).to(DEV)
