@@ -83,19 +83,23 @@ __device__ __forceinline__ float wave_sum(float v) { return wave_reduce(v, [](fl
 __device__ __forceinline__ float wave_max(float v) { return wave_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
 
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, one exp + 5 FMAs): ~3x fewer VALU instructions than erff in
-// the GELU epilogues, with an error far below the bf16/1e-3 budgets of this path.
+// the GELU epilogues, with an error far below the bf16/1e-3 budgets of this path.  The reciprocal is the hardware's (v_rcp_f32,
+// 1 ulp) instead of an IEEE division (~10 instructions), and gelu' shares the one exponential erf and the density both need:
+// the fc1 / fc2-dgrad epilogues evaluate these 64 times per thread on a 128x128 tile (a fifth of the workgroup's lifetime).
+__device__ __forceinline__ float erf_poly(float ax, float e) {           // 1 - erf(ax) for ax >= 0, e = exp(-ax^2)
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    return t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f)))) * e;
+}
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = 1.0f / (1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
+    return copysignf(1.0f - erf_poly(ax, __expf(-ax * ax)), x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    const float z = x * 0.70710678118654752f, az = fabsf(z);
+    const float e = __expf(-az * az);                                    // = exp(-x^2 / 2): erf's exponential AND the normal density's
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - erf_poly(az, e), z));
+    return cdf + x * (0.39894228040143268f * e);
 }
 
 // counter-based dropout mask (hash of the element index; the oracle evaluates the same function, voxel_oracle.hash_keep_mask)
