@@ -520,6 +520,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
     const long base = (long)b * p.sb * p.ld + h * HD;
     const int k0 = kt * 32, krow = k0 + l31;
     const bool kok = krow < p.N;
+    const float sc2 = p.scale * 1.4426950408889634f;                  // scores -> log2 units (lse is staged pre-scaled)
     const int krow_c = min(krow, p.N - 1);
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
     const DropRow dcol = drop_row(dkey, (unsigned long long)bh * p.N * p.N + krow_c);        // mask index = column base + q * N
@@ -554,7 +555,10 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             rq[i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + base + t * st_ld + cc * 8);
             rd[i] = *reinterpret_cast<const u32x4*>(p.dout + dobase + t * st_lddo + cc * 8);
         }
-        if (tid < 64) rr = (tid < 32 ? p.lse : p.delta)[(long)bh * p.N + min(q0 + (tid & 31), p.N - 1)];
+        if (tid < 64) {
+            rr = (tid < 32 ? p.lse : p.delta)[(long)bh * p.N + min(q0 + (tid & 31), p.N - 1)];
+            if (tid < 32) rr *= 1.4426950408889634f;               // lse is staged in log2 units: P = exp2(S * scale * log2 e - lse2)
+        }
     };
     auto lstore = [&](int buf) {
         bf16_t* q = reinterpret_cast<bf16_t*>(smem + buf * BUF_BYTES);
@@ -608,8 +612,9 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                 for (int e = 0; e < 2; ++e) {
                     const int r = 8 * s2 + j + e, qr = acc_row(r, h2);
                     const int q = q0 + qr;
-                    const bool ok = kok && (q < p.N);
-                    const float pr = ok ? fast_exp(sacc[r] * p.scale - lse4[r >> 2][r & 3]) : 0.f;
+                    // columns of keys >= N are never stored, so only the ragged last QUERY tile needs a select (clamped rows would count twice)
+                    float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
+                    if (q0 + 32 > p.N) pr = (q < p.N) ? pr : 0.f;
                     float dm = 1.f;     // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
                     if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)q * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
                     pv[e] = pr * dm;
@@ -725,6 +730,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;                  // scores -> log2 units
 
     ST st;
     const bf16_t* src[2 * NPL];
@@ -762,21 +768,24 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
             }
             sacc = MFMA32(kh, qh[s], sacc);
         }
+        // The running maximum lives in log2 units (m_i = max(raw score) * scale * log2 e): one fma + v_exp per probability instead of
+        // multiply / subtract / multiply / v_exp, and the key-validity select only on the last (ragged) key tile.
         float sv[16], mloc = -INFINITY;
+        if (k0 + 32 > p.N) {                                      // wave-uniform
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const bool ok = (k0 + acc_row(r, h2)) < p.N;
-            sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
-            mloc = fmaxf(mloc, sv[r]);
+            for (int r = 0; r < 16; ++r)
+                if (k0 + acc_row(r, h2) >= p.N) sacc[r] = -INFINITY;
         }
-        mloc = half_max(mloc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+        mloc = half_max(mloc) * sc2;                              // sc2 > 0
         const float mnew = fmaxf(m_i, mloc);
         const float mold = m_i;
-        const float alpha = fast_exp(m_i - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(m_i - mnew);
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            sv[r] = fast_exp(sv[r] - mnew);
+            sv[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -mnew));      // masked keys: exp2(-inf) = 0
             lsum += sv[r];
         }
         lsum = half_sum(lsum);
@@ -833,7 +842,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
                 *reinterpret_cast<uint2*>(p.out_hi + off) = hi.u;
                 if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
             }
-        if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i + logf(l_i);
+        if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i * 0.6931471805599453f + logf(l_i);      // m_i is in log2 units
     }
 }
 
@@ -903,6 +912,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
         if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
         const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
         const bf16_t* ldsV = ldsK + TILE;
+        const bool ragged = k0 + 32 > p.N;
+        const float sc2 = p.scale * 1.4426950408889634f, lse2 = lse_q * 1.4426950408889634f;
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
@@ -921,8 +932,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int r = 8 * s2 + j + e;
-                    const bool ok = (k0 + acc_row(r, h2)) < p.N;
-                    const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+                    float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse2));            // exp(S * scale - lse), one fma + v_exp
+                    if (ragged) pr = (k0 + acc_row(r, h2)) < p.N ? pr : 0.f;                 // last key tile only (wave-uniform)
                     float dpn = dpacc[r];
                     if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
                     dsv[e] = pr * (dpn - delta) * p.scale;
