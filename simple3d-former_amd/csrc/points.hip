@@ -489,11 +489,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
         s2[i] = (float)(sums[C + c + i] / rows);
     }
     const unsigned uK = (unsigned)(K > 0 ? K : 1);
+    const int kshift = (uK & (uK - 1)) == 0 ? __builtin_ctz(uK) : -1;        // k = 16 neighbours: a shift, not a 64-bit division per row
     for (long r = (long)blockIdx.x * l.rpb + l.sub; r < rows; r += (long)gridDim.x * l.rpb) {
         const f32x4 xv = ld4(x + r * ld + c);
         f32x4 gq = {0.f, 0.f, 0.f, 0.f};
         if (arg) {
-            const long sg = r / uK;
+            const long sg = kshift >= 0 ? (r >> kshift) : r / uK;
             const unsigned kk = (unsigned)(r - sg * uK);
             const unsigned ab = *reinterpret_cast<const unsigned*>(arg + sg * C + c);
             const f32x4 d = ld_grad4(dy, dyb, sg * lddy + c);
@@ -531,10 +532,38 @@ __global__ void interp3_kernel(const float* __restrict__ f1, int S, const float*
         out[i] = v;
     }
 }
+// channel-quad version (C % 4 == 0, rows * C / 4 < 2^32): 16-byte accesses and one 32-bit division per four channels instead of a
+// 64-bit division / modulo per element (the scalar kernels spent most of their instructions on index arithmetic)
+__global__ __launch_bounds__(256) void interp3_vec_kernel(const float* __restrict__ f1, int S, const float* __restrict__ f2,
+                                                          const int* __restrict__ idx, const float* __restrict__ w, int N, int C,
+                                                          unsigned rows, float* __restrict__ out) {
+    const unsigned qpr = (unsigned)C / 4, total = rows * qpr;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / qpr, c = 4 * (i - r * qpr), b = r / (unsigned)N;
+        f32x4 v = ld4(f2 + (long)r * C + c);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float wj = w[r * 3 + j];
+            const f32x4 f = ld4(f1 + ((long)b * S + idx[r * 3 + j]) * C + c);
+            v[0] += wj * f[0]; v[1] += wj * f[1]; v[2] += wj * f[2]; v[3] += wj * f[3];
+        }
+        *reinterpret_cast<f32x4*>(out + (long)r * C + c) = v;
+    }
+}
 // backward: df1[b, idx] += w * dout (df2 = dout is the caller's alias)
 __global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ w, int S,
                                    int N, int C, long rows, float* __restrict__ df1) {
     const long total = rows * C;
+    if (total < (1L << 32)) {                                  // 32-bit index arithmetic (a 64-bit division is ~3x the instructions)
+        const unsigned uC = (unsigned)C, uN = (unsigned)N;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+            const unsigned r = i / uC, c = i - r * uC, b = r / uN;
+            const float g = dout[i];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) atomic_add_f32(df1 + ((long)b * S + idx[r * 3 + j]) * (long)C + c, w[r * 3 + j] * g);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C;
         const int c = (int)(i % C);
@@ -736,6 +765,21 @@ __global__ void pack_rows_kernel(const float* __restrict__ x, int C, int ldx, lo
         if (lo) lo[i] = l;
     }
 }
+// quad version: C, ldx, ldo multiples of 4, rows * ldo / 4 < 2^32
+__global__ __launch_bounds__(256) void pack_rows_vec_kernel(const float* __restrict__ x, int C, int ldx, unsigned rows, bf16_t* __restrict__ hi,
+                                                            bf16_t* __restrict__ lo, int ldo) {
+    const unsigned qpr = (unsigned)ldo / 4, total = rows * qpr;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned r = i / qpr, c = 4 * (i - r * qpr);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((int)c < C) v = ld4(x + (long)r * ldx + c);
+        union { u32x2 u; uint32_t w[2]; } h, l;
+        split_bf16x2(v[0], v[1], h.w[0], l.w[0]);
+        split_bf16x2(v[2], v[3], h.w[1], l.w[1]);
+        *reinterpret_cast<u32x2*>(hi + (long)r * ldo + c) = h.u;
+        if (lo) *reinterpret_cast<u32x2*>(lo + (long)r * ldo + c) = l.u;
+    }
+}
 // a += b (fp32)
 __global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) a[i] += b[i];
@@ -924,12 +968,18 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
 int s3d_launch_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,
                        hipStream_t s) {
     const long rows = (long)B * N;
+    if (C % 4 == 0 && rows * (C / 4) < (1L << 32) && al(f1, 16) && al(f2, 16) && al(out, 16)) {
+        hipLaunchKernelGGL(interp3_vec_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, f1, S, f2, idx, w, N, C, (unsigned)rows, out);
+        S3D_CHECK_LAUNCH("interp3");
+        return 0;
+    }
     hipLaunchKernelGGL(interp3_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, f1, S, f2, idx, w, N, C, rows, out);
     S3D_CHECK_LAUNCH("interp3");
     return 0;
 }
 int s3d_launch_interp3_bwd(const float* dout, const int* idx, const float* w, int B, int S, int N, int C, float* df1, hipStream_t s) {
     const long rows = (long)B * N;
+    // (a channel-quad version of this kernel is 2x slower: four atomics per lane at 16-byte strides instead of one coalesced row)
     hipLaunchKernelGGL(interp3_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, s, dout, idx, w, S, N, C, rows, df1);
     S3D_CHECK_LAUNCH("interp3_bwd");
     return 0;
@@ -945,6 +995,11 @@ int s3d_launch_bcast_rows(const float* x, int N, int C, long rows, float scale, 
     return 0;
 }
 int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, bf16_t* lo, int ldo, hipStream_t s) {
+    if (C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && rows * (ldo / 4) < (1L << 32) && al(x, 16) && al(hi, 8) && al(lo, 8)) {
+        hipLaunchKernelGGL(pack_rows_vec_kernel, dim3(grid_for(rows * (ldo / 4))), dim3(256), 0, s, x, C, ldx, (unsigned)rows, hi, lo, ldo);
+        S3D_CHECK_LAUNCH("pack_rows");
+        return 0;
+    }
     hipLaunchKernelGGL(pack_rows_kernel, dim3(grid_for(rows * ldo)), dim3(256), 0, s, x, C, ldx, rows, hi, lo, ldo);
     S3D_CHECK_LAUNCH("pack_rows");
     return 0;
