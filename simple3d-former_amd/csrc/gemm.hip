@@ -29,6 +29,12 @@ static int env_int(const char* name) {
     return v ? atoi(v) : -1;
 }
 
+// token rows from which a GEMM counts as "long" (fat forward / backward tiles, 128x128 split-K wgrads): S3D_GEMM_LONG_ROWS
+static int long_rows() {
+    static const int v = env_int("S3D_GEMM_LONG_ROWS") > 0 ? env_int("S3D_GEMM_LONG_ROWS") : 8192;     // cfg-3 pass 2 has 12 608 rows: -1.9 ms with 8192 instead of 16384
+    return v;
+}
+
 namespace {
 struct ProfSlot { long long key; double flops; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -1514,7 +1520,7 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // 64x64 tiles with three workgroups per CU: 20 - 40 % slower -- bytes per flop decide, not occupancy).
         static const int fat = env_int("S3D_GEMM_NT_FAT");                  // 0: never
         static const int fat_mink = env_int("S3D_GEMM_NT_FAT_MINK") > 0 ? env_int("S3D_GEMM_NT_FAT_MINK") : 512;
-        if (fat != 0 && dma != 0 && tile == 2 && a.M >= 16384 && a.K >= fat_mink && (a.K & 31) == 0 && (a.N & 255) == 0 &&
+        if (fat != 0 && dma != 0 && tile == 2 && a.M >= long_rows() && a.K >= fat_mink && (a.K & 31) == 0 && (a.N & 255) == 0 &&
             (long)((a.M + 127) / 128) * (a.N / 256) >= 512)
         {
             // sixteen waves on 64x32 sub-tiles (76 - 90 registers): 0.5 % ahead of eight waves on 64x64 (140 - 164) in the cfg-3 step
@@ -1614,7 +1620,7 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
     if (forced_sk > 0) splitk = forced_sk;
     if (s3d_deterministic()) splitk = 1;       // one workgroup per output tile: a single fp32 add per element, no ordering freedom
     static const int big_min = env_int("S3D_WGRAD_BIG_MIN") > 0 ? env_int("S3D_WGRAD_BIG_MIN") : 48;   // narrow long-k wgrads (point path: 96 x 56 x 2.1 M) stream well on the DMA kernel too
-    if (splitk <= 0 && a.K >= 16384 && a.M >= big_min && a.N >= big_min) {
+    if (splitk <= 0 && a.K >= long_rows() && a.M >= big_min && a.N >= big_min) {
         // long reductions (cfg-3: k = 188k token rows): 128x128 tiles re-read 4x less than 64x64 ones, and k is long enough
         // to give every tile several k-slices -> size the split for >= 768 workgroups of 128x128
         const long tiles128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -1754,7 +1760,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
             // fc2 1302 -> 1082 us, proj 356 -> 322 us; the wide-output wgrads (qkv, fc1) lose 2 - 3 % and stay on 128x128.
             static const int fat = env_int("S3D_WGRAD_FAT");            // -1 (unset): as above; 0: never; 1: every long wgrad
             static const int dmat_on = env_int("S3D_GEMM_DMAT"), forced_sk = env_int("S3D_GEMM_SPLITK");
-            const bool shape_ok = a.K >= 16384 && a.M >= 256 && a.N >= 256 && (a.K & 7) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0;
+            const bool shape_ok = a.K >= long_rows() && a.M >= 256 && a.N >= 256 && (a.K & 7) == 0 && (a.M & 7) == 0 && (a.N & 7) == 0;
             if (fat != 0 && dmat_on != 0 && splitk <= 0 && forced_sk <= 0 && !s3d_deterministic() && shape_ok && (fat == 1 || fat == 3 || a.M <= 1024)) {
                 const long tiles = (long)((a.M + 255) / 256) * ((a.N + 127) / 128);
                 int sk = (int)((512 + tiles / 2) / tiles);               // about two workgroups per CU over the launch
@@ -1807,7 +1813,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         // long dgrads with a short reduction (k = output width <= 1024: cfg-3 proj, fc2): 256x128 tiles as for the wgrads above
         // (fc2 1479 -> 1327 us, proj 372 -> 358 us at 188 160 rows; neutral for k = 2304 / 3072)
         static const int dfat = env_int("S3D_DGRAD_FAT");               // -1 (unset): as above; 0: never; 1: every long dgrad
-        if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= 16384 && a.N >= 256 && (dfat == 1 || dfat == 3 || (a.K >= 512 && a.K <= 1024))) {
+        if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= long_rows() && a.N >= 256 && (dfat == 1 || dfat == 3 || (a.K >= 512 && a.K <= 1024))) {
             if (dfat == 3 && (a.N & 255) == 0) {                       // experiment: 128x256
                 switch (epi) {
                     case EPI_F32: return launch_dmat<false, true, EPI_F32, 128, false, 256>(a, 1, stream);
