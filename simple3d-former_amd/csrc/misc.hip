@@ -132,6 +132,17 @@ __global__ __launch_bounds__(64) void posgrad_det_kernel(const PosGradArgs p) {
 __global__ void assemble_tokens_kernel(const float* __restrict__ src, const float* __restrict__ cls,
                                        const float* __restrict__ pos, float* __restrict__ out, long B, int n, int D) {
     const long total = B * (n + 1) * (long)(D / 4);
+    if (total < (1L << 32)) {                                   // 32-bit index arithmetic (two 64-bit divisions per float4 otherwise)
+        const unsigned q = (unsigned)D / 4, n1 = (unsigned)n + 1;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+            const unsigned row = i / q, d4 = i - row * q, b = row / n1, t = row - b * n1;
+            const f32x4 p4 = reinterpret_cast<const f32x4*>(pos + (long)t * D)[d4];
+            const f32x4 s4 = (t == 0) ? reinterpret_cast<const f32x4*>(cls)[d4]
+                                      : reinterpret_cast<const f32x4*>(src + ((long)b * n + t - 1) * D)[d4];
+            reinterpret_cast<f32x4*>(out + (long)row * D)[d4] = s4 + p4;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int d4 = (int)(i % (D / 4));
         const long row = i / (D / 4);
@@ -145,6 +156,14 @@ __global__ void assemble_tokens_kernel(const float* __restrict__ src, const floa
 }
 __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc, long B, int n, int D) {
     const long total = B * n * (long)(D / 4);
+    if (total < (1L << 32)) {
+        const unsigned q = (unsigned)D / 4, un = (unsigned)n;
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+            const unsigned row = i / q, d4 = i - row * q, b = row / un, j = row - b * un;
+            reinterpret_cast<f32x4*>(dsrc + (long)row * D)[d4] = reinterpret_cast<const f32x4*>(dout + ((long)b * (n + 1) + 1 + j) * D)[d4];
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int d4 = (int)(i % (D / 4));
         const long row = i / (D / 4);
@@ -318,15 +337,19 @@ __global__ __launch_bounds__(256) void ce_main_kernel(const CeArgs p) {   // one
         for (int c = lane; c < p.C; c += 64) m = fmaxf(m, l[c]);
         m = wave_max(m);
         float s = 0.f;
-        for (int c = lane; c < p.C; c += 64) s += expf(l[c] - m);
+        for (int c = lane; c < p.C; c += 64) s += __expf(l[c] - m);
         s = wave_sum(s);
         const long t = p.target[row];
         const float w = p.weight ? p.weight[t] : 1.f;
         const float lse = m + logf(s);
         acc += w * (lse - l[t]);
-        if (p.dlogits)
+        if (p.dlogits) {
+            // softmax from the exponentials' sum (one fast exp and one multiply per class; the per-row factors are hoisted): this
+            // kernel walks 65 536 rows x 50 classes in the part-segmentation step
+            const float inv_s = 1.0f / s, gw = p.grad_scale * w / den;
             for (int c = lane; c < ld; c += 64)
-                p.dlogits[row * ld + c] = (c < p.C) ? p.grad_scale * w * (expf(l[c] - lse) - (c == t ? 1.f : 0.f)) / den : 0.f;
+                p.dlogits[row * ld + c] = (c < p.C) ? gw * (__expf(l[c] - m) * inv_s - (c == t ? 1.f : 0.f)) : 0.f;
+        }
     }
     if (gridDim.x == 1) {                        // deterministic mode: the four wave sums are combined in a fixed order
         __shared__ float part[4];
