@@ -1534,6 +1534,7 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // cfg-2, us: qkv 12.1 -> 9.7, proj 7.8 -> 6.4, fc1 18.8 -> 16.2, fc2 19.8 -> 14.6; three stages or k = 32 stages were neutral.
         static const int dma_small = env_int("S3D_GEMM_DMA_SMALL");
         if (dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0) {
+#ifdef S3D_EXPERIMENTAL_TILES       // make EXP=1: the tile / wave-count / ring-depth variants measured and rejected in DESIGN.md section 6 (S3D_GEMM_NT_TILE = 4 .. 28)
             if (tile == 24) return launch_nt_dma_small<SPLIT, EPI, 256, 128, 2, 4, 2, 0, 32>(a, s);  // fat tile, eight waves, 96 KB ring (135 KB with the staged epilogue)
             if (tile == 25) return launch_nt_dma_small<SPLIT, EPI, 256, 128, 3, 4, 2, 0, 32>(a, s);  // ... three stages (144 KB)
             if (tile == 26) return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 4, 0, 32>(a, s);  // the wide way round
@@ -1559,6 +1560,7 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
             if (tile == 8) return launch_nt_dma_small<SPLIT, EPI, 64, 96, 2, 2, 2, 1>(a, s);
             if (tile == 9) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2, 2, 2, 1>(a, s);
             if (tile == 10) return launch_nt_dma_small<SPLIT, EPI, 32, 32, 2, 2, 2, 1>(a, s);
+#endif
             if (tile == 1) return launch_nt_dma_small<SPLIT, EPI, 64, 64, 2>(a, s);
             if (tile == 0) return launch_nt_dma_small<SPLIT, EPI, 32, 64, 2>(a, s);
             if (tile == 3) {
