@@ -11,7 +11,8 @@ __device__ __forceinline__ void ln_row_finish(const float4 (&v)[MC], const int l
     float s = 0.f;
 #pragma unroll
     for (int c = 0; c < MC; ++c) s += v[c].x + v[c].y + v[c].z + v[c].w;
-    const float mean = wave_sum(s) / D;
+    const float inv_d = 1.0f / (float)D;                  // one division per row instead of two (each ~10 instructions on every lane)
+    const float mean = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int c = 0; c < MC; ++c) {
@@ -21,7 +22,7 @@ __device__ __forceinline__ void ln_row_finish(const float4 (&v)[MC], const int l
             q += a * a + b * b + cc * cc + d * d;
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / D + eps);
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
     if (lane == 0) {
         if (mean_out) *mean_out = mean;
         if (rstd_out) *rstd_out = rstd;
