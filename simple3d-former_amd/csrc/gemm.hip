@@ -1528,6 +1528,12 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
             return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 8, 0, 32>(a, s);
         }
     }
+    if constexpr (SPLIT) {
+        // N = 192 (point path, deit_tiny: proj / fc2): two 128-wide tile columns would compute 256 columns for 192; one 64x192 tile
+        // column (64 KB ring, two workgroups per CU) wastes nothing
+        static const int w192 = env_int("S3D_GEMM_NT_192");
+        if (w192 != 0 && dma != 0 && tile == 2 && a.N == 192 && (a.K & 31) == 0) return launch_nt_dma_small<SPLIT, EPI, 64, 192, 2, 2, 2, 0, 32>(a, s);
+    }
     if (dma != 0 && tile == 2 && (a.K & (SPLIT ? 31 : 63)) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
     if constexpr (SPLIT) {
         // small forward tiles on the same DMA pipeline with two k = 64 stages (S3D_GEMM_DMA_SMALL=0: register-staged kernel).
