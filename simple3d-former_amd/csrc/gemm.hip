@@ -1532,7 +1532,8 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         // N = 192 (point path, deit_tiny: proj / fc2): two 128-wide tile columns would compute 256 columns for 192; one 64x192 tile
         // column (64 KB ring, two workgroups per CU) wastes nothing
         static const int w192 = env_int("S3D_GEMM_NT_192");
-        if (w192 != 0 && dma != 0 && tile == 2 && a.N == 192 && (a.K & 31) == 0) return launch_nt_dma_small<SPLIT, EPI, 64, 192, 2, 2, 2, 0, 32>(a, s);
+        // (not with col_sums: the column-sum fold needs every thread on ONE 8-column group, 256 % 24 != 0 here)
+        if (w192 != 0 && dma != 0 && tile == 2 && a.N == 192 && (a.K & 31) == 0 && a.col_sums == nullptr) return launch_nt_dma_small<SPLIT, EPI, 64, 192, 2, 2, 2, 0, 32>(a, s);
     }
     if (dma != 0 && tile == 2 && (a.K & (SPLIT ? 31 : 63)) == 0 && (a.N & 7) == 0) return launch_nt_dma<SPLIT, EPI>(a, s);
     if constexpr (SPLIT) {

@@ -107,7 +107,7 @@ def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     assert rel_err(dW, 2 * (dyh.double().t() @ xh.double())) < 2e-5
 
 
-@pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40)])   # k = 40: register-staged kernel
+@pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40), (66000, 192, 192), (33000, 192, 96)])   # k = 40: register-staged kernel
 def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
     """S3dGemmArgs::col_sums: the F32 epilogue of a point-path convolution also accumulates sum(y) and sum(y^2) per output channel
     (fp64 atomics), i.e. the batch statistics of the BatchNorm that follows; the GEMM output itself is unchanged."""
