@@ -48,7 +48,7 @@ def test_split_bf16_reconstructs_fp32():
                                    # point-path shapes: many rows, narrow n, k = 96 / 64 / 192 (k % 32 on the 128x128 LDS-DMA kernel), ragged M
                                    (70000, 96, 96), (65537, 96, 64), (33000, 192, 192), (66000, 48, 48),
                                    # long cfg-3 shapes: 128x256 tiles, sixteen waves, three stages (ragged last row tile)
-                                   (33001, 768, 768), (66000, 256, 1024), (22000, 2304, 512)])
+                                   (33001, 768, 768), (66000, 256, 1024), (22000, 2304, 512), (12608, 3072, 768)])      # 12 608 = cfg-3 pass 2
 @pytest.mark.parametrize('split', [True, False])
 def test_gemm_forward_nt(M, N, K, split):
     g = torch.Generator().manual_seed(1)
@@ -72,7 +72,7 @@ def test_gemm_catches_transposes():
 
 @pytest.mark.parametrize('M,N,K', [(78, 192, 576), (1664, 1536, 384), (1664, 384, 1152), (4096, 768, 3072),
                                    (70000, 96, 96), (66000, 192, 192), (33001, 48, 96), (131072, 56, 96),       # point path: k = 96 stays register-staged
-                                   (20000, 768, 768), (16500, 3072, 768)])                                    # long + short reduction: 256x128 tiles, 8 waves
+                                   (20000, 768, 768), (16500, 3072, 768), (12608, 768, 3072), (12608, 3072, 768)])                                    # long + short reduction: 256x128 tiles, 8 waves
 def test_gemm_dgrad_nn(M, N, K):
     """dx[m][i] = sum_o dy[m][o] W[o][i]: W is stored [K=o][N=i] (k-major B operand)."""
     g = torch.Generator().manual_seed(2)
@@ -89,7 +89,7 @@ def test_gemm_dgrad_nn(M, N, K):
 
 @pytest.mark.parametrize('rows,O,I', [(30, 64, 192), (78, 576, 192), (1664, 1536, 384), (1664, 384, 1536), (1664, 384, 216),
                                       (70016, 96, 96), (131072, 96, 48), (188160, 768, 768), (33000, 192, 96),    # long reductions
-                                      (20032, 768, 3072), (16488, 512, 256)])                                     # 256x128 tiles (output rows <= 1024), partial last k-tile
+                                      (20032, 768, 3072), (16488, 512, 256), (12608, 3072, 768), (12608, 768, 768)])                                     # 256x128 tiles (output rows <= 1024), partial last k-tile
 def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     """dW[o][i] += sum_m dy[m][o] x[m][i]; db[o] += sum_m dy[m][o] (split-K fp32 atomics)."""
     g = torch.Generator().manual_seed(3)
