@@ -1387,6 +1387,10 @@ int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
     constexpr int STAGE = (SPLIT ? 2 : 1) * (BM + BN) * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, BM * (BN + 4) * 4);
     static_assert(LDS <= 160 * 1024, "stage ring exceeds the CU's LDS");
+    if (a.col_sums && ((64 * WM * WN) % (BN / 8)) != 0) {        // StagedEpilogue::ONE_COL: this tile cannot fold column sums
+        s3d_set_error("gemm: col_sums reached a %dx%d tile that cannot accumulate them", BM, BN);
+        return 2;
+    }
     auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, false>;
     static bool attr_set = false;
     if (!attr_set) {
