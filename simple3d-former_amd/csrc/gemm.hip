@@ -1436,17 +1436,21 @@ int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = cmax(NS * STAGE, 128 * 132 * 4);
     static bool attr_set = false;
     auto kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false>;
-    static const int m32 = env_int("S3D_GEMM_M32");                   // 1: 32x32x16 MFMAs in the 128x128 forward kernel
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+#ifdef S3D_EXPERIMENTAL_TILES
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+#endif
         if constexpr (EPI == EPI_RESID)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
+#ifdef S3D_EXPERIMENTAL_TILES       // make EXP=1, S3D_GEMM_M32=1: 32x32x16 MFMAs in the 128x128 forward kernel (measured 4 - 7 % slower)
+    static const int m32 = env_int("S3D_GEMM_M32");
     if (m32 == 1) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, false, true>;
+#endif
     if constexpr (EPI == EPI_RESID) {
         if (a.ln_tickets) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, 128, 128, 2, 2, 0, true>;
     }
