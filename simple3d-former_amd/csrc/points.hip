@@ -805,6 +805,11 @@ __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* 
 }
 __global__ void bump_kernel(int* c) { *c += 1; }
 
+// workgroups of the BatchNorm statistics passes (each ends in 2C fp64 atomics): S3D_BN_STATS_BLOCKS
+static long bn_stats_blocks() {
+    static const long v = getenv("S3D_BN_STATS_BLOCKS") ? atol(getenv("S3D_BN_STATS_BLOCKS")) : 1024;
+    return v > 0 ? v : 1024;
+}
 inline unsigned grid_for(long n, int per = 256, long cap = 8192) {
     long b = (n + per - 1) / per;
     if (b > cap) b = cap;
@@ -913,7 +918,7 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
         (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
         const int per = a.C <= 256 ? 256 / a.C : 1;
         if (bn_vec_ok(a))
-            hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
+            hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), bn_stats_blocks())), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
         else
             hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(a.rows, per, 1024)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
@@ -951,7 +956,7 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     const long n = a.K > 0 ? a.rows / a.K : a.rows;
     if (vec) {
         const int rpb = 256 / (a.C / 4);
-        hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
+        hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, bn_stats_blocks())), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
                            a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dy_bf);
         hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(a.rows, rpb, 8192)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg,
                            a.K, a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta, a.dy_bf);
