@@ -407,6 +407,8 @@ typedef struct S3dBnArgs {
                                            * accumulated them, e.g. s3d_group_project_fwd): skip the statistics pass */
     const float* momentum_dev;            /* optional: device-resident momentum (overrides `momentum`), so that a captured HIP graph
                                            * follows the reference's per-epoch BN-momentum decay (train_partseg.py:126-130) */
+    int sums_zeroed;                      /* the caller has zeroed `sums` (e.g. one memset over the statistics of every layer of a model):
+                                           * the library does not enqueue its own 2C-double memset in front of the statistics pass */
 } S3dBnArgs;
 int s3d_batchnorm_fwd(const S3dBnArgs* args, s3d_stream_t stream);
 int s3d_batchnorm_bwd(const S3dBnArgs* args, s3d_stream_t stream);

@@ -915,7 +915,7 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(bn_finalize_kernel, dim3(cblocks), dim3(256), 0, s, a.sums, a.rows, a.C, a.eps, a.momentum, a.mean, a.rstd,
                            a.run_mean, a.run_var, a.momentum_dev);
     } else {
-        (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+        if (!a.sums_zeroed) (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
         const int per = a.C <= 256 ? 256 / a.C : 1;
         if (bn_vec_ok(a))
             hipLaunchKernelGGL(bn_stats_vec_kernel, dim3(grid_for(a.rows, 256 / (a.C / 4), bn_stats_blocks())), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.sums);
@@ -951,7 +951,7 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.dy_bf == nullptr || vec, "batchnorm bwd: a bf16 upstream gradient needs the vector kernels (C %% 4 == 0, aligned rows)");
     S3D_REQUIRE(a.C > 0 && (a.C <= 256 || (a.C <= 1024 && vec)),
                 "batchnorm: C=%d must be in 1..256 (or a multiple of 4 up to 1024 with 16-byte aligned rows)", a.C);
-    (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
+    if (!a.sums_zeroed) (void)hipMemsetAsync(a.sums, 0, 2 * a.C * sizeof(double), s);
     const int per = a.C <= 256 ? 256 / a.C : 1;
     const long n = a.K > 0 ? a.rows / a.K : a.rows;
     if (vec) {

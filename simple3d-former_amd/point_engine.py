@@ -203,24 +203,27 @@ class _BatchNorm:
         self.eng, self.key, self.C = eng, key, C
         self.mean = torch.zeros(C, device=dev); self.rstd = torch.zeros(C, device=dev)
         self.run_mean = torch.zeros(C, device=dev); self.run_var = torch.ones(C, device=dev)
-        self.sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        self.sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)      # forward statistics (re-pointed into the engine's flat block)
+        self.sums_b = torch.zeros(2 * C, dtype=torch.float64, device=dev)    # backward statistics
+        self.prezeroed = False              # the engine zeroes every layer's statistics with one memset per direction
 
     def _args(self, x, rows, K=0, **kw):
         a = self.eng.arena
         return L.fill(L.S3dBnArgs(), x=x, ldx=self.C, rows=rows, C=self.C, K=K, eps=BN_EPS, momentum=self.eng.bn_momentum,
                       momentum_dev=self.eng.hyper[3:4],
                       gamma=a.param(self.key + '.weight'), beta=a.param(self.key + '.bias'), mean=self.mean, rstd=self.rstd,
-                      run_mean=self.run_mean, run_var=self.run_var, sums=self.sums, eval_mode=0 if self.eng.training else 1, **kw)
+                      run_mean=self.run_mean, run_var=self.run_var, eval_mode=0 if self.eng.training else 1,
+                      sums_zeroed=1 if self.prezeroed else 0, **kw)
 
     def fwd(self, x, rows, K=0, **kw):
-        L.check(self.eng.lib.s3d_batchnorm_fwd(ctypes.byref(self._args(x, rows, K, **kw)), L.current_stream()), self.key)
+        L.check(self.eng.lib.s3d_batchnorm_fwd(ctypes.byref(self._args(x, rows, K, sums=self.sums, **kw)), L.current_stream()), self.key)
 
     def bwd(self, x, rows, dy, dx, K=0, arg=None):
         """dy: fp32 or bf16 [rows (or groups)][C] gradient wrt the output"""
         a = self.eng.arena
         gkw = dict(dy_bf=dy) if dy.dtype == torch.bfloat16 else dict(dy=dy)
         args = self._args(x, rows, K, lddy=self.C, dx=dx, lddx=self.C, arg=arg, dgamma=a.grad(self.key + '.weight'),
-                          dbeta=a.grad(self.key + '.bias'), **gkw)
+                          dbeta=a.grad(self.key + '.bias'), sums=self.sums_b, **gkw)
         L.check(self.eng.lib.s3d_batchnorm_bwd(ctypes.byref(args), L.current_stream()), self.key + ' bwd')
 
 
@@ -284,6 +287,17 @@ class PointEngine:
             [t[k] for t in self.tu for k in ('l1', 'l2')] + ([self.head] if self.head else [])
         self.bns = {t[k].key: t[k] for t in self.td for k in ('b0', 'b1')}
         self.bns.update({t[k].key: t[k] for t in self.tu for k in ('b1', 'b2')})
+        # one flat block holds the fp64 statistics of every BatchNorm (forward halves first, then the backward halves): ONE memset at
+        # the start of a training forward / of a backward instead of one per layer and pass (~14 five-microsecond launches per step)
+        n2c = sum(2 * bn.C for bn in self.bns.values())
+        self.bn_sums = torch.zeros(2 * n2c, dtype=torch.float64, device=self.device)
+        off = 0
+        for bn in (self.bns.values() if os.environ.get('S3D_BN_ONE_MEMSET', '1') != '0' else ()):      # =0: a memset per layer and pass
+            bn.sums = self.bn_sums[off:off + 2 * bn.C]
+            bn.sums_b = self.bn_sums[n2c + off:n2c + off + 2 * bn.C]
+            bn.prezeroed = True
+            off += 2 * bn.C
+        self.bn_sums_f, self.bn_sums_b = self.bn_sums[:n2c], self.bn_sums[n2c:]
         # transformer block tables
         self.bparams = (L.S3dBlockParams * self.depth)()
         self.bgrads = (L.S3dBlockGrads * self.depth)()
@@ -458,7 +472,8 @@ class PointEngine:
         own statistics pass over x (0.5 - 0.8 GB per level-0 tensor)."""
         fused = self.training and conv.opad == ch and bool(self.lib.s3d_gemm_col_sums_ok(1 if self.split else 0, int(rows), int(conv.opad)))
         if fused:
-            bn.sums.zero_()
+            if not bn.prezeroed:
+                bn.sums.zero_()
             conv.fwd(planes[0], planes[1], rows, 4, C=x, ldc=ch, col_sums=bn.sums)
         else:
             conv.fwd(planes[0], planes[1], rows, 4, C=x, ldc=ch)
@@ -555,6 +570,8 @@ class PointEngine:
         ws = self.workspace(B)
         lib, s, a, C0, D = self.lib, L.current_stream(), self.arena, self.C0, self.D
         BN = B * N
+        if self.training:
+            self.bn_sums_f.zero_()              # every layer's forward statistics (gather kernel / GEMM epilogue / statistics pass add into them)
         if geometry is None:
             assert len(starts) >= self.levels, f'{self.variant} needs {self.levels} FPS start tensors'
             geometry = ws.geo[0]
@@ -582,7 +599,7 @@ class PointEngine:
                        M=B * t.Nin, N=ch, K=cin_feats, C=t.Pf, ldc=ch, alpha=1.0)
             L.check(lib.s3d_gemm(0, 0, 1 if self.split else 0, 4, ctypes.byref(g), 1, s), 'per-point projection')
             fused = self.training                    # the gather kernel also accumulates the BatchNorm statistics of x1
-            if fused:
+            if fused and not lay['b0'].prezeroed:
                 lay['b0'].sums.zero_()
             L.check(lib.s3d_group_project_fwd(ctypes.byref(gp.args(t, xyz_in, B, Pf=t.Pf, x=t.x1, ldx=ch,
                                                                    sums=lay['b0'].sums if fused else None)), s), 'group_project_fwd')
@@ -665,6 +682,7 @@ class PointEngine:
         ws = self.workspace(B)
         lib, s, a, C0, D, N = self.lib, L.current_stream(), self.arena, self.C0, self.D, self.N
         BN = B * N
+        self.bn_sums_b.zero_()                  # every layer's backward statistics (backward_bottom runs after this call)
         # head
         if self.task == 'cls':
             L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
