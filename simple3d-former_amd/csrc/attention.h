@@ -7,3 +7,4 @@
 typedef S3dAttnArgs AttnArgs;
 int s3d_launch_attention_fwd(const AttnArgs& a, bool split, hipStream_t s);
 int s3d_launch_attention_bwd(const AttnArgs& a, hipStream_t s);
+bool s3d_attention_pairs_packed(const AttnArgs& a);   // lse / delta of this problem use the pair-packed layout (see attention.hip)

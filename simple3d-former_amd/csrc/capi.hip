@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include "attention.h"
+#include "fused_block.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "s3d_hip.h"
@@ -57,14 +58,33 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     const long pd = cls_only ? (long)sh.N * D : D, ph = cls_only ? (long)sh.N * Hd : Hd;
     S3D_REQUIRE(M < (1L << 31), "block: too many rows");
     if (next_ln1_done) *next_ln1_done = false;
-    // 1. norm1
+    // Fused launches (fused_block.hip): norm1 + qkv + attention per (sample pair, head), norm2 + fc1 + GELU per (64-row band, hidden
+    // slice).  Split-bf16 forward of the small-batch shapes only; S3dBlockShape::fuse = -1 keeps the seven-launch sequence.
+    const bool fuse_ok = split && sh.fuse >= 0 && sh.ln_tickets == nullptr && !ln1_done && p.qkv_wp_hi && p.qkv_wp_lo && p.fc1_wp_hi && p.fc1_wp_lo;
+    const bool fuse_attn = fuse_ok && s3d_fused_attn_ok(sh.Bb, sh.N, D, sh.H);
+    const bool fuse_mlp = fuse_ok && !cls_only && s3d_fused_mlp1_ok(M, D, Hd);
     LnArgs ln;
     memset(&ln, 0, sizeof(ln));
-    ln.x = a.x_in; ln.ldx = D; ln.rows = M; ln.D = D; ln.eps = sh.eps; ln.gamma = p.ln1_w; ln.beta = p.ln1_b;
+    ln.D = D; ln.eps = sh.eps;
+    GemmArgs g = gemm_zero();
+    if (fuse_attn) {
+        FusedAttnArgs fa;
+        fa.x = a.x_in; fa.gamma = p.ln1_w; fa.beta = p.ln1_b; fa.eps = sh.eps;
+        fa.w_hi = p.qkv_wp_hi; fa.w_lo = p.qkv_wp_lo; fa.bias = p.qkv_b;
+        fa.xn_hi = a.xn1_hi; fa.xn_lo = a.xn1_lo; fa.mean = a.mean1; fa.rstd = a.rstd1;
+        fa.qkv_hi = a.qkv_hi; fa.att_hi = a.att_hi; fa.att_lo = a.att_lo; fa.lse = a.lse;
+        fa.Bb = sh.Bb; fa.N = sh.N; fa.H = sh.H; fa.scale = 1.0f / sqrtf((float)(D / sh.H));
+        AttnArgs bw;                                                       // the problem as block_bwd will pose it: which lse layout?
+        memset(&bw, 0, sizeof(bw));
+        bw.Bb = sh.Bb; bw.H = sh.H; bw.N = sh.N; bw.D = D; bw.sb = sh.N; bw.st = 1;
+        fa.lse_packed = s3d_attention_pairs_packed(bw) ? 1 : 0;
+        S3D_TRY(s3d_launch_fused_attn(fa, D, s));
+    } else {
+    // 1. norm1
+    ln.x = a.x_in; ln.ldx = D; ln.rows = M; ln.gamma = p.ln1_w; ln.beta = p.ln1_b;
     ln.out_hi = a.xn1_hi; ln.out_lo = split ? a.xn1_lo : nullptr; ln.ldo = D; ln.mean = a.mean1; ln.rstd = a.rstd1;
     if (!ln1_done) S3D_TRY(s3d_launch_ln_fwd(ln, s));
     // 2. qkv = xn1 @ Wqkv^T + b
-    GemmArgs g = gemm_zero();
     g.A_hi = a.xn1_hi; g.A_lo = a.xn1_lo; g.lda = D; g.B_hi = p.qkv_w_hi; g.B_lo = p.qkv_w_lo; g.ldb = D;
     g.M = (int)M; g.N = 3 * D; g.K = D; g.bias = p.qkv_b; g.O_hi = a.qkv_hi; g.O_lo = split ? a.qkv_lo : nullptr; g.ldo = 3 * D;
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_BF16_BIAS, g, 1, s));
@@ -75,6 +95,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
+    }
     // 4. x_mid = x_in + att @ Wproj^T + b   [+ norm2 by the last-arriving tile of every row band]
     g = gemm_zero();
     g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = pd; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D;
@@ -83,6 +104,15 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     g.ln_lo = split ? a.xn2_lo : nullptr; g.ld_ln = D; g.ln_mean = a.mean2; g.ln_rstd = a.rstd2;
     const bool fused2 = s3d_gemm_ln_fusable(split, g);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    if (fuse_mlp) {
+        FusedMlpArgs fm;
+        fm.x = a.x_mid; fm.gamma = p.ln2_w; fm.beta = p.ln2_b; fm.eps = sh.eps;
+        fm.w_hi = p.fc1_wp_hi; fm.w_lo = p.fc1_wp_lo; fm.bias = p.fc1_b;
+        fm.xn_hi = a.xn2_hi; fm.xn_lo = a.xn2_lo; fm.mean = a.mean2; fm.rstd = a.rstd2;
+        fm.hpre = a.hpre; fm.hact_hi = a.hact_hi; fm.hact_lo = a.hact_lo;
+        fm.M = M; fm.hidden = Hd; fm.nslice = Hd / 192;
+        S3D_TRY(s3d_launch_fused_mlp1(fm, D, s));
+    } else {
     // 5. norm2 (stand-alone only when the GEMM could not carry it)
     ln.x = a.x_mid; ln.gamma = p.ln2_w; ln.beta = p.ln2_b; ln.out_hi = a.xn2_hi; ln.out_lo = split ? a.xn2_lo : nullptr;
     ln.mean = a.mean2; ln.rstd = a.rstd2; ln.rows = M2; ln.ldx = pd; ln.ldo = pd;       // cls_only: statistics of class row b at [b]
@@ -93,6 +123,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     g.M = (int)M2; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = ph; g.O_hi = a.hact_hi;
     g.O_lo = split ? a.hact_lo : nullptr; g.ldo = ph;
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_GELU, g, 1, s));
+    }
     // 7. x_out = x_mid + h @ W2^T + b2   [+ the next block's norm1]
     g = gemm_zero();
     g.A_hi = a.hact_hi; g.A_lo = a.hact_lo; g.lda = ph; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd;
@@ -348,7 +379,7 @@ size_t s3d_sizeof(const char* n) {
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dHeadLossArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
-    SZ(S3dGroupProjArgs);
+    SZ(S3dGroupProjArgs); SZ(S3dPackedWeights);
 #undef SZ
     return 0;
 }
@@ -438,15 +469,22 @@ int s3d_image_patchify(const float* img, uint16_t* a_hi, uint16_t* a_lo, long ld
 }
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t s) {
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, nullptr, st(s));
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, nullptr, nullptr, st(s));
 }
 int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
                        S3dAdamState* state, int zero_grad, s3d_stream_t s) {
     S3D_REQUIRE(g_wire != nullptr, "s3d_adam_step_wire: the bf16 gradient buffer is required");
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, st(s));
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, nullptr, st(s));
+}
+int s3d_adam_step_packed(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                         S3dAdamState* state, int zero_grad, const S3dPackedWeights* packed, s3d_stream_t s) {
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, packed, st(s));
 }
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
 
+int s3d_pack_weights(const uint16_t* src_hi, const uint16_t* src_lo, uint16_t* dst_hi, uint16_t* dst_lo, int rows, int K, s3d_stream_t s) {
+    return s3d_launch_pack_weights(src_hi, src_lo, dst_hi, dst_lo, rows, K, st(s));
+}
 int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_block_fwd: null args");
     return block_fwd(*sh, *p, *a, st(s));

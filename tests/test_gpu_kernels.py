@@ -487,6 +487,76 @@ def test_block_fwd_bwd_matches_oracle(D, H, N, Bb):
         assert e < 3e-2, f'{k}: grad rms err {e:.3e}'
 
 
+@pytest.mark.parametrize('D,H,N,Bb,depth', [(384, 6, 26, 64, 3), (384, 6, 26, 5, 2), (192, 3, 10, 3, 2), (192, 3, 10, 4, 2), (192, 3, 32, 2, 1), (384, 6, 1, 7, 1)])
+def test_fused_block_launches_equal_the_seven_launch_sequence(D, H, N, Bb, depth):
+    """s3d_blocks_fwd with S3dBlockShape::fuse = 0 (norm1 + qkv + attention in one launch, norm2 + fc1 + GELU in another) against
+    fuse = -1 (one launch per operator) on the same parameters: the residual stream and EVERY saved activation the backward reads.
+    Same arithmetic (split-bf16 products, fp32 accumulation / LayerNorm / softmax / GELU), different summation order: fp32 values to
+    5e-6 of their scale (hi + lo sums: 2e-5, the resolution of the split), bf16 planes to one bf16 ulp of a few entries; the forward stays bitwise reproducible run to run."""
+    from simple3d_former_amd.engine import ParamArena, _BlockWorkspace
+    g = torch.Generator().manual_seed(11)
+    Hd, M = 4 * D, Bb * N
+    shapes = {}
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        shapes.update({p + 'norm1.weight': (D,), p + 'norm1.bias': (D,), p + 'attn.qkv.weight': (3 * D, D), p + 'attn.qkv.bias': (3 * D,),
+                       p + 'attn.proj.weight': (D, D), p + 'attn.proj.bias': (D,), p + 'norm2.weight': (D,), p + 'norm2.bias': (D,),
+                       p + 'mlp.fc1.weight': (Hd, D), p + 'mlp.fc1.bias': (Hd,), p + 'mlp.fc2.weight': (D, Hd), p + 'mlp.fc2.bias': (D,)})
+    sd = {k: (1 + 0.1 * torch.randn(shp, generator=g)) if ('norm' in k and k.endswith('weight')) else torch.randn(shp, generator=g) * 0.05
+          for k, shp in shapes.items()}
+    arena = ParamArena(shapes, torch.device(DEV)); arena.load(sd); arena.refresh_planes()
+    bp = (L.S3dBlockParams * depth)()
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        L.fill(bp[i], ln1_w=arena.param(p + 'norm1.weight'), ln1_b=arena.param(p + 'norm1.bias'), ln2_w=arena.param(p + 'norm2.weight'),
+               ln2_b=arena.param(p + 'norm2.bias'), qkv_b=arena.param(p + 'attn.qkv.bias'), proj_b=arena.param(p + 'attn.proj.bias'),
+               fc1_b=arena.param(p + 'mlp.fc1.bias'), fc2_b=arena.param(p + 'mlp.fc2.bias'),
+               qkv_w_hi=arena.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=arena.lo_of(p + 'attn.qkv.weight'),
+               proj_w_hi=arena.hi_of(p + 'attn.proj.weight'), proj_w_lo=arena.lo_of(p + 'attn.proj.weight'),
+               fc1_w_hi=arena.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=arena.lo_of(p + 'mlp.fc1.weight'),
+               fc2_w_hi=arena.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=arena.lo_of(p + 'mlp.fc2.weight'),
+               qkv_wp_hi=arena.hi_pk_of(p + 'attn.qkv.weight'), qkv_wp_lo=arena.lo_pk_of(p + 'attn.qkv.weight'),
+               fc1_wp_hi=arena.hi_pk_of(p + 'mlp.fc1.weight'), fc1_wp_lo=arena.lo_pk_of(p + 'mlp.fc1.weight'))
+    x = torch.randn(M, D, generator=g)
+    runs = {}
+    for fuse in (False, True, True):
+        ws = _BlockWorkspace(depth, Bb, N, D, H, Hd, DEV, True, fuse=fuse)
+        for t in (ws.stats, ws.lse, ws.xn1, ws.qkv, ws.att, ws.xn2, ws.hpre, ws.hact):
+            t.fill_(float('nan'))                                       # whatever the backward reads must have been written
+        ws.x[0].copy_(x)
+        L.check(L.lib().s3d_blocks_fwd(ctypes.byref(ws.shape), bp, ws.acts, depth, L.current_stream()), 'blocks_fwd')
+        torch.cuda.synchronize()
+        runs.setdefault(fuse, []).append(ws)
+    ref, (got, again) = runs[False][0], runs[True]
+
+    def close32(a, b, what, rel=5e-6):
+        scale = float(b.abs().max())
+        e = float((a - b).abs().max())
+        assert e <= rel * scale + 1e-7, f'{what}: {e:.3e} of scale {scale:.3e}'
+
+    def close16(a, b, what):                                            # bf16 planes: a rounding boundary may flip by one ulp
+        a, b = a.float(), b.float()
+        assert not torch.isnan(a).any(), f'{what}: not written'
+        e = (a - b).abs()
+        tol = b.abs() * 2.0 ** -7 + 5e-6 * float(b.abs().max())         # one bf16 ulp, or the fp32 difference itself near zero
+        assert bool((e <= tol).all()), f'{what}: max {float(e.max()):.3e}'
+        assert float((e > 0).float().mean()) < 0.02, f'{what}: {float((e > 0).float().mean()):.3%} of the entries differ'
+
+    for i in range(depth):
+        close32(got.x[i + 1], ref.x[i + 1], f'x_out[{i}]')
+        close32(got.x_mid[i], ref.x_mid[i], f'x_mid[{i}]')
+        close32(got.stats[i], ref.stats[i], f'mean / rstd [{i}]')
+        close32(got.lse[i], ref.lse[i], f'lse[{i}]')
+        close16(got.xn1[i, 0], ref.xn1[i, 0], 'xn1_hi'); close16(got.xn2[i, 0], ref.xn2[i, 0], 'xn2_hi')
+        close32(got.xn1[i, 0].float() + got.xn1[i, 1].float(), ref.xn1[i, 0].float() + ref.xn1[i, 1].float(), 'xn1 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close32(got.xn2[i, 0].float() + got.xn2[i, 1].float(), ref.xn2[i, 0].float() + ref.xn2[i, 1].float(), 'xn2 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close16(got.qkv[i, 0], ref.qkv[i, 0], 'qkv_hi'); close16(got.att[i, 0], ref.att[i, 0], 'att_hi')
+        close32(got.att[i, 0].float() + got.att[i, 1].float(), ref.att[i, 0].float() + ref.att[i, 1].float(), 'att hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close16(got.hpre[i], ref.hpre[i], 'hpre'); close16(got.hact[i, 0], ref.hact[i, 0], 'hact_hi')
+        close32(got.hact[i, 0].float() + got.hact[i, 1].float(), ref.hact[i, 0].float() + ref.hact[i, 1].float(), 'hact hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        assert torch.equal(got.x[i + 1], again.x[i + 1]) and torch.equal(got.hact[i], again.hact[i]) and torch.equal(got.att[i], again.att[i])
+
+
 @pytest.mark.parametrize('D,G,Nb', [(192, 27, 4), (768, 40, 15), (384, 50, 6)])
 def test_group_encoder_layer_fwd_bwd_matches_oracle(D, G, Nb):
     """nn.TransformerEncoderLayer(d_model=D, dim_feedforward=D, nhead=4), seq-first as fed at vit_3d_2d_pretrain.py:479,
