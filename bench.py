@@ -21,6 +21,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 with the collectives suppressed and overlap_frac
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -77,6 +78,10 @@ def kernel_name(key):
     (BM|BN|TA|TB|SPLIT|EPI), 2 register-staged dgrad+wgrad pair (BMdgrad|BMwgrad|EPI), 3 LDS-DMA forward kernel, 4 LDS-DMA kernel
     with transpose reads for k-major operands, 6 the dgrad+wgrad pair on that pipeline."""
     kind, b0, b1, tail = _key_fields(key)
+    if kind == 7:
+        return f'blk_attn_kernel<{tail}> (fused norm1 + qkv + attention, split3)'
+    if kind == 8:
+        return f'blk_mlp1_kernel<{tail}> (fused norm2 + fc1 + GELU, split3)'
     epi = EPI_NAMES.get(tail % 100, tail % 100)
     ta, tb, sp = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10
     lay = f'{"T" if ta else "N"}{"T" if not tb else "N"}'
@@ -94,6 +99,8 @@ def kernel_name(key):
 def rocprof_name(key):
     """The same kernel as rocprofv3 prints it (template arguments), for looking it up in profiles/*.json."""
     kind, b0, b1, tail = _key_fields(key)
+    if kind in (7, 8):
+        return f'{"blk_attn_kernel" if kind == 7 else "blk_mlp1_kernel"}<{tail}>'
     tf = lambda v: 'true' if v else 'false'
     ta, tb, sp, epi = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10, tail % 100
     if kind == 2:
@@ -107,22 +114,30 @@ def rocprof_name(key):
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
 
 
+PMC_TRAFFIC_FILE = 'profiles/r03_pmc_step_traffic.json'
+
+
 def pmc_traffic(key):
     """HBM-side bytes per launch of this kernel from the committed PMC passes (tools/pmc_step.sh -> profiles/), or None.
-    bench.py cannot collect PMC counters itself (they need rocprofv3 around the process, one pass per counter group)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_step_traffic.json')
+    bench.py cannot collect PMC counters itself (they need rocprofv3 around the process, one pass per counter group), so the figure
+    is only as fresh as that file: it is matched by the EXACT rocprofv3 kernel name (a changed kernel has a changed template
+    argument list or no entry -> traffic null, never a neighbour's figure), and the line carries the file's hash and the commit /
+    date the passes were taken at."""
+    import hashlib
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)
     try:
-        with open(path) as f:
-            kernels = json.load(f)['kernels']
+        raw = open(path, 'rb').read()
+        doc = json.loads(raw)
+        prov = {'file': PMC_TRAFFIC_FILE, 'sha16': hashlib.sha256(raw).hexdigest()[:16], 'collected_at_head': doc.get('head'),
+                'collected_on': doc.get('date')}
         want = rocprof_name(key)
-        k = kernels.get(want)
-        if k is None:                          # later template parameters (wave grid, loop mode, k-tail) follow the ones named here
-            stem = want[:-1]
-            hits = [n for n in kernels if n.startswith(stem + ',') or n.startswith(stem + '>')]
-            k = kernels[hits[0]] if len(hits) == 1 else None
-        return (k['hbm_bytes_per_launch'], k) if k else (None, None)
+        hits = [n for n in doc['kernels'] if n == want or n.startswith(want + '(')]
+        if len(hits) != 1:
+            return None, None, prov
+        k = doc['kernels'][hits[0]]
+        return k['hbm_bytes_per_launch'], k, prov
     except (OSError, ValueError, KeyError):
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(x, y, budget_s=15.0, pos_embedding='default', dropout=0.0, full_batch=None):
@@ -506,6 +521,8 @@ def main():
     x, y = x_cpu.to(dev), y_cpu.to(dev)
     if conf.get('dropout') and os.environ.get('S3D_BENCH_NO_DROPOUT') != '1':          # (tuning aid: the cost of the dropout masks)
         eng.set_dropout(conf['dropout'], seed=9)                # model.train(): nn.TransformerEncoderLayer(dropout=0.1)
+    # auto: bf16 on the wire when there IS a wire (half the xGMI bytes; bounded against the fp32 wire by the two-rank real-engine
+    # test tests/test_gpu_dp_two_ranks.py::test_bf16_gradient_wire_tracks_the_fp32_wire_over_twenty_steps), fp32 = DDP's arithmetic
     wire = ('bf16' if world > 1 else 'fp32') if args.wire == 'auto' else args.wire
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
                                   force_collectives=args.force_collectives, graph_collectives=args.graph_collectives, wire=wire)
@@ -539,6 +556,8 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    L.lib().s3d_prof_skip_get.restype = ctypes.c_double
+    suppressed = L.lib().s3d_prof_skip_get() != 0.0           # difference timing (roofline leg, below) must not be active in the timed loop
     final_loss = float(loss)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -566,6 +585,7 @@ def main():
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
         'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         'loss_first_step': round(first_loss, 5) if first_loss is not None else None, 'loss_last_step': round(final_loss, 5),
+        'kernels_suppressed': bool(suppressed),
     }
 
     if (world > 1 or args.force_collectives) and not args.no_diagnostics and not args.graph_collectives:
@@ -578,7 +598,7 @@ def main():
         for _ in range(n_inst):
             eng.train_step(x, y)          # engine-only step (no collective): rank-0 kernel timing
         torch.cuda.synchronize()
-        import ctypes
+        pass  # (ctypes: module-level import)
         rows = (ctypes.c_double * (4 * 64))()
         n = lib.s3d_prof_collect(rows, 64)
         lib.s3d_prof_enable(0)
@@ -625,14 +645,15 @@ def main():
             avg_us = dom[2] / dom[1] * 1e3
             achieved = dom[3] / (dom[2] * 1e-3) / 1e12                       # algorithmic TFLOP/s of the dominant kernel
             all_ach = sum(k[3] for k in ks) / (tot_ms * 1e-3) / 1e12
-            traffic, tdetail = pmc_traffic(dom[0])
+            traffic, tdetail, tprov = pmc_traffic(dom[0])
             ev_by_key = {k[0]: k for k in ev}
             out['roofline'] = {
                 'bound': 'mfma', 'kernel': kernel_name(dom[0]), 'achieved': round(achieved, 2), 'peak': MFMA_BF16_PEAK_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 5), 'traffic': traffic,
                 'traffic_unit': 'bytes per launch (memory side of L2: HBM + Infinity Cache)',
-                'traffic_source': ('profiles/r02_pmc_step_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + '
-                                   'WRITE_SIZE, separate passes, ' + rocprof_name(dom[0])) if traffic else None,
+                'traffic_source': ('rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, separate passes; kernel '
+                                   + rocprof_name(dom[0])) if traffic else None,
+                'traffic_provenance': tprov,
                 'traffic_detail': tdetail,
                 'avg_launch_us': round(avg_us, 3), 'timing': method,
                 'avg_launch_us_events': round(ev_by_key[dom[0]][2] / ev_by_key[dom[0]][1] * 1e3, 3),
@@ -654,7 +675,7 @@ def main():
 
     # RCCL writes a version banner to the C stdout of every rank, block-buffered until the process exits -- i.e. AFTER a JSON line
     # printed from Python.  Push it out on every rank first, so that the JSON line is the last thing on stdout.
-    import ctypes
+
     try:
         ctypes.CDLL(None).fflush(None)
     except OSError:

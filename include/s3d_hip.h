@@ -98,6 +98,8 @@ int s3d_prof_event_overhead(s3d_stream_t stream, double* microseconds);
  * suppressed (they return 0 without enqueuing anything).  bench.py captures the training step once with and once without the
  * dominant kernel and takes (t_full - t_without) / launches as that kernel's duration inside the busy, gap-free graph. */
 int s3d_prof_skip(double key);
+/* the key currently suppressed (0 = none): bench.py reads it right behind its timed loop and reports "kernels_suppressed" */
+double s3d_prof_skip_get(void);
 
 /* ------------------------------------------------------------------------------------------------ LayerNorm
  * nn.LayerNorm(eps=1e-6) of timm Block.norm1/.norm2 and VisionTransformer.norm (vit_3d_2d_pretrain.py:287,469). */

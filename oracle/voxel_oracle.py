@@ -126,7 +126,7 @@ def run_blocks(x, sd, depth, num_heads, bf16=False):
 # ----------------------------------------------------------------------------- group_embed
 def hash_keep_mask(shape, seed, site, p):
     """Counter-based dropout mask shared with the HIP kernels (common.h: drop_key / drop_mix32 / drop_keep): element i (row-major
-    linear index) is kept iff mix32(lo(i) + (mix32(hi(i) ^ hi(key)) ^ lo(key))) >= floor(p * 2^32), with
+    linear index) is kept iff mix32((lo(i) ^ (lo(key) * 0x9E3779B9)) + (mix32(hi(i) ^ hi(key)) ^ lo(key))) >= floor(p * 2^32), with
     key = seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019 (mod 2^64) and mix32 two rounds of
     xor-shift / multiply."""
     import numpy as np
@@ -146,7 +146,7 @@ def hash_keep_mask(shape, seed, site, p):
         idx = np.arange(n, dtype=np.uint64)
         lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
         h = mix32(hi ^ key_hi) ^ key_lo
-        z = mix32(lo + h)
+        z = mix32((lo ^ (key_lo * np.uint32(0x9E3779B9))) + h)     # the key is NOT just an additive offset: no shifted-copy masks
     keep = z.astype(np.uint64) >= np.uint64(thr)
     return torch.from_numpy(keep.reshape(tuple(shape)))
 

@@ -1085,15 +1085,15 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
 // One wave per work item.  With few items (cfg-2: 384 = 64 samples x 6 heads) four-wave workgroups would occupy only 96 of the
 // 256 CUs; single-wave workgroups spread them over the chip.  S3D_ATTN_WPB overrides (tuning).
 int waves_per_block(long W) {
-    static const int forced = getenv("S3D_ATTN_WPB") ? atoi(getenv("S3D_ATTN_WPB")) : 0;
+    static const int forced = s3d_tune_int("S3D_ATTN_WPB");
     if (forced == 1 || forced == 2 || forced == 4) return forced;
     return W <= 1024 ? 1 : (W <= 2048 ? 2 : 4);
 }
 
 // Cooperative (shared-stream) kernels pay off once a (batch, head) has enough tiles to stream; S3D_ATTN_COOP=0/1 forces.
 bool use_coop(int N) {
-    static const int env = getenv("S3D_ATTN_COOP") ? atoi(getenv("S3D_ATTN_COOP")) : -1;
-    static const int min_tiles = getenv("S3D_ATTN_COOP_MIN_TILES") ? atoi(getenv("S3D_ATTN_COOP_MIN_TILES")) : 6;
+    static const int env = s3d_tune_int("S3D_ATTN_COOP");
+    static const int min_tiles = s3d_tune_int("S3D_ATTN_COOP_MIN_TILES") > 0 ? s3d_tune_int("S3D_ATTN_COOP_MIN_TILES") : 6;
     if (env == 0) return false;
     return env > 0 || (N + 31) / 32 >= min_tiles;
 }
@@ -1105,7 +1105,7 @@ void set_lds(K kern, int bytes) {
 
 // waves per workgroup of the cooperative long-sequence kernels: S3D_ATTN_COOP_WAVES=4|8
 static int coop_waves() {
-    static const int w = [] { const char* v = getenv("S3D_ATTN_COOP_WAVES"); const int x = v ? atoi(v) : 4; return x == 8 ? 8 : 4; }();
+    static const int w = s3d_tune_int("S3D_ATTN_COOP_WAVES") == 8 ? 8 : 4;
     return w;
 }
 
@@ -1185,8 +1185,8 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
     {
-        static const bool no_small = getenv("S3D_ATTN_NO_SMALL") != nullptr;
-        static const bool no_small_big = getenv("S3D_ATTN_NO_SMALL_BIG") != nullptr;       // hd > 96: back to the two-kernel path
+        static const bool no_small = s3d_tune_int("S3D_ATTN_NO_SMALL") >= 0;
+        static const bool no_small_big = s3d_tune_int("S3D_ATTN_NO_SMALL_BIG") >= 0;       // hd > 96: back to the two-kernel path
         if (a.N <= 32 && !no_small && (HD <= 96 || !no_small_big)) {
             constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;
             constexpr int MAXW = (160 * 1024) / WAVE_LDS >= 4 ? 4 : (160 * 1024) / WAVE_LDS;      // 3 waves per workgroup at hd = 256
@@ -1261,7 +1261,7 @@ int check(const AttnArgs& a) {
 // latency.  When consecutive batch entries are contiguous in memory (sb == N * st), the pair (2b, 2b+1) IS a 2N-token
 // sequence; the block-diagonal mask (seg = N) keeps the two apart.  Half the waves, the same bytes.  S3D_ATTN_PACK=0 disables.
 AttnArgs pack_pairs(const AttnArgs& a) {
-    static const int on = getenv("S3D_ATTN_PACK") ? atoi(getenv("S3D_ATTN_PACK")) : 1;
+    static const int on = s3d_tune_int("S3D_ATTN_PACK");                    // 0 disables (tuning builds)
     if (on == 0 || a.seg != 0 || a.N > 16 || (a.Bb & 1) || a.sb != (long)a.N * a.st || a.drop_thr) return a;
     AttnArgs b = a;
     b.Bb = a.Bb / 2;

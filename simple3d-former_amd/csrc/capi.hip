@@ -171,7 +171,7 @@ struct BwdStreams {
 };
 BwdStreams g_bwd_streams;
 bool bwd_streams_enabled() {
-    static const int on = [] { const char* v = getenv("S3D_BWD_STREAMS"); return v ? atoi(v) : 0; }();
+    static const int on = s3d_tune_int("S3D_BWD_STREAMS");                  // measured and rejected: tuning builds only
     return on > 0;
 }
 // dgrad on `s`, wgrad on the side stream once everything `s` has enqueued so far (i.e. dy) is complete
@@ -390,6 +390,7 @@ int s3d_get_deterministic(void) { return s3d_deterministic() ? 1 : 0; }
 int s3d_prof_enable(int on) { s3d_gemm_prof_enable(on != 0); return 0; }
 int s3d_prof_collect(double* rows, int cap) { return s3d_gemm_prof_collect(rows, cap); }
 int s3d_prof_skip(double key) { s3d_gemm_prof_skip((long long)key); return 0; }
+double s3d_prof_skip_get(void) { return (double)s3d_gemm_prof_skip_get(); }
 int s3d_prof_event_overhead(s3d_stream_t stream, double* us) {
     S3D_REQUIRE(us != nullptr, "s3d_prof_event_overhead: null result pointer");
     constexpr int R = 33;
@@ -410,8 +411,8 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int split
     return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));
 }
 int s3d_gemm_col_sums_ok(int split, int M, int N) {
-    static const bool forced = getenv("S3D_GEMM_NT_TILE") != nullptr && atoi(getenv("S3D_GEMM_NT_TILE")) >= 0;
-    static const bool off = getenv("S3D_GEMM_COL_SUMS") != nullptr && atoi(getenv("S3D_GEMM_COL_SUMS")) == 0;
+    static const bool forced = s3d_tune_int("S3D_GEMM_NT_TILE") >= 0;
+    static const bool off = s3d_tune_int("S3D_GEMM_COL_SUMS") == 0;
     return (!forced && !off && M > 0 && N > 0 && (N & 7) == 0 && s3d_gemm_pick_tile(M, N, 1, split != 0) == 2) ? 1 : 0;
 }
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* a) { return (a != nullptr && s3d_gemm_ln_fusable(split != 0, *a)) ? 1 : 0; }

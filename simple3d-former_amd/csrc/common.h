@@ -113,25 +113,46 @@ __device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x21f0aaadu; x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
     return x;
 }
+// The key enters twice: xor-ed into the low index word BEFORE the add of the (keyed) high-word hash -- with a purely additive key the
+// masks of two seeds / sites / ranks are shifted copies of one 2^32-periodic sequence (mask_k'(i) == mask_k(i + delta)), and windows of
+// ~1.5e8 elements from different steps overlap with a probability of a few per cent.  Same instruction count (the xor replaces nothing
+// on the hoisted path: lo ^ klo is formed once per row in DropRow).
 __device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long long idx, unsigned thr) {
-    const uint32_t hi = drop_mix32((uint32_t)(idx >> 32) ^ (uint32_t)(key >> 32)) ^ (uint32_t)key;   // changes every 2^32 elements
-    return drop_mix32((uint32_t)idx + hi) >= thr;        // lowbias32 avalanches consecutive integers by itself: no pre-multiply (a quarter-rate op)
+    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+    const uint32_t hi = drop_mix32((uint32_t)(idx >> 32) ^ khi) ^ klo;   // changes every 2^32 elements
+    return drop_mix32(((uint32_t)idx ^ (klo * 0x9E3779B9u)) + hi) >= thr;   // lowbias32 avalanches consecutive integers by itself
 }
 
 // The same mask for element (base + off), off < 2^32, with the 64-bit part hoisted: the long-sequence attention kernels evaluate the
 // mask (196 B)^2 * 60 times per pass, and a 64-bit multiply-add per element to form the index cost more than the hash itself.
-struct DropRow { uint32_t lo, mix_a, mix_b; };
+struct DropRow { uint32_t lo, mix_a, mix_b, kx; };
 __device__ __forceinline__ DropRow drop_row(unsigned long long key, unsigned long long base) {
     const uint32_t hi = (uint32_t)(base >> 32), khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
-    return DropRow{(uint32_t)base, drop_mix32(hi ^ khi) ^ klo, drop_mix32((hi + 1u) ^ khi) ^ klo};
+    return DropRow{(uint32_t)base, drop_mix32(hi ^ khi) ^ klo, drop_mix32((hi + 1u) ^ khi) ^ klo, klo * 0x9E3779B9u};
 }
 __device__ __forceinline__ bool drop_keep_at(const DropRow& r, uint32_t off, unsigned thr) {
     const uint32_t lo = r.lo + off;
-    return drop_mix32(lo + (lo < r.lo ? r.mix_b : r.mix_a)) >= thr;                    // lo < r.lo: the add carried into the high word
+    return drop_mix32((lo ^ r.kx) + (lo < r.lo ? r.mix_b : r.mix_a)) >= thr;           // lo < r.lo: the add carried into the high word
 }
 
 // fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// Element counts up to which a grid-stride loop may keep a 32-bit induction variable (`unsigned i; i += gridDim.x * blockDim.x`): the
+// increment past the last element must not wrap, and the launchers use at most 2^13 workgroups of 2^8 threads (stride <= 2^21).
+#define S3D_U32_LOOP_MAX ((1L << 32) - (1L << 22))
+
+// ---- tuning knobs ----
+// Tile / ring-depth / dispatch overrides (the experiments measured and rejected in DESIGN.md section 6, tools/gemm_bench.py ...) exist
+// only in the tuning builds (make EXP=1 / TL=1): there s3d_tune_int(name) = atoi(getenv(name)), -1 when unset.  In the product library
+// it is the constant -1 and every knob branch folds away; the only environment variable the product library reads is
+// S3D_DETERMINISTIC (capi.hip), the documented parity mode.
+#ifdef S3D_EXPERIMENTAL_TILES
+#include <stdlib.h>
+static inline int s3d_tune_int(const char* name) { const char* v = getenv(name); return v ? atoi(v) : -1; }
+#else
+static inline int s3d_tune_int(const char*) { return -1; }
+#endif
 
 // ---- host-side error plumbing (capi.hip owns the storage) ----
 void s3d_set_error(const char* fmt, ...);

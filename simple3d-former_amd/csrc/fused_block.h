@@ -22,6 +22,7 @@ struct FusedMlpArgs {
     float* mean; float* rstd;             // out: [M]
     bf16_t* hpre; bf16_t* hact_hi; bf16_t* hact_lo;        // out: [M][hidden]
     long M; int hidden, nslice;           // nslice = hidden / 192
+    int band_rows;                        // filled by the launcher: token rows per workgroup (<= 64)
 };
 bool s3d_fused_attn_ok(int Bb, int N, int D, int H);
 bool s3d_fused_mlp1_ok(long M, int D, int hidden);

@@ -34,6 +34,7 @@
 #include "fused_block.h"
 
 #include "attn_frag.h"
+#include "gemm.h"
 #include "dma_tile.h"
 
 #include <type_traits>
@@ -95,8 +96,9 @@ __device__ __forceinline__ void ln_gemm_64x192(const Rows rows, const float* x, 
                                                const long wrow1, const long wrow2, bf16_t* xn_hi, bf16_t* xn_lo, const int kp_store,
                                                unsigned char* smem, f32x4 (&acc)[4][3]) {
     constexpr int KP = D / 64;                                             // 64-wide k-slabs
-    constexpr int PS = KP < 2 ? KP : 2;                                    // slabs of weight fragments in flight ahead of their use (48 registers each:
-                                                                           // with three the compiler runs out of its 256 VGPRs and sinks the loads to their uses)
+    // slabs of weight fragments in flight ahead of their use (48 registers each): two while the residual rows occupy 96 + 48 registers,
+    // three from the end of the LayerNorm phase on (the main loop runs at the rate the fragments arrive: 30 B/clk/CU with two)
+    constexpr int PS0 = KP < 2 ? KP : 2, PS = KP < 3 ? KP : 3;
     static_assert(D % 64 == 0, "model dimension");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -141,9 +143,9 @@ __device__ __forceinline__ void ln_gemm_64x192(const Rows rows, const float* x, 
 #pragma unroll
                 for (int q = 0; q < 2; ++q) bw[kp][pl][j][q] = *reinterpret_cast<const bf16x8*>(wp[pl][j] + (2 * kp + q) * 512);
     };
-    if constexpr (PS > 0) fetch(std::integral_constant<int, 0>{});
-    if constexpr (PS > 1) fetch(std::integral_constant<int, 1>{});
-    if constexpr (PS > 2) fetch(std::integral_constant<int, 2>{});
+    if constexpr (PS0 > 0) fetch(std::integral_constant<int, 0>{});
+    if constexpr (PS0 > 1) fetch(std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- the whole A operand: slab j = [hi plane [64][64]][lo plane], 128-byte rows, 16-byte chunk c at slot c ^ dma_swz64(row):
     // k-step q reads chunks 4 q + (lane >> 4) exactly like the DMA GEMM tiles (conflict-free, dma_tile.h)
@@ -182,6 +184,11 @@ __device__ __forceinline__ void ln_gemm_64x192(const Rows rows, const float* x, 
         }
     }
     FB_STAMP(1);
+    if constexpr (PS > PS0) {
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(std::integral_constant<int, PS0>{});
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -388,20 +395,21 @@ template <int D>
 __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nband = (int)((p.M + FB_ROWS - 1) / FB_ROWS);
+    const int RB = p.band_rows;                                            // token rows per band (<= 64)
+    const int nband = (int)((p.M + RB - 1) / RB);
     const int item = xcd_item(blockIdx.x, nband * p.nslice);
     const int js = item / nband, band = item % nband;                      // slice-major: the bands of a slice share an XCD
-    const long m0 = (long)band * FB_ROWS;
+    const long m0 = (long)band * RB;
     struct Rows {
-        long m0, M;
-        __device__ __forceinline__ long grow(int r) const { return min(m0 + r, M - 1); }
-        __device__ __forceinline__ bool ok(int r) const { return m0 + r < M; }
+        long m0, M; int RB;
+        __device__ __forceinline__ long grow(int r) const { return min(m0 + min(r, RB - 1), M - 1); }
+        __device__ __forceinline__ bool ok(int r) const { return r < RB && m0 + r < M; }
     };
     f32x4 acc[4][3];
     constexpr int FB_KERNEL_ID = 1;
     const long w0 = (long)FB_WROWS * js;
     const bool st = js < D / 64;                                           // slices 0 .. D / 64 - 1 store one 64-column slab of xn2 each
-    ln_gemm_64x192<D, 1>(Rows{m0, p.M}, p.x, p.gamma, p.beta, p.eps, js == 0 ? p.mean : nullptr, p.rstd, p.w_hi, p.w_lo, w0, w0 + 64,
+    ln_gemm_64x192<D, 1>(Rows{m0, p.M, RB}, p.x, p.gamma, p.beta, p.eps, js == 0 ? p.mean : nullptr, p.rstd, p.w_hi, p.w_lo, w0, w0 + 64,
                          w0 + 128, st ? p.xn_hi : nullptr, p.xn_lo, js, smem, acc);
 
     // ---- epilogue: pre = acc + b1 -> bf16; gelu(pre) -> split planes; staged over the (consumed) A operand for 16-byte row stores
@@ -432,7 +440,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
     for (int i = 0; i < 18; ++i) {
         const int e = tid + FB_THREADS * i;                                // 3 arrays x 64 rows x 24 chunks of 16 bytes
         const int arr = e / (FB_ROWS * 24), rc = e % (FB_ROWS * 24), r = rc / 24, ch = rc % 24;
-        if (m0 + r < p.M) {
+        if (r < RB && m0 + r < p.M) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + arr * TILE + (r * H_PITCH + 8 * ch) * 2);
             bf16_t* const out = arr == 0 ? p.hpre : arr == 1 ? p.hact_hi : p.hact_lo;
             *reinterpret_cast<u32x4*>(out + (m0 + r) * p.hidden + FB_WROWS * js + 8 * ch) = v;
@@ -474,7 +482,12 @@ int launch_attn(const FusedAttnArgs& a, hipStream_t s) {
     static const int once = set_lds(blk_attn_kernel<D>, LDS);
     (void)once;
     const int grid = ((a.Bb + 1) / 2) * a.H;
+    constexpr long long KEY = 700000000000LL + D;                          // bench.py: 7 = fused norm1 + qkv + attention
+    if (s3d_prof_skipped(KEY)) return 0;
+    const double M = (double)a.Bb * a.N;
+    s3d_prof_begin(KEY, 2.0 * M * 3 * D * D + 4.0 * a.Bb * a.N * a.N * D, s);       // qkv GEMM + (q k^T, p v) of every head
     hipLaunchKernelGGL((blk_attn_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
+    s3d_prof_end(s);
     S3D_CHECK_LAUNCH("blk_attn");
     return 0;
 }
@@ -484,8 +497,12 @@ int launch_mlp1(const FusedMlpArgs& a, hipStream_t s) {
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static const int once = set_lds(blk_mlp1_kernel<D>, LDS);
     (void)once;
-    const int grid = (int)((a.M + FB_ROWS - 1) / FB_ROWS) * a.nslice;
+    const int grid = (int)((a.M + a.band_rows - 1) / a.band_rows) * a.nslice;
+    constexpr long long KEY = 800000000000LL + D;                          // bench.py: 8 = fused norm2 + fc1 + GELU
+    if (s3d_prof_skipped(KEY)) return 0;
+    s3d_prof_begin(KEY, 2.0 * (double)a.M * a.hidden * D, s);
     hipLaunchKernelGGL((blk_mlp1_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
+    s3d_prof_end(s);
     S3D_CHECK_LAUNCH("blk_mlp1");
     return 0;
 }
@@ -514,7 +531,17 @@ int s3d_launch_fused_attn(const FusedAttnArgs& a, int D, hipStream_t s) {
     S3D_REQUIRE(s3d_fused_attn_ok(a.Bb, a.N, D, a.H), "fused attention block: unsupported shape Bb=%d N=%d D=%d H=%d", a.Bb, a.N, D, a.H);
     return D == 192 ? launch_attn<192>(a, s) : launch_attn<384>(a, s);
 }
-int s3d_launch_fused_mlp1(const FusedMlpArgs& a, int D, hipStream_t s) {
+int s3d_launch_fused_mlp1(const FusedMlpArgs& a_in, int D, hipStream_t s) {
+    FusedMlpArgs a = a_in;
+    // Rows per band: 64 fill the MFMA tile; but when 64-row bands leave CUs without a workgroup, thinner bands on all 256 CUs shorten
+    // every workgroup's row-proportional phases (loads, LayerNorm, GELU, stores).  cfg-2: 1664 rows x 8 slices = 208 workgroups of 64 rows
+    // -> 256 of 52 (= two samples).
+    a.band_rows = FB_ROWS;
+    if (a.nslice > 0 && a.nslice <= 256) {
+        const long full = (a.M + FB_ROWS - 1) / FB_ROWS, fit = 256 / a.nslice;
+        if (full < fit) a.band_rows = (int)((a.M + fit - 1) / fit);
+        if (a.band_rows < 16) a.band_rows = 16;
+    }
     S3D_REQUIRE(s3d_fused_mlp1_ok(a.M, D, a.hidden) && a.nslice * FB_WROWS == a.hidden, "fused mlp block: unsupported shape M=%ld D=%d hidden=%d", a.M, D,
                 a.hidden);
     return D == 192 ? launch_mlp1<192>(a, s) : launch_mlp1<384>(a, s);

@@ -31,3 +31,8 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad
 void s3d_gemm_prof_enable(bool on);
 int s3d_gemm_prof_collect(double* rows, int cap);
 void s3d_gemm_prof_skip(long long key);
+long long s3d_gemm_prof_skip_get();
+// ... and for launches outside gemm.hip: skipped? / events around the launch when profiling is enabled
+bool s3d_prof_skipped(long long key);
+void s3d_prof_begin(long long key, double flops, hipStream_t s);
+void s3d_prof_end(hipStream_t s);

@@ -25,10 +25,7 @@
 
 // ---- optional per-launch timing (bench.py's roofline leg): HIP events around every GEMM launch, keyed by kernel
 // instantiation.  Off by default; never active during graph capture.
-static int env_int(const char* name) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : -1;
-}
+static int env_int(const char* name) { return s3d_tune_int(name); }   // tuning builds only, see common.h
 
 // token rows from which a GEMM counts as "long" (fat forward / backward tiles, 128x128 split-K wgrads): S3D_GEMM_LONG_ROWS
 static int long_rows() {
@@ -43,6 +40,20 @@ std::vector<ProfSlot> g_prof;
 long long g_skip_key = 0;      // bench.py's difference timing: launches of this kernel instantiation are suppressed
 }  // namespace
 void s3d_gemm_prof_skip(long long key) { g_skip_key = key; }
+long long s3d_gemm_prof_skip_get() { return g_skip_key; }
+// the same bookkeeping for launches outside this file (fused_block.hip)
+bool s3d_prof_skipped(long long key) { return g_skip_key == key; }
+void s3d_prof_begin(long long key, double flops, hipStream_t s) {
+    if (!g_prof_on) return;
+    ProfSlot sl;
+    sl.key = key; sl.flops = flops;
+    (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+    (void)hipEventRecord(sl.e0, s);
+    g_prof.push_back(sl);
+}
+void s3d_prof_end(hipStream_t s) {
+    if (g_prof_on && !g_prof.empty()) (void)hipEventRecord(g_prof.back().e1, s);
+}
 void s3d_gemm_prof_enable(bool on) {
     if (on) { for (auto& sl : g_prof) { (void)hipEventDestroy(sl.e0); (void)hipEventDestroy(sl.e1); } g_prof.clear(); }
     g_prof_on = on;

@@ -205,7 +205,7 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
         else if (a.D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a); \
         else hipLaunchKernelGGL((ln_bwd_kernel<RPW, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a);                 \
     } while (0)
-    static const int forced_rpw = getenv("S3D_LN_RPW") ? atoi(getenv("S3D_LN_RPW")) : 0;      // tuning override
+    static const int forced_rpw = s3d_tune_int("S3D_LN_RPW") > 0 ? s3d_tune_int("S3D_LN_RPW") : 0;      // tuning builds only
     const int rpw = forced_rpw ? forced_rpw : (per_wave >= 3 ? 4 : per_wave == 2 ? 2 : 1);
     if (rpw >= 4) S3D_LN_BWD(4);
     else if (rpw == 2) S3D_LN_BWD(2);

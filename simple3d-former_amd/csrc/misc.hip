@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64) void posgrad_det_kernel(const PosGradArgs p) {
 __global__ void assemble_tokens_kernel(const float* __restrict__ src, const float* __restrict__ cls,
                                        const float* __restrict__ pos, float* __restrict__ out, long B, int n, int D) {
     const long total = B * (n + 1) * (long)(D / 4);
-    if (total < (1L << 32)) {                                   // 32-bit index arithmetic (two 64-bit divisions per float4 otherwise)
+    if (total < S3D_U32_LOOP_MAX) {                                   // 32-bit index arithmetic (two 64-bit divisions per float4 otherwise)
         const unsigned q = (unsigned)D / 4, n1 = (unsigned)n + 1;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
             const unsigned row = i / q, d4 = i - row * q, b = row / n1, t = row - b * n1;
@@ -158,7 +158,7 @@ __global__ void assemble_tokens_kernel(const float* __restrict__ src, const floa
 }
 __global__ void assemble_tokens_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dsrc, long B, int n, int D) {
     const long total = B * n * (long)(D / 4);
-    if (total < (1L << 32)) {
+    if (total < S3D_U32_LOOP_MAX) {
         const unsigned q = (unsigned)D / 4, un = (unsigned)n;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
             const unsigned row = i / q, d4 = i - row * q, b = row / un, j = row - b * un;

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void interp3_vec_kernel(const float* __restric
 __global__ void interp3_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ idx, const float* __restrict__ w, int S,
                                    int N, int C, long rows, float* __restrict__ df1) {
     const long total = rows * C;
-    if (total < (1L << 32)) {                                  // 32-bit index arithmetic (a 64-bit division is ~3x the instructions)
+    if (total < S3D_U32_LOOP_MAX) {                                  // 32-bit index arithmetic (a 64-bit division is ~3x the instructions)
         const unsigned uC = (unsigned)C, uN = (unsigned)N;
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
             const unsigned r = i / uC, c = i - r * uC, b = r / uN;
@@ -807,7 +807,7 @@ __global__ void bump_kernel(int* c) { *c += 1; }
 
 // workgroups of the BatchNorm statistics passes (each ends in 2C fp64 atomics): S3D_BN_STATS_BLOCKS
 static long bn_stats_blocks() {
-    static const long v = getenv("S3D_BN_STATS_BLOCKS") ? atol(getenv("S3D_BN_STATS_BLOCKS")) : 1024;
+    static const long v = s3d_tune_int("S3D_BN_STATS_BLOCKS");              // tuning builds only; 1024 measured best
     return v > 0 ? v : 1024;
 }
 inline unsigned grid_for(long n, int per = 256, long cap = 8192) {
@@ -864,7 +864,7 @@ int s3d_launch_group_scatter(const float* dA, int ldd, const int* idx, int B, in
 }
 // vector kernels: 4 | C, C/4 <= 256 lanes, 16-byte aligned rows
 static bool bn_vec_ok(const S3dBnArgs& a) {
-    static const bool off = getenv("S3D_BN_SCALAR") != nullptr;
+    static const bool off = s3d_tune_int("S3D_BN_SCALAR") >= 0;
     return !off && a.C % 4 == 0 && a.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(a.x) & 15) == 0;
 }
 static bool al(const void* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
@@ -973,7 +973,7 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
 int s3d_launch_interp3(const float* f1, int S, const float* f2, const int* idx, const float* w, int B, int N, int C, float* out,
                        hipStream_t s) {
     const long rows = (long)B * N;
-    if (C % 4 == 0 && rows * (C / 4) < (1L << 32) && al(f1, 16) && al(f2, 16) && al(out, 16)) {
+    if (C % 4 == 0 && rows * (C / 4) < S3D_U32_LOOP_MAX && al(f1, 16) && al(f2, 16) && al(out, 16)) {
         hipLaunchKernelGGL(interp3_vec_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, s, f1, S, f2, idx, w, N, C, (unsigned)rows, out);
         S3D_CHECK_LAUNCH("interp3");
         return 0;
@@ -1000,7 +1000,7 @@ int s3d_launch_bcast_rows(const float* x, int N, int C, long rows, float scale, 
     return 0;
 }
 int s3d_launch_pack_rows(const float* x, int C, int ldx, long rows, bf16_t* hi, bf16_t* lo, int ldo, hipStream_t s) {
-    if (C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && rows * (ldo / 4) < (1L << 32) && al(x, 16) && al(hi, 8) && al(lo, 8)) {
+    if (C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && rows * (ldo / 4) < S3D_U32_LOOP_MAX && al(x, 16) && al(hi, 8) && al(lo, 8)) {
         hipLaunchKernelGGL(pack_rows_vec_kernel, dim3(grid_for(rows * (ldo / 4))), dim3(256), 0, s, x, C, ldx, (unsigned)rows, hi, lo, ldo);
         S3D_CHECK_LAUNCH("pack_rows");
         return 0;

@@ -402,12 +402,12 @@ class VoxelEngine:
     def set_dropout(self, p, seed=None):
         """Dropout of nn.TransformerEncoderLayer inside group_embed (vit_3d_2d_pretrain.py:381; p = 0.1 when model.train()).
         The seed lives on the device and is advanced once per training step (advance_dropout_seed).  The probability is a
-        launch argument, i.e. baked into captured graphs: changing it drops this engine's graphs and bumps capture_epoch so that
-        trainers holding their own captures re-capture."""
+        launch argument, i.e. baked into captured graphs: this engine's graph cache is keyed by it (toggling train / eval re-uses
+        both captures) and capture_epoch is bumped so that trainers holding their own captures re-capture."""
         p = float(p)
         if p != self.dropout_p:
-            self._graphs.clear()
-            self.capture_epoch += 1
+            self.capture_epoch += 1           # trainers holding their own captures re-capture; this engine's cache is keyed by p
+
         self.dropout_p = p
         if seed is not None:
             self.dropout_seed.fill_(int(seed))
@@ -577,8 +577,13 @@ class VoxelEngine:
         """head backward + final-norm backward: leaves d(loss)/d(x_final) in the scratch ping-pong buffer."""
         ws = self.workspace(B)
         lib, s, a, D = self.lib, L.current_stream(), self.arena, self.D
-        if getattr(self, '_loss_end_done', False) and dlogits is None:
-            self._loss_end_done = False          # head_loss() already produced d(loss)/d(x_final) and the head / norm gradients
+        if getattr(self, '_loss_end_done', False):
+            # head_loss() already produced d(loss)/d(x_final) AND accumulated the head / final-norm gradients: a second head backward
+            # from caller-supplied d(logits) would add them twice
+            self._loss_end_done = False
+            if dlogits is not None:
+                raise RuntimeError('backward(dlogits=...) after forward_loss(): the fused loss end has already accumulated the head and '
+                                   'final-norm gradients; call forward() + cross_entropy() when you want to supply d(logits) yourself')
             return ws
         if dlogits is not None and dlogits.data_ptr() != ws.dlogits.data_ptr():
             ws.dlogits.copy_(dlogits)
@@ -717,8 +722,10 @@ class VoxelEngine:
         return loss
 
     def forward_loss(self, x, target, weight=None):
-        """model(voxel) + F.cross_entropy for a training step; with the Linear head the loss end runs fused (head_loss)."""
-        if self.am or not FUSE_LOSS_END:
+        """model(voxel) + F.cross_entropy for a TRAINING step; with the Linear head (C <= 256, D <= 1024) the loss end runs fused
+        (head_loss): the head / final-norm gradients are accumulated right here, so follow it with exactly one backward() (no
+        dlogits) -- for inference or custom d(logits) use forward() + cross_entropy()."""
+        if self.am or not FUSE_LOSS_END or self.C > 256 or self.D > 1024:     # s3d_head_loss_fused: Linear head, C <= 256, D <= 1024
             self.forward(x)
             return self.cross_entropy(x.shape[0], target, weight)
         self.forward_features(x)
@@ -742,7 +749,7 @@ class VoxelEngine:
 
     def capture_train_step(self, B, weight=None):
         """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""
-        key = (B, None if weight is None else weight.data_ptr())
+        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p)     # model.train() / .eval() toggles keep both captures
         if key in self._graphs:
             return self._graphs[key]
         sx = torch.zeros(B, 1, self.V, self.V, self.V, dtype=torch.float32, device=self.device)

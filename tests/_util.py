@@ -47,8 +47,11 @@ def check_grads_against_golden(z, grads, rtol, atol, names=None, skip=()):
     60*rtol -- the error of a plain-bf16 backward is noise with sigma ~ the rms bound, and the largest of 4096 draws sits at
     ~4.1 sigma, i.e. AT 40*rtol when the rms error is at its own bound (observed: 0.118 .. 0.135 of the gradient rms on the
     n = 1024 / 2048 point fixtures, with either formulation of the set-abstraction backward).  The ~100 sampled entries get
-    50*rtol: the first layer's weight gradient (fc1.0.weight, every error of the backward pass summed over B*N rows by
-    split-K atomics, so it moves from run to run) was seen between 0.09 and 0.126 of the gradient rms on the same build."""
+    50*rtol.  ADVICE r02 asked whether that allowance covers atomic-order noise or the bf16 rounding of dy1 in the TransitionDown
+    backward: the point goldens now run in deterministic mode (tests/test_gpu_points.py: deterministic_reductions) and the first
+    layer's weight gradient (fc1.0.weight of pts_seg_tiny_n2048_b1, every error of the backward pass summed over B*N rows) still
+    sits at 0.128 of the gradient rms there -- it is rounding of the bf16 backward operands, not run-to-run noise, so 40*rtol
+    (0.12) is simply below what a plain-bf16 backward delivers on that tensor."""
     gold_names = json.loads(str(z['grad_names']))
     worst = 0.0
     for k in (names or gold_names):

@@ -126,8 +126,19 @@ def test_gather_scatter_interp():
     assert rel_err(out.view(B, N, C), ref_out) < 1e-5
 
 
+@pytest.fixture
+def deterministic_reductions():
+    """Gradient parity against the reference goldens runs without split-K / atomic-order noise (s3d_set_deterministic): the error
+    that is left is the bf16 rounding of the backward operands, so the bars need no allowance for run-to-run variation."""
+    lib = L.lib()
+    was = lib.s3d_get_deterministic()
+    lib.s3d_set_deterministic(1)
+    yield
+    lib.s3d_set_deterministic(was)
+
+
 @pytest.mark.parametrize('name', POINT_CASES)
-def test_point_engine_matches_reference_golden(name):
+def test_point_engine_matches_reference_golden(name, deterministic_reductions):
     z, cfg, sd, x, y, starts = load_point_case(name)
     eng = PointEngine(backbone=cfg['backbone'], n_points=cfg['n_points'], d_points=cfg['d_points'], n_classes=cfg['n_classes'],
                       task=cfg['task'], device=DEV)
