@@ -483,6 +483,9 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
     ap.add_argument('--wire', choices=['auto', 'fp32', 'bf16'], default='auto',
                     help="gradient all-reduce format: fp32 (DDP's arithmetic) or bf16 (half the xGMI bytes); auto = bf16 when N > 1")
+    ap.add_argument('--event-graph', action='store_true',
+                    help='ONE graph with an event-record node behind every backward segment, collectives launched from a side stream on '
+                         'those events (measured slower than the default on this runtime: one graph per segment, collectives in between)')
     ap.add_argument('--no-diagnostics', action='store_true', help='skip the per-bucket all-reduce / overlap measurement at N > 1')
     ap.add_argument('--no-pipeline', action='store_true',
                     help='point configs: FPS / kNN inside the step instead of one step ahead on the side stream (the default)')
@@ -525,7 +528,8 @@ def main():
     # test tests/test_gpu_dp_two_ranks.py::test_bf16_gradient_wire_tracks_the_fp32_wire_over_twenty_steps), fp32 = DDP's arithmetic
     wire = ('bf16' if world > 1 else 'fp32') if args.wire == 'auto' else args.wire
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
-                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives, wire=wire)
+                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives, wire=wire,
+                                  event_graph=args.event_graph)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
     ident = rccl_identity(dev, world)
     if world > 1:
@@ -579,8 +583,7 @@ def main():
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
                    'grad_buckets': len(trainer.slices), 'grad_wire': wire,
-                   'collectives': ('none' if not (world > 1 or args.force_collectives) else 'captured in the step graph'
-                                   if args.graph_collectives else 'host-launched between graph segments')},
+                   'collectives': trainer.collectives_mode()},
         'rccl_ranks': ident['rccl_ranks'], 'distinct_devices': ident['distinct_devices'], 'dist_backend': ident['backend'],
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
         'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),

@@ -260,6 +260,23 @@ int s3d_adam_step_packed(float* p, float* g, const uint16_t* g_wire, float* m, f
 int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
                        S3dAdamState* state, int zero_grad, s3d_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ mid-graph events for data parallelism
+ * DDP (train_cls_voxel.py:155-159, :287) all-reduces gradient buckets while backward is still running.  With HIP graphs that used to
+ * mean one graph per backward segment and a host-launched RCCL call in between -- every graph boundary drains the device queue
+ * (DESIGN.md section 7).  Here the whole step is captured as ONE flat graph with a marker (s3d_graph_marker) behind every backward
+ * segment; s3d_graph_events_at_markers then replaces marker k of the captured hipGraph_t (e.g. torch.cuda.CUDAGraph(keep_graph=True)
+ * .raw_cuda_graph(), before its first replay) by an event-record node of events[k], in line.  The host launches the graph once and,
+ * per bucket, makes the stream it issues the collective from wait for the event behind "its" segment (s3d_stream_wait_event, called
+ * after the graph launch: it sees the record that replay is going to perform).  The collective overlaps the later segments, no
+ * collective is inside a graph (no hang risk with real peers), and the compute stream runs the whole backward without a boundary.
+ * PyTorch's Event API refuses external events inside its captures (tools/probes/external_event_probe.py) and so does
+ * hipEventRecordWithFlags(hipEventRecordExternal) in the runtime it bundles; the edited graph works (tools/probes/step_graph_probe.py). */
+int s3d_event_create(void** event_out);
+int s3d_event_destroy(void* event);
+int s3d_graph_marker(int id, s3d_stream_t capturing_stream);
+int s3d_graph_events_at_markers(void* hip_graph, void* const* events, int n);
+int s3d_stream_wait_event(s3d_stream_t waiting_stream, void* event);
+
 /* ------------------------------------------------------------------------------------------------ timm Block
  * One pre-norm transformer block: x += attn(norm1(x)); x += mlp(norm2(x))  (timm==0.3.2 Block.forward, invoked by
  * `for blk in self.blocks: x = blk(x)` at vit_3d_2d_pretrain.py:467-468,481-482,493-494) and its backward. */

@@ -4,6 +4,8 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <vector>
+
 #include "attention.h"
 #include "fused_block.h"
 #include "gemm.h"
@@ -482,6 +484,79 @@ int s3d_adam_step_packed(float* p, float* g, const uint16_t* g_wire, float* m, f
     return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, packed, st(s));
 }
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
+
+// ---- events recorded INSIDE a stream capture as external event-record nodes (see s3d_hip.h)
+int s3d_event_create(void** out) {
+    S3D_REQUIRE(out != nullptr, "s3d_event_create: null result pointer");
+    hipEvent_t e = nullptr;
+    const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    S3D_REQUIRE(rc == hipSuccess, "s3d_event_create: %s", hipGetErrorString(rc));
+    *out = e;
+    return 0;
+}
+int s3d_event_destroy(void* ev) {
+    if (ev) (void)hipEventDestroy(static_cast<hipEvent_t>(ev));
+    return 0;
+}
+// A marker in a stream capture: a kernel node that s3d_graph_events_at_markers replaces by an event-record node.  (Recording with
+// hipEventRecordWithFlags(.., hipEventRecordExternal) on the capturing stream is refused -- "invalid argument" -- by the HIP runtime
+// PyTorch 2.10+rocm7.0 bundles; editing the captured graph works.)
+__global__ void s3d_marker_kernel(int) {}
+int s3d_graph_marker(int id, s3d_stream_t s) {
+    hipLaunchKernelGGL(s3d_marker_kernel, dim3(1), dim3(1), 0, st(s), id);
+    S3D_CHECK_LAUNCH("graph_marker");
+    return 0;
+}
+int s3d_graph_events_at_markers(void* graph, void* const* events, int n) {
+    S3D_REQUIRE(graph && events && n >= 1 && n <= 64, "s3d_graph_events_at_markers: graph, 1..64 events");
+    hipGraph_t g = static_cast<hipGraph_t>(graph);
+#define S3D_HIP(expr)                                                                                          \
+    do {                                                                                                       \
+        const hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                               \
+            s3d_set_error("s3d_graph_events_at_markers: %s failed: %s", #expr, hipGetErrorString(e__));        \
+            return 3;                                                                                          \
+        }                                                                                                      \
+    } while (0)
+    size_t count = 0;
+    S3D_HIP(hipGraphGetNodes(g, nullptr, &count));
+    std::vector<hipGraphNode_t> nodes(count);
+    S3D_HIP(hipGraphGetNodes(g, nodes.data(), &count));
+    std::vector<hipGraphNode_t> marker(n, nullptr);
+    for (size_t i = 0; i < count; ++i) {
+        hipGraphNodeType ty;
+        S3D_HIP(hipGraphNodeGetType(nodes[i], &ty));
+        if (ty != hipGraphNodeTypeKernel) continue;
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        S3D_HIP(hipGraphKernelNodeGetParams(nodes[i], &kp));
+        if (kp.func != reinterpret_cast<void*>(s3d_marker_kernel) || kp.kernelParams == nullptr) continue;
+        const int id = *static_cast<const int*>(kp.kernelParams[0]);
+        S3D_REQUIRE(id >= 0 && id < n && marker[id] == nullptr, "s3d_graph_events_at_markers: unexpected marker id %d", id);
+        marker[id] = nodes[i];
+    }
+    for (int k = 0; k < n; ++k) {
+        S3D_REQUIRE(marker[k] != nullptr, "s3d_graph_events_at_markers: marker %d not found in the graph", k);
+        size_t nd = 0, nx = 0;
+        S3D_HIP(hipGraphNodeGetDependencies(marker[k], nullptr, &nd));
+        S3D_HIP(hipGraphNodeGetDependentNodes(marker[k], nullptr, &nx));
+        std::vector<hipGraphNode_t> deps(nd ? nd : 1), nexts(nx ? nx : 1);
+        if (nd) S3D_HIP(hipGraphNodeGetDependencies(marker[k], deps.data(), &nd));
+        if (nx) S3D_HIP(hipGraphNodeGetDependentNodes(marker[k], nexts.data(), &nx));
+        hipGraphNode_t rec = nullptr;              // in line (prev -> record -> next): the graph stays one chain, no fork / join
+        S3D_HIP(hipGraphAddEventRecordNode(&rec, g, nd ? deps.data() : nullptr, nd, static_cast<hipEvent_t>(events[k])));
+        for (size_t j = 0; j < nx; ++j) S3D_HIP(hipGraphAddDependencies(g, &rec, &nexts[j], 1));
+        S3D_HIP(hipGraphDestroyNode(marker[k]));
+    }
+#undef S3D_HIP
+    return 0;
+}
+int s3d_stream_wait_event(s3d_stream_t s, void* ev) {
+    S3D_REQUIRE(ev != nullptr, "s3d_stream_wait_event: null event");
+    const hipError_t rc = hipStreamWaitEvent(st(s), static_cast<hipEvent_t>(ev), 0);
+    S3D_REQUIRE(rc == hipSuccess, "s3d_stream_wait_event: %s", hipGetErrorString(rc));
+    return 0;
+}
 
 int s3d_pack_weights(const uint16_t* src_hi, const uint16_t* src_lo, uint16_t* dst_hi, uint16_t* dst_lo, int rows, int K, s3d_stream_t s) {
     return s3d_launch_pack_weights(src_hi, src_lo, dst_hi, dst_lo, rows, K, st(s));

@@ -66,8 +66,15 @@ class DataParallelTrainer:
     """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
 
     def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False, graph_collectives=False,
-                 wire='fp32'):
-        """wire: 'fp32' all-reduces the gradient arena itself (DDP's arithmetic); 'bf16' rounds every finished bucket to bf16
+                 wire='fp32', event_graph=False):
+        """event_graph (opt-in, with use_graphs): forward + the whole backward are captured as ONE flat graph with an external
+        event-record node behind every backward segment (s3d_graph_marker / s3d_graph_events_at_markers); the all-reduce of bucket k is
+        launched from the host on a side stream that waits for "segment k done" only, so it overlaps the later segments and the
+        compute stream never sees a graph boundary or a c10d event packet.  No collective lives inside a graph (nothing that could
+        hang with real peers).  Built and measured in round 3 (tools/dp_overhead_probe.py, profiles/r03_dp_overhead_probe.txt): on
+        this runtime an event-record node inside a graph costs ~20 us -- MORE than the graph boundary it replaces (~10 us) -- so the
+        default stays event_graph=False: one graph per segment with the collectives launched in between.
+        wire: 'fp32' all-reduces the gradient arena itself (DDP's arithmetic); 'bf16' rounds every finished bucket to bf16
         (s3d_pack_bf16, on the compute stream right after its backward segment), all-reduces HALF the bytes over xGMI and lets the
         Adam kernel read the bf16 sum (s3d_adam_step_wire) -- gradient compression as in DDP's bf16_compress_hook.
         graph_collectives: capture the WHOLE step -- backward segments, the all-reduce of every bucket (RCCL calls are
@@ -96,7 +103,19 @@ class DataParallelTrainer:
         if self.world > 1:                   # DDP ranks draw different dropout masks (independent RNG streams per process)
             engine.dropout_seed.add_(1000003 * dist.get_rank(group))
         self.use_graphs = use_graphs
+        self.event_graph = bool(event_graph) and not self.graph_collectives
+        self._side = None                   # the stream the bucket collectives are issued from in event_graph mode
         self._cap = None
+
+    def collectives_mode(self):
+        """How this trainer's captured step issues the bucket all-reduces (bench.py prints it)."""
+        if self.world == 1 and not self.reducer.force:
+            return 'none'
+        if not self.use_graphs:
+            return 'host-launched between eager backward segments'
+        if self.graph_collectives:
+            return 'captured in the step graph'
+        return 'host-launched on graph events' if self.event_graph else 'host-launched between graph segments'
 
     def set_optimizer(self, lr=None, betas=None, eps=None):
         self.eng.set_optimizer(lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.world)
@@ -155,6 +174,31 @@ class DataParallelTrainer:
             self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
             self._guarded_first_replay(g, state)
             return self._cap
+        self._release_events()
+        if self.event_graph:
+            import ctypes
+            from . import _lib as L
+            lib = L.lib()
+            events = []
+            for _ in self.segments:
+                ev = ctypes.c_void_p()
+                L.check(lib.s3d_event_create(ctypes.byref(ev)), 'event_create')
+                events.append(ev)
+            g = torch.cuda.CUDAGraph(keep_graph=True)                   # instantiated at its first replay, i.e. after the edit below
+            with torch.cuda.graph(g):
+                for k in range(len(self.segments)):
+                    self._phase(k, B, sx, sy, weight)
+                    L.check(lib.s3d_graph_marker(k, L.current_stream()), 'graph_marker')
+            L.check(lib.s3d_graph_events_at_markers(ctypes.c_void_p(g.raw_cuda_graph()), (ctypes.c_void_p * len(events))(*events),
+                                                    len(events)), 'graph_events_at_markers')
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt):
+                eng.adam_step(zero_grad=True, wire=self.wire)
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._cap = dict(B=B, graphs=[], fwd_bwd=g, events=events, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss,
+                             epoch=eng.capture_epoch)
+            return self._cap
         graphs = []
         for k in range(len(self.segments)):
             g = torch.cuda.CUDAGraph()
@@ -166,6 +210,20 @@ class DataParallelTrainer:
             eng.adam_step(zero_grad=True, wire=self.wire)
         self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
         return self._cap
+
+    def _release_events(self):
+        if self._cap is not None and self._cap.get('events'):
+            from . import _lib as L
+            torch.cuda.synchronize()
+            for ev in self._cap['events']:
+                L.lib().s3d_event_destroy(ev)
+            self._cap['events'] = []
+
+    def __del__(self):
+        try:
+            self._release_events()
+        except Exception:                   # interpreter shutdown
+            pass
 
     def _guarded_first_replay(self, graph, state, timeout_s=None):
         """First replay of a graph that holds RCCL kernels, under a watchdog: a capture problem that only shows with real peers
@@ -203,6 +261,21 @@ class DataParallelTrainer:
             raise RuntimeError('the captured step is stale (set_dropout changed a value baked into the graphs): capture() again')
         if 'whole' in cap:
             cap['whole'].replay()
+            return cap['loss'][0]
+        if cap.get('fwd_bwd') is not None:
+            import ctypes
+            from . import _lib as L
+            lib, cur, side = L.lib(), torch.cuda.current_stream(), self._side
+            cap['fwd_bwd'].replay()
+            for k, ev in enumerate(cap['events']):
+                # the side stream waits for the event behind segment k -- recorded inside the graph that is already running -- and the
+                # collective (and the bf16 pack in front of it) is issued from there: c10d synchronises with the SIDE stream
+                L.check(lib.s3d_stream_wait_event(ctypes.c_void_p(side.cuda_stream), ev), 'stream_wait_event')
+                with torch.cuda.stream(side):
+                    self.reducer.launch(k)
+            self.reducer.wait()             # the compute stream waits for every collective ...
+            cur.wait_stream(side)           # ... and for whatever else the side stream did (wire packing at world size 1)
+            cap['opt'].replay()
             return cap['loss'][0]
         for k, g in enumerate(cap['graphs']):
             g.replay()

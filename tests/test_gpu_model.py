@@ -223,9 +223,11 @@ def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
     assert rel < 2e-2, rel
 
 
-def test_dp_trainer_segmented_graphs_and_rccl_path():
-    """DataParallelTrainer on one GPU: 3 backward segments captured as HIP graphs with a (forced) RCCL all-reduce of each
-    gradient bucket between replays, vs the plain eager fused step."""
+@pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire'])
+def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
+    """DataParallelTrainer on one GPU with a (forced) RCCL all-reduce of each of 3 gradient buckets, vs the plain eager fused step.
+    event_graph (default): ONE natively assembled graph with an event behind every backward segment, collectives launched from a
+    side stream on those events (s3d_graph_marker / s3d_graph_events_at_markers); segment_graphs: one graph per segment, collectives in between."""
     import os
     import torch.distributed as dist
     from simple3d_former_amd.parallel import DataParallelTrainer
@@ -238,14 +240,17 @@ def test_dp_trainer_segmented_graphs_and_rccl_path():
     try:
         ref = make_engine(cfg, sd)
         eng = make_engine(cfg, sd)
-        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
+        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True, event_graph=mode != 'segment_graphs',
+                                 wire='bf16' if mode.endswith('bf16_wire') else 'fp32')
         assert len(tr.slices) == 3 and tr.segments == [(11, 6), (5, 3), (2, 0)]
-        for step in range(3):
+        assert tr.collectives_mode() == ('host-launched between graph segments' if mode == 'segment_graphs' else 'host-launched on graph events')
+        for step in range(4):
             l_ref = float(ref.train_step(x.to(DEV), y.to(DEV)))
             l_dp = float(tr.step(x.to(DEV), y.to(DEV)))
             assert abs(l_ref - l_dp) <= 2e-3, f'step {step}: {l_ref} vs {l_dp}'
         d = (eng.arena.p - ref.arena.p).abs().max()
-        assert float(d) <= 6.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
+        assert ('fwd_bwd' in tr._cap) == (mode != 'segment_graphs')
+        assert float(d) <= 8.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
         dist.destroy_process_group()
 
