@@ -42,6 +42,7 @@ def main():
     write = load(f'{src}/write/p_counter_collection.csv', 'WRITE_SIZE')
     hit = load(f'{src}/tcc/p_counter_collection.csv', 'TCC_HIT_sum')
     miss = load(f'{src}/tcc/p_counter_collection.csv', 'TCC_MISS_sum')
+    req = load(f'{src}/tcc/p_counter_collection.csv', 'TCC_REQ_sum')
     mfma = gui = None
     if os.path.exists(f'{src}/mfma/p_counter_collection.csv'):
         mfma = load(f'{src}/mfma/p_counter_collection.csv', 'SQ_VALU_MFMA_BUSY_CYCLES')
@@ -60,7 +61,8 @@ def main():
         h, m = hit.get(k, [0, 0.0])[1], miss.get(k, [0, 0.0])[1]
         out[k] = dict(launches=n, fetch_bytes_raw=round(f_kb * 1024), fetch_bytes_corrected=round(2 * f_kb * 1024),
                       write_bytes_raw=round(w_kb * 1024), hbm_bytes_per_launch=round((2 * f_kb + w_kb) * 1024),
-                      l2_hit_rate=round(h / (h + m), 4) if h + m else None)
+                      l2_hit_rate=round(h / (h + m), 4) if h + m else None,
+                      l2_requests_per_launch=round(req[k][1] / req[k][0]) if k in req and req[k][0] else None)
         if k in dur:
             out[k]['avg_us'] = dur[k]
             out[k]['hbm_side_GBps'] = round(out[k]['hbm_bytes_per_launch'] / dur[k] / 1e3, 1)
@@ -68,7 +70,13 @@ def main():
                 out[k]['mfma_busy_cycles_per_launch'] = round(mfma[k][1] / mfma[k][0])
                 out[k]['mfma_busy_frac'] = round(mfma[k][1] / mfma[k][0] / N_SIMD / (dur[k] * CLOCK_MHZ), 4)
     with open(dst + '.json', 'w') as f:
-        json.dump(dict(command='bench.py --no-graphs --steps 4 --warmup 2 (cfg-2, batch 64), rocprofv3 --kernel-trace --pmc, '
+        import subprocess, datetime
+        try:
+            head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or None
+        except OSError:
+            head = None
+        head = os.environ.get('S3D_HEAD', head)             # the GPU box has no .git: the caller passes the commit the tree was cut from
+        json.dump(dict(head=head, date=datetime.date.today().isoformat(), command='bench.py --no-graphs --steps 4 --warmup 2 (cfg-2, batch 64), rocprofv3 --kernel-trace --pmc, '
                                'one pass per counter group', correction='fetch x2 (gfx950 wide-read tally), write raw',
                        kernels=out), f, indent=1)
     with open(dst + '.txt', 'w') as f:
