@@ -245,20 +245,6 @@ int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t
  * on xGMI): s3d_pack_bf16 rounds a finished gradient bucket to bf16 (rne; n % 8 == 0), the bf16 buffer is sum-all-reduced, and
  * s3d_adam_step_wire takes the gradient from it (g is only zeroed).  The averaging stays in S3dAdamState::grad_scale. */
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t stream);
-/* The same step, additionally keeping MFMA-fragment-ordered copies (s3d_pack_weights layout) of selected weight matrices current: for
- * every table row {start, end, K} (element offsets into the arena, start % 8 == 0, a row-major [rows][K] matrix with rows % 16 == 0,
- * K % 32 == 0, fewer than 2^24 elements) the refreshed hi / lo planes of [start, end) are also written, permuted, to packed->hi / lo
- * at the SAME element offsets.  g_wire may be NULL (fp32 gradients).  packed == NULL or n == 0: plain s3d_adam_step. */
-typedef struct S3dPackedWeights {
-    uint16_t* hi; uint16_t* lo;       /* packed planes, arena-sized */
-    const long* table;                /* device memory: n rows of {start, end, K} */
-    int n;
-    long max_elems;                   /* largest end - start of the table (host-side check of the 2^24 bound) */
-} S3dPackedWeights;
-int s3d_adam_step_packed(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
-                         S3dAdamState* state, int zero_grad, const S3dPackedWeights* packed, s3d_stream_t stream);
-int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
-                       S3dAdamState* state, int zero_grad, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ mid-graph events for data parallelism
  * DDP (train_cls_voxel.py:155-159, :287) all-reduces gradient buckets while backward is still running.  With HIP graphs that used to
@@ -301,9 +287,6 @@ typedef struct S3dBlockShape {
 typedef struct S3dBlockParams {
     const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_b, *proj_b, *fc1_b, *fc2_b;
     const uint16_t *qkv_w_hi, *qkv_w_lo, *proj_w_hi, *proj_w_lo, *fc1_w_hi, *fc1_w_lo, *fc2_w_hi, *fc2_w_lo;
-    /* optional: attn.qkv / mlp.fc1 weight planes in MFMA fragment order (s3d_pack_weights of the planes above).  The fused launches of
-     * S3dBlockShape::fuse stream their weights from these; NULL (any of the four) -> the seven-launch sequence. */
-    const uint16_t *qkv_wp_hi, *qkv_wp_lo, *fc1_wp_hi, *fc1_wp_lo;
 } S3dBlockParams;
 typedef struct S3dBlockGrads {
     float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *fc1_w, *fc1_b, *fc2_w, *fc2_b;
@@ -333,13 +316,6 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
 } S3dBlockScratch;
 int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
                   s3d_stream_t stream);
-/* Row-major bf16 planes [rows][K] (rows % 16 == 0, K % 32 == 0) -> MFMA fragment order: the 16 x 32 block (rows 16 nb .., k 32 ks ..)
- * becomes 1 KB at element offset (nb * K / 32 + ks) * 512, inside it lane l = (n = l & 15, g = l >> 4) of a v_mfma_f32_16x16x32_bf16
- * operand holds W[16 nb + n][32 ks + 8 g .. + 7] at element 8 l.  A wave that streams a weight slice from this copy reads 1 KB of
- * consecutive bytes per load instruction (from the row-major planes: 16 - 64 cache lines).  src_lo / dst_lo may both be NULL.
- * s3d_adam_step_packed keeps such copies current; this entry point is for parameters changed by anything else. */
-int s3d_pack_weights(const uint16_t* src_hi, const uint16_t* src_lo, uint16_t* dst_hi, uint16_t* dst_lo, int rows, int K,
-                     s3d_stream_t stream);
 /* in: d(x_out) in scratch->dx_a (+ bf16 copy dx_a_bf); out: d(x_in) in scratch->dx_a / dx_a_bf again. */
 int s3d_block_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockGrads* grads,
                   const S3dBlockActs* acts, const S3dBlockScratch* scratch, s3d_stream_t stream);

@@ -62,7 +62,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     if (next_ln1_done) *next_ln1_done = false;
     // Fused launches (fused_block.hip): norm1 + qkv + attention per (sample pair, head), norm2 + fc1 + GELU per (64-row band, hidden
     // slice).  Split-bf16 forward of the small-batch shapes only; S3dBlockShape::fuse = -1 keeps the seven-launch sequence.
-    const bool fuse_ok = split && sh.fuse >= 0 && sh.ln_tickets == nullptr && !ln1_done && p.qkv_wp_hi && p.qkv_wp_lo && p.fc1_wp_hi && p.fc1_wp_lo;
+    const bool fuse_ok = split && sh.fuse >= 0 && sh.ln_tickets == nullptr && !ln1_done;
     const bool fuse_attn = fuse_ok && s3d_fused_attn_ok(sh.Bb, sh.N, D, sh.H);
     const bool fuse_mlp = fuse_ok && !cls_only && s3d_fused_mlp1_ok(M, D, Hd);
     LnArgs ln;
@@ -72,7 +72,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     if (fuse_attn) {
         FusedAttnArgs fa;
         fa.x = a.x_in; fa.gamma = p.ln1_w; fa.beta = p.ln1_b; fa.eps = sh.eps;
-        fa.w_hi = p.qkv_wp_hi; fa.w_lo = p.qkv_wp_lo; fa.bias = p.qkv_b;
+        fa.w_hi = p.qkv_w_hi; fa.w_lo = p.qkv_w_lo; fa.bias = p.qkv_b;
         fa.xn_hi = a.xn1_hi; fa.xn_lo = a.xn1_lo; fa.mean = a.mean1; fa.rstd = a.rstd1;
         fa.qkv_hi = a.qkv_hi; fa.att_hi = a.att_hi; fa.att_lo = a.att_lo; fa.lse = a.lse;
         fa.Bb = sh.Bb; fa.N = sh.N; fa.H = sh.H; fa.scale = 1.0f / sqrtf((float)(D / sh.H));
@@ -109,7 +109,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     if (fuse_mlp) {
         FusedMlpArgs fm;
         fm.x = a.x_mid; fm.gamma = p.ln2_w; fm.beta = p.ln2_b; fm.eps = sh.eps;
-        fm.w_hi = p.fc1_wp_hi; fm.w_lo = p.fc1_wp_lo; fm.bias = p.fc1_b;
+        fm.w_hi = p.fc1_w_hi; fm.w_lo = p.fc1_w_lo; fm.bias = p.fc1_b;
         fm.xn_hi = a.xn2_hi; fm.xn_lo = a.xn2_lo; fm.mean = a.mean2; fm.rstd = a.rstd2;
         fm.hpre = a.hpre; fm.hact_hi = a.hact_hi; fm.hact_lo = a.hact_lo;
         fm.M = M; fm.hidden = Hd; fm.nslice = Hd / 192;
@@ -381,7 +381,7 @@ size_t s3d_sizeof(const char* n) {
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dHeadLossArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
-    SZ(S3dGroupProjArgs); SZ(S3dPackedWeights);
+    SZ(S3dGroupProjArgs);
 #undef SZ
     return 0;
 }
@@ -472,16 +472,12 @@ int s3d_image_patchify(const float* img, uint16_t* a_hi, uint16_t* a_lo, long ld
 }
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t s) {
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, nullptr, nullptr, st(s));
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, nullptr, st(s));
 }
 int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
                        S3dAdamState* state, int zero_grad, s3d_stream_t s) {
     S3D_REQUIRE(g_wire != nullptr, "s3d_adam_step_wire: the bf16 gradient buffer is required");
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, nullptr, st(s));
-}
-int s3d_adam_step_packed(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
-                         S3dAdamState* state, int zero_grad, const S3dPackedWeights* packed, s3d_stream_t s) {
-    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, packed, st(s));
+    return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, st(s));
 }
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
 
@@ -558,9 +554,6 @@ int s3d_stream_wait_event(s3d_stream_t s, void* ev) {
     return 0;
 }
 
-int s3d_pack_weights(const uint16_t* src_hi, const uint16_t* src_lo, uint16_t* dst_hi, uint16_t* dst_lo, int rows, int K, s3d_stream_t s) {
-    return s3d_launch_pack_weights(src_hi, src_lo, dst_hi, dst_lo, rows, K, st(s));
-}
 int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_block_fwd: null args");
     return block_fwd(*sh, *p, *a, st(s));

@@ -5,7 +5,7 @@
 struct FusedAttnArgs {
     const float* x;                       // residual stream into the block [Bb*N][D]
     const float* gamma; const float* beta; float eps;      // norm1
-    const bf16_t* w_hi; const bf16_t* w_lo; const float* bias;   // attn.qkv: PACKED weight planes of [3D][D] (s3d_pack_weights), bias [3D]
+    const bf16_t* w_hi; const bf16_t* w_lo; const float* bias;   // attn.qkv: weight planes [3D][D], bias [3D]
     bf16_t* xn_hi; bf16_t* xn_lo;         // out: norm1(x) planes [M][D]
     float* mean; float* rstd;             // out: [M]
     bf16_t* qkv_hi;                       // out: [M][3D] (bf16 of q | k | v; the lo plane is not needed by anything downstream)
@@ -17,7 +17,7 @@ struct FusedAttnArgs {
 struct FusedMlpArgs {
     const float* x;                       // residual stream after the attention branch [M][D]
     const float* gamma; const float* beta; float eps;      // norm2
-    const bf16_t* w_hi; const bf16_t* w_lo; const float* bias;   // mlp.fc1: PACKED weight planes of [hidden][D], bias [hidden]
+    const bf16_t* w_hi; const bf16_t* w_lo; const float* bias;   // mlp.fc1: weight planes [hidden][D], bias [hidden]
     bf16_t* xn_hi; bf16_t* xn_lo;         // out: norm2(x) planes [M][D]
     float* mean; float* rstd;             // out: [M]
     bf16_t* hpre; bf16_t* hact_hi; bf16_t* hact_lo;        // out: [M][hidden]
@@ -26,6 +26,5 @@ struct FusedMlpArgs {
 };
 bool s3d_fused_attn_ok(int Bb, int N, int D, int H);
 bool s3d_fused_mlp1_ok(long M, int D, int hidden);
-int s3d_launch_pack_weights(const bf16_t* src_hi, const bf16_t* src_lo, bf16_t* dst_hi, bf16_t* dst_lo, int rows, int K, hipStream_t s);
 int s3d_launch_fused_attn(const FusedAttnArgs& a, int D, hipStream_t s);
 int s3d_launch_fused_mlp1(const FusedMlpArgs& a, int D, hipStream_t s);

@@ -534,7 +534,7 @@ __global__ void adam_prelude_kernel(AdamState* st) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, bf16_t* __restrict__ hi,
                                                    bf16_t* __restrict__ lo, long n4, const AdamState* st, int zero_grad,
-                                                   const bf16_t* __restrict__ gw, const S3dPackedWeights pk) {
+                                                   const bf16_t* __restrict__ gw) {
     const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
     const float step_size = st->step_size, bc2s = st->bc2_sqrt;
     // back to front: the arena is laid out in forward order, so the tokenizer's and the first blocks' weight planes are the LAST
@@ -567,24 +567,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (hi) reinterpret_cast<uint2*>(hi)[i] = H.u;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = L.u;
-        // fragment-ordered copies of the weight matrices the fused block launches stream (s3d_pack_weights layout): the four
-        // elements of this thread are half of one 16-byte operand piece.  The table walk is scalar (uniform index); tensors start
-        // on multiples of 8 elements and K % 32 == 0, so a quad never straddles a tensor, a row or a piece.
-        for (int t = 0; t < pk.n; ++t) {
-            const long start = pk.table[3 * t], end = pk.table[3 * t + 1];
-            const long e = 4 * i;
-            if (e >= start && e < end) {
-                const int K = (int)pk.table[3 * t + 2];
-                const int rel = (int)(e - start);                      // < 2^24 (checked by the launcher): exact in fp32
-                int nrow = (int)((float)rel * (1.0f / (float)K));
-                int k = rel - nrow * K;
-                if (k < 0) { --nrow; k += K; }
-                if (k >= K) { ++nrow; k -= K; }
-                const long dst = start + ((long)(nrow >> 4) * (K >> 5) + (k >> 5)) * 512 + ((nrow & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
-                *reinterpret_cast<uint2*>(pk.hi + dst) = H.u;
-                *reinterpret_cast<uint2*>(pk.lo + dst) = L.u;
-            }
-        }
     }
 }
 
@@ -705,20 +687,12 @@ int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s) {
 }
 
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
-                    int zero_grad, const bf16_t* g_wire, const S3dPackedWeights* packed, hipStream_t s) {
+                    int zero_grad, const bf16_t* g_wire, hipStream_t s) {
     S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
-    S3dPackedWeights pk;
-    memset(&pk, 0, sizeof(pk));
-    if (packed != nullptr && packed->n > 0) {
-        S3D_REQUIRE(packed->hi && packed->lo && packed->table && hi && lo, "adam: packed weight planes / table missing");
-        S3D_REQUIRE(packed->max_elems > 0 && packed->max_elems < (1L << 24), "adam: packed tensors must have fewer than 2^24 elements (got %ld)",
-                    packed->max_elems);
-        pk = *packed;
-    }
     hipLaunchKernelGGL(adam_prelude_kernel, dim3(1), dim3(1), 0, s, st);
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire, pk);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire);
     S3D_CHECK_LAUNCH("adam");
     return 0;
 }

@@ -89,11 +89,6 @@ def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_emb
     return shapes
 
 
-def is_packed_weight(key, shape):
-    """Weight matrices that the fused block launches (csrc/fused_block.hip) stream in MFMA fragment order."""
-    return (key.endswith('attn.qkv.weight') or key.endswith('mlp.fc1.weight')) and len(shape) == 2 and shape[0] % 16 == 0 and shape[1] % 32 == 0
-
-
 class ParamArena:
     """Flat fp32 arena + same-layout gradient / moment arenas + split-bf16 (hi, lo) planes."""
 
@@ -112,17 +107,6 @@ class ParamArena:
         self.v = torch.zeros_like(self.p)
         self.hi = torch.zeros(self.numel, dtype=torch.bfloat16, device=device)
         self.lo = torch.zeros_like(self.hi)
-        # MFMA-fragment-ordered copies of the weight matrices the fused block launches stream (attn.qkv / mlp.fc1 of every block; see
-        # s3d_pack_weights): same offsets as the arena, only those tensors' ranges are ever written
-        self.packed = [k for k, shp in self.shapes.items() if is_packed_weight(k, shp)]
-        self.hi_pk = torch.zeros_like(self.hi) if self.packed else None
-        self.lo_pk = torch.zeros_like(self.hi) if self.packed else None
-        self.pk = None                      # S3dPackedWeights for s3d_adam_step_packed
-        if self.packed:
-            rows = [[self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k])), self.shapes[k][1]] for k in self.packed]
-            self.pk_table = torch.tensor(rows, dtype=torch.int64, device=device)
-            self.pk = L.fill(L.S3dPackedWeights(), hi=self.hi_pk, lo=self.lo_pk, table=self.pk_table, n=len(rows),
-                             max_elems=max(r[1] - r[0] for r in rows))
 
     def _view(self, flat, k):
         o, shp = self.offsets[k], self.shapes[k]
@@ -132,8 +116,6 @@ class ParamArena:
     def grad(self, k): return self._view(self.g, k)
     def hi_of(self, k): return self._view(self.hi, k)
     def lo_of(self, k): return self._view(self.lo, k)
-    def hi_pk_of(self, k): return self._view(self.hi_pk, k) if k in self.packed else None
-    def lo_pk_of(self, k): return self._view(self.lo_pk, k) if k in self.packed else None
 
     def load(self, sd):
         with torch.no_grad():
@@ -148,15 +130,6 @@ class ParamArena:
         lib = L.lib()
         L.check(lib.s3d_split_bf16(L.ptr(self.p), L.ptr(self.hi), L.ptr(self.lo), ctypes.c_long(1),
                                    ctypes.c_long(self.numel), ctypes.c_long(self.numel), L.current_stream()), 'split_bf16')
-        self.repack()
-
-    def repack(self):
-        """row-major weight planes -> fragment-ordered copies (after anything but s3d_adam_step_packed changed the parameters)."""
-        lib = L.lib()
-        for k in self.packed:
-            rows, K = self.shapes[k]
-            L.check(lib.s3d_pack_weights(L.ptr(self.hi_of(k)), L.ptr(self.lo_of(k)), L.ptr(self.hi_pk_of(k)), L.ptr(self.lo_pk_of(k)),
-                                         rows, K, L.current_stream()), 'pack_weights')
 
 
 class _BlockWorkspace:
@@ -331,9 +304,7 @@ class VoxelEngine:
                    qkv_w_hi=a.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=a.lo_of(p + 'attn.qkv.weight'),
                    proj_w_hi=a.hi_of(p + 'attn.proj.weight'), proj_w_lo=a.lo_of(p + 'attn.proj.weight'),
                    fc1_w_hi=a.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=a.lo_of(p + 'mlp.fc1.weight'),
-                   fc2_w_hi=a.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=a.lo_of(p + 'mlp.fc2.weight'),
-                   qkv_wp_hi=a.hi_pk_of(p + 'attn.qkv.weight'), qkv_wp_lo=a.lo_pk_of(p + 'attn.qkv.weight'),
-                   fc1_wp_hi=a.hi_pk_of(p + 'mlp.fc1.weight'), fc1_wp_lo=a.lo_pk_of(p + 'mlp.fc1.weight'))
+                   fc2_w_hi=a.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=a.lo_of(p + 'mlp.fc2.weight'))
             L.fill(self.bgrads[i], ln1_w=a.grad(p + 'norm1.weight'), ln1_b=a.grad(p + 'norm1.bias'),
                    ln2_w=a.grad(p + 'norm2.weight'), ln2_b=a.grad(p + 'norm2.bias'),
                    qkv_w=a.grad(p + 'attn.qkv.weight'), qkv_b=a.grad(p + 'attn.qkv.bias'),
@@ -693,12 +664,15 @@ class VoxelEngine:
         """wire: bf16 tensor of the arena's layout holding the (all-reduced) gradient -- the data-parallel wire format; the
         fp32 gradient arena is then only zeroed."""
         a = self.arena
-        if wire is not None:
+        if wire is None:
+            L.check(self.lib.s3d_adam_step(L.ptr(a.p), L.ptr(a.g), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
+                                           ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                           L.current_stream()), 'adam')
+        else:
             assert wire.dtype == torch.bfloat16 and wire.numel() == a.numel and wire.is_cuda
-        # one kernel: Adam, the split-bf16 planes, the fragment-ordered copies of the attn.qkv / mlp.fc1 planes, gradient zeroing
-        L.check(self.lib.s3d_adam_step_packed(L.ptr(a.p), L.ptr(a.g), L.ptr(wire), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
-                                              ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
-                                              ctypes.byref(a.pk) if a.pk is not None else None, L.current_stream()), 'adam')
+            L.check(self.lib.s3d_adam_step_wire(L.ptr(a.p), L.ptr(a.g), L.ptr(wire), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo),
+                                                ctypes.c_long(a.numel), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                                L.current_stream()), 'adam (bf16 wire)')
         self._refresh_conv_planes()
 
     def pack_grads(self, start, end, wire):

@@ -514,9 +514,7 @@ def test_fused_block_launches_equal_the_seven_launch_sequence(D, H, N, Bb, depth
                qkv_w_hi=arena.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=arena.lo_of(p + 'attn.qkv.weight'),
                proj_w_hi=arena.hi_of(p + 'attn.proj.weight'), proj_w_lo=arena.lo_of(p + 'attn.proj.weight'),
                fc1_w_hi=arena.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=arena.lo_of(p + 'mlp.fc1.weight'),
-               fc2_w_hi=arena.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=arena.lo_of(p + 'mlp.fc2.weight'),
-               qkv_wp_hi=arena.hi_pk_of(p + 'attn.qkv.weight'), qkv_wp_lo=arena.lo_pk_of(p + 'attn.qkv.weight'),
-               fc1_wp_hi=arena.hi_pk_of(p + 'mlp.fc1.weight'), fc1_wp_lo=arena.lo_pk_of(p + 'mlp.fc1.weight'))
+               fc2_w_hi=arena.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=arena.lo_of(p + 'mlp.fc2.weight'))
     x = torch.randn(M, D, generator=g)
     runs = {}
     for fuse in (False, True, True):
