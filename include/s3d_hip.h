@@ -69,9 +69,13 @@ typedef struct S3dGemmArgs {
      * sums of its squares over the M rows (fp64 atomics; the caller zeroes it).  They are the batch statistics of the train-mode
      * BatchNorm that follows a point-path convolution (S3dBnArgs::have_sums), so that tensor is not read a second time to get them. */
     double* col_sums;
+    /* optional low plane of `aux` (the saved pre-activation): GELU / RELU epilogues then store aux_lo = bf16(pre - aux), DGELU / DRELU read
+     * pre = aux + aux_lo.  Only the split-precision backward mode (S3dBlockScratch::dx_a_lo) sets it. */
+    uint16_t* aux_lo;
 } S3dGemmArgs;
 /* ta / tb: operand stored k-major.  (0,0) forward "x @ W^T"; (0,1) dgrad "dy @ W"; (1,1) wgrad "dy^T @ x" (split-K,
- * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product (forward). */
+ * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product -- the forward's precision;
+ * for (0,1) / (1,1) it is the split-precision BACKWARD of the parity mode (both operands need their lo planes, no split-K). */
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
 /* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
@@ -126,6 +130,7 @@ typedef struct S3dLnBwdArgs {
     float* partial; int partial_blocks;
     /* optional dropout mask applied to the bf16 copy only (the branch gradient of a post-norm residual), see S3dGemmArgs */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
+    uint16_t* dx_bf_lo;            /* optional: low plane of dx_bf (dx ~= dx_bf + dx_bf_lo), same pitch -- split-precision backward mode */
 } S3dLnBwdArgs;
 int s3d_layernorm_fwd(const S3dLnArgs* args, s3d_stream_t stream);
 int s3d_layernorm_bwd(const S3dLnBwdArgs* args, s3d_stream_t stream);
@@ -154,6 +159,10 @@ typedef struct S3dAttnArgs {
      * contiguous in memory: group_embed pass 1 has N = 15) into one 32-row MFMA tile; lse / delta are then laid out for the
      * packed problem (Bb/2, 2N), consistently between forward and backward. */
     int seg;
+    /* split-precision backward (parity mode): when dqkv_lo is set, s3d_attention_bwd takes q, k, v, dout and out as hi + lo pairs
+     * (qkv_lo, dout_lo, out_lo required), evaluates the backward in fp32 and stores d(qkv) as the pair dqkv / dqkv_lo.  Slow reference
+     * kernels, any N / head dim / layout; delta is still written. */
+    const uint16_t* dout_lo; uint16_t* dqkv_lo;
 } S3dAttnArgs;
 int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
 int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);
@@ -297,6 +306,8 @@ typedef struct S3dBlockActs {     /* written by forward, read by backward; M = B
     float *lse;                                   /* [Bb*H*N] */
     uint16_t *xn1_hi, *xn1_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *xn2_hi, *xn2_lo;
     uint16_t *hpre, *hact_hi, *hact_lo;           /* [M][hidden] */
+    uint16_t* hpre_lo;                            /* optional [M][hidden]: low plane of hpre, written by the forward when set (the
+                                                   * split-precision backward needs the pre-activation to 16 bits); disables the fused launches */
 } S3dBlockActs;
 typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
     float* dxn;                                   /* [M][D] */
@@ -313,6 +324,11 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
     /* S3dBlockShape::cls_only_block: d(x_mid) fp32 / bf16 and d(att) of that block, [M][D] each, ZERO-initialised by the caller once;
      * only the class rows are ever written, so the other rows stay zero for the dense attention / norm1 backward that follow */
     float* dx_b_cls; uint16_t* dx_b_bf_cls; uint16_t* datt_cls;
+    /* Split-precision backward (parity mode; train_cls_voxel.py:287 checked to ~1e-4 instead of the bf16 noise floor): low planes of every
+     * bf16 gradient buffer above.  When dx_a_lo is set (then all of them must be, and acts->hpre_lo / the lo planes of the saved
+     * activations), s3d_block(s)_bwd run every dgrad / wgrad as a three-MFMA split product on hi + lo operands without split-K, the
+     * attention backward in fp32, and keep every intermediate gradient as a hi + lo pair.  Several times slower; tests only. */
+    uint16_t *dx_a_lo, *dx_b_lo, *dh_lo, *dqkv_lo, *datt_lo, *dx_b_lo_cls, *datt_lo_cls;
 } S3dBlockScratch;
 int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
                   s3d_stream_t stream);

@@ -1245,6 +1245,94 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------- split-precision backward (parity mode)
+// Reference-grade attention backward for the split-precision parity mode (S3dAttnArgs::dqkv_lo): every operand is read as hi + lo
+// (fp32 value), all arithmetic is fp32 VALU, results are stored as hi + lo pairs.  One thread per (batch, head, token, 16-wide slice of
+// the head dimension); the scores of a row / column are recomputed by every slice.  Same mathematics as the MFMA kernels above
+// (P = exp(q k^T * scale - lse) from the forward's lse, delta = sum(dO * O), dS = P * (dP - delta) * scale, the dropout mask on P and
+// dP, block-diagonal segments), any N / head dimension / layout.  Slow by design: tests only.
+struct RefView {
+    const bf16_t *hi, *lo; long ld;
+    __device__ __forceinline__ float at(long row, int col) const { return bf2f(hi[row * ld + col]) + bf2f(lo[row * ld + col]); }
+};
+__device__ __forceinline__ bool ref_valid(const AttnArgs& p, int q, int k) { return p.seg == 0 || (q >= p.seg) == (k >= p.seg); }
+
+template <bool KEY_SIDE>
+__global__ __launch_bounds__(256) void attn_bwd_ref_kernel(const AttnArgs p) {
+    const int hd = p.D / p.H, nch = hd / 16;
+    const long total = (long)p.Bb * p.H * p.N * nch;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % nch), t = (int)((e / nch) % p.N), h = (int)((e / ((long)nch * p.N)) % p.H), b = (int)(e / ((long)nch * p.N * p.H));
+    const long bh = (long)b * p.H + h;
+    const RefView Q{p.qkv_hi, p.qkv_lo, p.ld}, O{p.out_hi, p.out_lo, p.ldo}, DO{p.dout, p.dout_lo, p.lddo};
+    const int qc = h * hd, kc = p.D + h * hd, vc = 2 * p.D + h * hd;
+    auto rowof = [&](int tok) { return (long)b * p.sb + (long)tok * p.st; };
+    const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    float acc0[16], acc1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc0[i] = acc1[i] = 0.f;
+    if (!KEY_SIDE && c == 0 && p.delta) {
+        float dl = 0.f;
+        for (int d = 0; d < hd; ++d) dl += DO.at(rowof(t), qc + d) * O.at(rowof(t), qc + d);
+        p.delta[bh * p.N + t] = dl;
+    }
+    // the other index runs over the whole sequence; (i, j) = (query, key)
+    for (int u = 0; u < p.N; ++u) {
+        const int i = KEY_SIDE ? u : t, j = KEY_SIDE ? t : u;
+        if (!ref_valid(p, i, j)) continue;
+        const long ri = rowof(i), rj = rowof(j);
+        float sc = 0.f, dp = 0.f, delta = 0.f;
+        for (int d = 0; d < hd; ++d) {
+            const float dov = DO.at(ri, qc + d);
+            sc += Q.at(ri, qc + d) * Q.at(rj, kc + d);
+            dp += dov * Q.at(rj, vc + d);
+            delta += dov * O.at(ri, qc + d);
+        }
+        float pr = expf(sc * p.scale - p.lse[bh * p.N + i]);
+        float dm = 1.f;
+        if (p.drop_thr) dm = drop_keep(dkey, ((unsigned long long)bh * p.N + i) * p.N + j, p.drop_thr) ? p.drop_scale : 0.f;
+        const float ds = pr * (dp * dm - delta) * p.scale;
+        if (KEY_SIDE) {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) {
+                acc0[d] += ds * Q.at(ri, qc + 16 * c + d);               // dK
+                acc1[d] += pr * dm * DO.at(ri, qc + 16 * c + d);        // dV
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc0[d] += ds * Q.at(rj, kc + 16 * c + d);      // dQ
+        }
+    }
+    const long orow = rowof(t) * p.lddq;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        bf16_t hi, lo;
+        if (KEY_SIDE) {
+            split_bf16(acc0[d], hi, lo);
+            p.dqkv[orow + kc + 16 * c + d] = hi; p.dqkv_lo[orow + kc + 16 * c + d] = lo;
+            split_bf16(acc1[d], hi, lo);
+            p.dqkv[orow + vc + 16 * c + d] = hi; p.dqkv_lo[orow + vc + 16 * c + d] = lo;
+        } else {
+            split_bf16(acc0[d], hi, lo);
+            p.dqkv[orow + qc + 16 * c + d] = hi; p.dqkv_lo[orow + qc + 16 * c + d] = lo;
+        }
+    }
+}
+
+int launch_bwd_ref(const AttnArgs& a, hipStream_t s) {
+    S3D_REQUIRE(a.qkv_lo && a.out_lo && a.dout_lo && a.dqkv_lo, "attention_bwd (split precision): qkv_lo, out_lo, dout_lo and dqkv_lo are required");
+    const int hd = a.D / a.H;
+    S3D_REQUIRE(hd % 16 == 0, "attention_bwd (split precision): head dim %d", hd);
+    const long total = (long)a.Bb * a.H * a.N * (hd / 16);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(attn_bwd_ref_kernel<false>, dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_ref_kernel<true>, dim3(grid), dim3(256), 0, s, a);
+    S3D_CHECK_LAUNCH("attention_bwd_ref");
+    return 0;
+}
+
 int check(const AttnArgs& a) {
     S3D_REQUIRE(a.H > 0 && a.D % a.H == 0, "attention: D=%d not divisible by H=%d", a.D, a.H);
     const int hd = a.D / a.H;
@@ -1293,6 +1381,7 @@ int s3d_launch_attention_fwd(const AttnArgs& a0, bool split, hipStream_t s) {
 int s3d_launch_attention_bwd(const AttnArgs& a0, hipStream_t s) {
     if (int e = check(a0)) return e;
     const AttnArgs a = pack_pairs(a0);
+    if (a.dqkv_lo != nullptr) return launch_bwd_ref(a, s);               // parity mode: fp32 reference kernels on hi + lo operands
     S3D_REQUIRE(a.lddo % 8 == 0 && a.lddq % 8 == 0, "attention: leading dims must be multiples of 8");
     switch (a.D / a.H) {
         case 48: return bwd_hd<48, 1>(a, s);

@@ -62,7 +62,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     if (next_ln1_done) *next_ln1_done = false;
     // Fused launches (fused_block.hip): norm1 + qkv + attention per (sample pair, head), norm2 + fc1 + GELU per (64-row band, hidden
     // slice).  Split-bf16 forward of the small-batch shapes only; S3dBlockShape::fuse = -1 keeps the seven-launch sequence.
-    const bool fuse_ok = split && sh.fuse >= 0 && sh.ln_tickets == nullptr && !ln1_done;
+    const bool fuse_ok = split && sh.fuse >= 0 && sh.ln_tickets == nullptr && !ln1_done && a.hpre_lo == nullptr;
     const bool fuse_attn = fuse_ok && s3d_fused_attn_ok(sh.Bb, sh.N, D, sh.H);
     const bool fuse_mlp = fuse_ok && !cls_only && s3d_fused_mlp1_ok(M, D, Hd);
     LnArgs ln;
@@ -122,7 +122,7 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     // 6. h = gelu(xn2 @ W1^T + b1)
     g = gemm_zero();
     g.A_hi = a.xn2_hi; g.A_lo = a.xn2_lo; g.lda = pd; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D;
-    g.M = (int)M2; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.ldaux = ph; g.O_hi = a.hact_hi;
+    g.M = (int)M2; g.N = Hd; g.K = D; g.bias = p.fc1_b; g.aux = a.hpre; g.aux_lo = a.hpre_lo; g.ldaux = ph; g.O_hi = a.hact_hi;
     g.O_lo = split ? a.hact_lo : nullptr; g.ldo = ph;
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_GELU, g, 1, s));
     }
@@ -213,8 +213,76 @@ struct LnPartials {
     }
 };
 
+// Split-precision backward of one block (parity mode, S3dBlockScratch::dx_a_lo): the same chain as block_bwd below -- fc2 dgrad * gelu'
+// -> fc1 dgrad -> norm2 -> proj dgrad -> attention -> qkv dgrad -> norm1, with the four wgrads -- but every GEMM is a three-MFMA split
+// product on hi + lo operands without split-K, the attention backward runs in fp32, and every intermediate gradient is a hi + lo pair.
+int block_bwd_split(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
+                    const S3dBlockScratch& w, hipStream_t s, LnPartials* lp, bool cls_only) {
+    const long M = (long)sh.Bb * sh.N;
+    const int D = sh.D, Hd = sh.hidden;
+    const long M2 = cls_only ? sh.Bb : M;
+    const long pd = cls_only ? (long)sh.N * D : D, ph = cls_only ? (long)sh.N * Hd : Hd;
+    S3D_REQUIRE(w.dx_b_lo && w.dh_lo && w.dqkv_lo && w.datt_lo && a.hpre_lo && a.xn1_lo && a.xn2_lo && a.att_lo && a.hact_lo && a.qkv_lo,
+                "split-precision backward: every lo plane (gradient scratch, saved activations, hpre_lo) is required");
+    if (cls_only) S3D_REQUIRE(w.dx_b_lo_cls && w.datt_lo_cls, "split-precision backward: cls_only_block needs dx_b_lo_cls / datt_lo_cls");
+    float* dxb = cls_only ? w.dx_b_cls : w.dx_b;
+    bf16_t* dxb_hi = cls_only ? w.dx_b_bf_cls : w.dx_b_bf;
+    bf16_t* dxb_lo = cls_only ? w.dx_b_lo_cls : w.dx_b_lo;
+    bf16_t* datt_hi = cls_only ? w.datt_cls : w.datt;
+    bf16_t* datt_lo = cls_only ? w.datt_lo_cls : w.datt_lo;
+    auto wgrad_s = [&](const bf16_t* dy_hi, const bf16_t* dy_lo, int out, long ld_dy, const bf16_t* x_hi, const bf16_t* x_lo, int in, long ld_x,
+                       long rows, float* dW, float* db) {
+        GemmArgs g = wgrad_args(dy_hi, out, x_hi, in, rows, dW, db, ld_dy, ld_x);
+        g.A_lo = dy_lo; g.B_lo = x_lo;
+        return s3d_launch_gemm(true, true, true, EPI_ATOMIC, g, 1, s);
+    };
+    // ---- MLP branch: d(x_out) in dx_a (fp32) / dx_a_bf + dx_a_lo
+    GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)
+    g.A_hi = w.dx_a_bf; g.A_lo = w.dx_a_lo; g.lda = pd; g.B_hi = p.fc2_w_hi; g.B_lo = p.fc2_w_lo; g.ldb = Hd; g.M = (int)M2; g.N = Hd; g.K = D;
+    g.aux = a.hpre; g.aux_lo = a.hpre_lo; g.ldaux = ph; g.O_hi = w.dh; g.O_lo = w.dh_lo; g.ldo = ph;
+    S3D_TRY(s3d_launch_gemm(false, true, true, EPI_DGELU, g, 1, s));
+    S3D_TRY(wgrad_s(w.dx_a_bf, w.dx_a_lo, D, pd, a.hact_hi, a.hact_lo, Hd, ph, M2, gr.fc2_w, gr.fc2_b));
+    g = gemm_zero();            // dxn2 = dh @ W1
+    g.A_hi = w.dh; g.A_lo = w.dh_lo; g.lda = ph; g.B_hi = p.fc1_w_hi; g.B_lo = p.fc1_w_lo; g.ldb = D; g.M = (int)M2; g.N = D; g.K = Hd;
+    g.C = w.dxn; g.ldc = pd;
+    S3D_TRY(s3d_launch_gemm(false, true, true, EPI_F32, g, 1, s));
+    S3D_TRY(wgrad_s(w.dh, w.dh_lo, Hd, ph, a.xn2_hi, a.xn2_lo, D, pd, M2, gr.fc1_w, gr.fc1_b));
+    LnBwdArgs lb;
+    memset(&lb, 0, sizeof(lb));
+    lb.dy = w.dxn; lb.lddy = pd; lb.x = a.x_mid; lb.ldx = pd; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
+    lb.dres = w.dx_a; lb.lddres = pd; lb.dx = dxb; lb.lddx = pd; lb.dx_bf = dxb_hi; lb.dx_bf_lo = dxb_lo; lb.lddxbf = pd;
+    lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M2; lb.D = D;
+    if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    // ---- attention branch: d(x_mid) in dx_b
+    g = gemm_zero();            // datt = dx_mid @ Wproj
+    g.A_hi = dxb_hi; g.A_lo = dxb_lo; g.lda = pd; g.B_hi = p.proj_w_hi; g.B_lo = p.proj_w_lo; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D;
+    g.O_hi = datt_hi; g.O_lo = datt_lo; g.ldo = pd;
+    S3D_TRY(s3d_launch_gemm(false, true, true, EPI_BF16_BIAS, g, 1, s));
+    S3D_TRY(wgrad_s(dxb_hi, dxb_lo, D, pd, a.att_hi, a.att_lo, D, pd, M2, gr.proj_w, gr.proj_b));
+    AttnArgs at;
+    memset(&at, 0, sizeof(at));
+    at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = a.att_lo;
+    at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    at.dout = datt_hi; at.dout_lo = datt_lo; at.lddo = D; at.dqkv = w.dqkv; at.dqkv_lo = w.dqkv_lo; at.lddq = 3 * D; at.delta = w.delta;
+    S3D_TRY(s3d_launch_attention_bwd(at, s));
+    g = gemm_zero();            // dxn1 = dqkv @ Wqkv
+    g.A_hi = w.dqkv; g.A_lo = w.dqkv_lo; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.B_lo = p.qkv_w_lo; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D;
+    g.C = w.dxn; g.ldc = D;
+    S3D_TRY(s3d_launch_gemm(false, true, true, EPI_F32, g, 1, s));
+    S3D_TRY(wgrad_s(w.dqkv, w.dqkv_lo, 3 * D, 3 * D, a.xn1_hi, a.xn1_lo, D, D, M, gr.qkv_w, gr.qkv_b));
+    lb.dy = w.dxn; lb.lddy = D; lb.ldx = D; lb.lddres = D; lb.lddx = D; lb.lddxbf = D; lb.rows = M;
+    lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = dxb; lb.dx = w.dx_a;
+    lb.dx_bf = w.dx_a_bf; lb.dx_bf_lo = w.dx_a_lo; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
+    if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
+    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    return 0;
+}
+
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
               const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false) {
+    if (w.dx_a_lo != nullptr) return block_bwd_split(sh, p, gr, a, w, s, lp, cls_only);
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     // cls_only (see block_fwd): d(x_out) is non-zero at the class rows only and proj / norm2 / mlp are row-local -> their backward

@@ -102,6 +102,11 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * (0.39894228040143268f * e);
 }
 
+// parity mode (split-precision backward): libm erf / exp instead of the 1.5e-7 polynomial and the hardware exponential
+__device__ __forceinline__ float gelu_erf_grad_exact(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * (0.39894228040143268f * expf(-0.5f * x * x));
+}
+
 // counter-based dropout mask (hash of the element index; the oracle evaluates the same function, voxel_oracle.hash_keep_mask)
 __device__ __forceinline__ unsigned long long drop_key(const unsigned long long* seed, int site) {
     return (*seed) * 0x9E3779B97F4A7C15ull + (unsigned long long)site * 0xD1B54A32D192ED03ull + 0x632BE59BD9B4E019ull;

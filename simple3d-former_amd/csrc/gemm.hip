@@ -268,6 +268,12 @@ __device__ __forceinline__ void epilogue_core(const GemmArgs& p, const int m, co
             ax.u[r / 2] = f2bf2(p0, p1); hi.u[r / 2] = h2; lo.u[r / 2] = l2;
         }
         if (p.aux) st_bf<W>(p.aux + (long)m * p.ldaux + n, ax);
+        if (p.aux_lo) {                                 // parity mode: the pre-activation to 16 bits
+            BfVec<W> axl;
+#pragma unroll
+            for (int r = 0; r < W; ++r) axl.h[r] = f2bf((v[r] + bq[r]) - bf2f(ax.h[r]));
+            st_bf<W>(p.aux_lo + (long)m * p.ldaux + n, axl);
+        }
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
         if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
     } else if constexpr (EPI == EPI_RESID) {
@@ -277,8 +283,14 @@ __device__ __forceinline__ void epilogue_core(const GemmArgs& p, const int m, co
         if (p.ln_tickets) st_f32_wt<W>(p.C + (long)m * p.ldc + n, o);     // block-uniform: another workgroup of THIS launch reads it
         else st_f32<W>(p.C + (long)m * p.ldc + n, o);
         if (p.O_hi) {                                   // optional bf16 copy (operand of a following wgrad)
+            if (p.O_lo) {
 #pragma unroll
-            for (int r = 0; r < W; ++r) hi.h[r] = f2bf(o[r]);
+                for (int r = 0; r < W; ++r) split_bf16(o[r], hi.h[r], lo.h[r]);
+                st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
+            } else {
+#pragma unroll
+                for (int r = 0; r < W; ++r) hi.h[r] = f2bf(o[r]);
+            }
             st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
         }
     } else if constexpr (EPI == EPI_TOKEN) {
@@ -295,12 +307,24 @@ __device__ __forceinline__ void epilogue_core(const GemmArgs& p, const int m, co
         for (int r = 0; r < W; ++r) o[r] = v[r] * p.alpha + bq[r];
         st_f32<W>(p.C + (long)m * p.ldc + n, o);
     } else if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) {
+        if (p.aux_lo) {                                 // block-uniform: parity mode (pre-activation and gradient as hi + lo pairs)
+            BfVec<W> axl;
+            ld_bf<W>(axl, p.aux_lo + (long)m * p.ldaux + n);
 #pragma unroll
-        for (int r = 0; r < W; ++r) {
-            const float pre = bf2f(ax_in.h[r]);
-            hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
+            for (int r = 0; r < W; ++r) {
+                const float pre = bf2f(ax_in.h[r]) + bf2f(axl.h[r]);
+                split_bf16((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad_exact(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f), hi.h[r], lo.h[r]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < W; ++r) {
+                const float pre = bf2f(ax_in.h[r]);
+                hi.h[r] = f2bf((EPI == EPI_DGELU) ? v[r] * gelu_erf_grad(pre) : (pre > 0.f ? v[r] * dm[r] : 0.f));
+                lo.h[r] = 0;
+            }
         }
         st_bf<W>(p.O_hi + (long)m * p.ldo + n, hi);
+        if (p.O_lo) st_bf<W>(p.O_lo + (long)m * p.ldo + n, lo);
     }
 }
 
@@ -448,6 +472,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
                     b__.u = va_hi[SET][2 * j + 1];                                        \
                     _Pragma("unroll") for (int i = 0; i < 8; ++i)                         \
                         bsum[j][i] += bf2f(a__.h[i]) + bf2f(b__.h[i]);                    \
+                    if constexpr (SPLIT) {                                                \
+                        a__.u = va_lo[SET][2 * j];                                        \
+                        b__.u = va_lo[SET][2 * j + 1];                                    \
+                        _Pragma("unroll") for (int i = 0; i < 8; ++i)                     \
+                            bsum[j][i] += bf2f(a__.h[i]) + bf2f(b__.h[i]);                \
+                    }                                                                     \
                 }                                                                         \
             }                                                                             \
         }                                                                                 \
@@ -473,6 +503,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, unsigned char* smem
             _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                           \
                 _Pragma("unroll") for (int j = 0; j < FN; ++j) {                                                     \
                     if constexpr (EPI == EPI_ATOMIC) { /* natural order: lanes 0-15 = consecutive n */               \
+                        if constexpr (SPLIT) {                                                                       \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0); \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0); \
+                        }                                                                                            \
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);   \
                     } else { /* swapped order: 4 consecutive n per lane */                                           \
                         if constexpr (SPLIT) {                                                                       \
@@ -1757,7 +1791,11 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
                     "gemm: col_sums needs the forward F32 epilogue on 128x128 tiles (M=%d N=%d; ask s3d_gemm_col_sums_ok)", a.M, a.N);
 
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
-        S3D_REQUIRE(epi == EPI_ATOMIC && !split, "gemm: TN supports only the atomic epilogue");
+        S3D_REQUIRE(epi == EPI_ATOMIC, "gemm: TN supports only the atomic epilogue");
+        if (split) {      // parity mode: three-MFMA split product, one workgroup per output tile (no split-K: a single fp32 add per element)
+            a.kchunk = (a.K + 63) / 64 * 64;
+            return launch_tiles<true, true, true, EPI_ATOMIC>(((long)((a.M + 63) / 64) * ((a.N + 63) / 64) >= 64) ? 1 : 3, a, 1, stream);
+        }
         int kchunk = 0;
         {
             // Long reductions onto a weight matrix with <= 1024 output rows (cfg-3: proj, fc2): 256x128 tiles, eight waves, three
@@ -1804,7 +1842,15 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         return split ? launch_nt<true>(epi, t, a, stream) : launch_nt<false>(epi, t, a, stream);
     }
     if (!ta && tb) {
-        S3D_REQUIRE(!split, "gemm: NN (dgrad) runs in plain bf16");
+        if (split) {      // parity mode: split-precision dgrad on the register-staged kernel
+            const int t = ((long)((a.M + 63) / 64) * ((a.N + 63) / 64) >= 64) ? 1 : 3;
+            switch (epi) {
+                case EPI_F32: return launch_tiles<false, true, true, EPI_F32>(t, a, 1, stream);
+                case EPI_DGELU: return launch_tiles<false, true, true, EPI_DGELU>(t, a, 1, stream);
+                case EPI_BF16_BIAS: return launch_tiles<false, true, true, EPI_BF16_BIAS>(t, a, 1, stream);
+                default: s3d_set_error("gemm: epilogue %d not available for the split-precision NN product", epi); return 2;
+            }
+        }
         static const int dmat = env_int("S3D_GEMM_DMAT");
         static const int dmat_small = env_int("S3D_GEMM_DMAT_SMALL");
         if (dmat_small != 0 && tile == 1 && (a.K & 7) == 0 && (a.N & 7) == 0) {

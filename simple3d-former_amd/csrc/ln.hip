@@ -111,8 +111,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
                             for (int k = 0; k < 4; ++k)
                                 d[k] = drop_keep(key, (unsigned long long)row * p.D + col + k, p.drop_thr) ? d[k] * p.drop_scale : 0.f;
                         }
+                        if (p.dx_bf_lo) {                  // parity mode: the gradient as a hi + lo pair
+                            union { uint2 u; bf16_t h[4]; } ol;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) o.h[k] = f2bf(d[k]);
+                            for (int k = 0; k < 4; ++k) split_bf16(d[k], o.h[k], ol.h[k]);
+                            *reinterpret_cast<uint2*>(p.dx_bf_lo + row * p.lddxbf + col) = ol.u;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) o.h[k] = f2bf(d[k]);
+                        }
                         *reinterpret_cast<uint2*>(p.dx_bf + row * p.lddxbf + col) = o.u;
                     }
                 }

@@ -135,7 +135,7 @@ class ParamArena:
 class _BlockWorkspace:
     """Saved activations of `depth` consecutive blocks on M = Bb*N rows, plus the ctypes act table."""
 
-    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None, cls_only=False, fuse=None):
+    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None, cls_only=False, fuse=None, precise=False):
         M = Bb * N
         ln_fuse = LN_FUSE if ln_fuse is None else bool(ln_fuse)
         fuse = FUSED_BLOCKS if fuse is None else bool(fuse)
@@ -153,13 +153,15 @@ class _BlockWorkspace:
         self.xn2 = torch.empty(depth, 2, M, D, **b16)
         self.hpre = torch.empty(depth, M, hidden, **b16)
         self.hact = torch.empty(depth, 2, M, hidden, **b16)
+        self.hpre_lo = torch.empty(depth, M, hidden, **b16) if precise else None      # split-precision backward: hpre to 16 bits
         self.acts = (L.S3dBlockActs * depth)()
         for i in range(depth):
             L.fill(self.acts[i], x_in=self.x[i], x_mid=self.x_mid[i], x_out=self.x[i + 1],
                    mean1=self.stats[i, 0], rstd1=self.stats[i, 1], mean2=self.stats[i, 2], rstd2=self.stats[i, 3],
                    lse=self.lse[i], xn1_hi=self.xn1[i, 0], xn1_lo=self.xn1[i, 1], qkv_hi=self.qkv[i, 0],
                    qkv_lo=self.qkv[i, 1], att_hi=self.att[i, 0], att_lo=self.att[i, 1], xn2_hi=self.xn2[i, 0],
-                   xn2_lo=self.xn2[i, 1], hpre=self.hpre[i], hact_hi=self.hact[i, 0], hact_lo=self.hact[i, 1])
+                   xn2_lo=self.xn2[i, 1], hpre=self.hpre[i], hact_hi=self.hact[i, 0], hact_lo=self.hact[i, 1],
+                   hpre_lo=self.hpre_lo[i] if precise else None)
         # one ticket per 32-row band: the LayerNorms that follow attn.proj / mlp.fc2 run inside those GEMM launches (left zero)
         self.ln_tickets = torch.zeros((M + 31) // 32 + 8, dtype=torch.int32, device=device)
         self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0,
@@ -192,14 +194,14 @@ def ln_partial_blocks(rows):
 
 
 class _BlockScratch:
-    def __init__(self, M, D, H, hidden, BHN, device, depth=0):
+    def __init__(self, M, D, H, hidden, BHN, device, depth=0, precise=False):
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
         self.dxn = torch.empty(M, D, **f32)
         # dx_a and its bf16 copy share one allocation: the backward starts from "zero except the cls rows", one fill instead of two
-        self._dxa_raw = torch.empty(M * D * 6, dtype=torch.uint8, device=device)
+        self._dxa_raw = torch.empty(M * D * (8 if precise else 6), dtype=torch.uint8, device=device)
         self.dx_a = self._dxa_raw[:M * D * 4].view(torch.float32).view(M, D)
-        self.dx_a_bf = self._dxa_raw[M * D * 4:].view(torch.bfloat16).view(M, D)
+        self.dx_a_bf = self._dxa_raw[M * D * 4:M * D * 6].view(torch.bfloat16).view(M, D)
         self.dx_b = torch.empty(M, D, **f32)
         self.dx_b_bf = torch.empty(M, D, **b16)
         self.dh = torch.empty(M, hidden, **b16)
@@ -210,6 +212,11 @@ class _BlockScratch:
         self.c = L.S3dBlockScratch()
         L.fill(self.c, dxn=self.dxn, dx_a=self.dx_a, dx_b=self.dx_b, dx_a_bf=self.dx_a_bf, dx_b_bf=self.dx_b_bf,
                dh=self.dh, dqkv=self.dqkv, datt=self.datt, delta=self.delta)
+        if precise:            # split-precision backward (S3dBlockScratch::dx_a_lo ...): a lo plane behind every bf16 gradient buffer
+            self.dx_a_lo = self._dxa_raw[M * D * 6:].view(torch.bfloat16).view(M, D)
+            self.dx_b_lo = torch.empty(M, D, **b16); self.dh_lo = torch.empty(M, hidden, **b16)
+            self.dqkv_lo = torch.empty(M, 3 * D, **b16); self.datt_lo = torch.empty(M, D, **b16)
+            L.fill(self.c, dx_a_lo=self.dx_a_lo, dx_b_lo=self.dx_b_lo, dh_lo=self.dh_lo, dqkv_lo=self.dqkv_lo, datt_lo=self.datt_lo)
         self.M, self.D = M, D
         nblk = ln_partial_blocks(M)
         if depth > 0 and nblk > 0:
@@ -218,7 +225,7 @@ class _BlockScratch:
             L.fill(self.c, ln_partial=self.ln_partial, ln_partial_blocks=nblk)
 
 
-def _cls_scratch(base, rows, D, device):
+def _cls_scratch(base, rows, D, device, precise=False):
     """A copy of the S3dBlockScratch table `base` with zero-initialised class-row gradient buffers for a block pass of `rows` rows
     (S3dBlockShape::cls_only_block): only the class rows are ever written, the rest stays zero."""
     c = L.S3dBlockScratch()
@@ -226,6 +233,9 @@ def _cls_scratch(base, rows, D, device):
     bufs = (torch.zeros(rows, D, dtype=torch.float32, device=device), torch.zeros(rows, D, dtype=torch.bfloat16, device=device),
             torch.zeros(rows, D, dtype=torch.bfloat16, device=device))
     L.fill(c, dx_b_cls=bufs[0], dx_b_bf_cls=bufs[1], datt_cls=bufs[2])
+    if precise:
+        bufs += (torch.zeros(rows, D, dtype=torch.bfloat16, device=device), torch.zeros(rows, D, dtype=torch.bfloat16, device=device))
+        L.fill(c, dx_b_lo_cls=bufs[3], datt_lo_cls=bufs[4])
     return c, bufs
 
 
@@ -234,7 +244,8 @@ class VoxelEngine:
     positional embedding (vit_3d_2d_pretrain.py:455-470) and Linear / AM-softmax head."""
 
     def __init__(self, *, backbone, embed_layer, voxel_size, cell, patch, n_classes, pos_embedding='default',
-                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False, ln_fuse=None):
+                 head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False, ln_fuse=None,
+                 precise_backward=False):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
         if pos_embedding not in (None, 'default', 'group_embed'):
@@ -265,6 +276,13 @@ class VoxelEngine:
         self.Kpad = _round_up(self.Kc, 8)
         self.am = head == 'AMSoftmax'
         self.split = bool(split)
+        # Parity mode: the backward (train_cls_voxel.py:287) in split precision -- every dgrad / wgrad a three-MFMA product on hi + lo
+        # operands without split-K, fp32 attention backward, gradients carried as hi + lo pairs -- so that gradients can be held to
+        # ~1e-4 of the reference instead of the plain-bf16 noise floor.  Several times slower; the timm-block path (default positional
+        # embedding) only.  Tests only.
+        self.precise = bool(precise_backward)
+        if self.precise and (pos_embedding == 'group_embed' or image_branch or not split):
+            raise NotImplementedError('precise_backward covers the split-bf16 default-positional-embedding path')
         self.ln_fuse = ln_fuse              # None: S3D_LN_FUSE decides (default off, see LN_FUSE above)
         self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
         self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
@@ -406,11 +424,12 @@ class VoxelEngine:
         ws = type('WS', (), {})()
         ws.B, ws.M, ws.G = B, M, G
         ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
-        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY)
+        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY,
+                                    precise=self.precise)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
-        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth)
-        ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev) if CLS_ONLY else (ws.scratch.c, None)       # scratch table of the (first) pass
+        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth, precise=self.precise)
+        ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev, self.precise) if CLS_ONLY else (ws.scratch.c, None)       # scratch table of the (first) pass
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)
@@ -566,7 +585,7 @@ class VoxelEngine:
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.last.x[self.depth], ldx=nt * D,
                     mean=ws.fstats[0], rstd=ws.fstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=nt * D,
                     dx_bf=sc.dx_a_bf, lddxbf=nt * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
-                    rows=B, D=D)
+                    rows=B, D=D, dx_bf_lo=sc.dx_a_lo if self.precise else None)
         L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'final norm bwd')
         return ws
 
@@ -651,7 +670,9 @@ class VoxelEngine:
             self.conv_gpad.zero_()
         g = L.fill(L.S3dGemmArgs(), A_hi=dx_bf, lda=D, B_hi=ws.a[0], ldb=self.Kpad, M=D, N=self.Kpad, K=ws.M,
                    C=gw, ldc=self.Kpad, alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0))
-        L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), 'tokenizer wgrad')
+        if self.precise:
+            L.fill(g, A_lo=sc.dx_a_lo, B_lo=ws.a[1])
+        L.check(lib.s3d_gemm(1, 1, 1 if self.precise else 0, 6, ctypes.byref(g), 0, s), 'tokenizer wgrad')
         if padded:
             a.grad(ck + '.weight').view(D, self.Kc).add_(self.conv_gpad[:, :self.Kc])
         pg = L.fill(L.S3dPosGradArgs(), dx=dx, groups=ws.G, ntok=self.ntok, D=D,
@@ -699,7 +720,7 @@ class VoxelEngine:
         """model(voxel) + F.cross_entropy for a TRAINING step; with the Linear head (C <= 256, D <= 1024) the loss end runs fused
         (head_loss): the head / final-norm gradients are accumulated right here, so follow it with exactly one backward() (no
         dlogits) -- for inference or custom d(logits) use forward() + cross_entropy()."""
-        if self.am or not FUSE_LOSS_END or self.C > 256 or self.D > 1024:     # s3d_head_loss_fused: Linear head, C <= 256, D <= 1024
+        if self.am or not FUSE_LOSS_END or self.C > 256 or self.D > 1024 or self.precise:     # s3d_head_loss_fused: Linear head, C <= 256, D <= 1024
             self.forward(x)
             return self.cross_entropy(x.shape[0], target, weight)
         self.forward_features(x)
