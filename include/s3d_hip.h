@@ -369,6 +369,7 @@ typedef struct S3dEncActs {      /* M = G*Nb rows */
     float *mean1, *rstd1, *mean2, *rstd2, *lse;    /* [M] x4, [Nb*H*G] */
     uint16_t *xin_hi, *xin_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *x1_hi, *x1_lo;
     uint16_t *fpre, *f_hi, *f_lo;                  /* [M][Dff] */
+    uint16_t* fpre_lo;                             /* optional: low plane of fpre (split-precision backward, see S3dBlockScratch::dx_a_lo) */
 } S3dEncActs;
 int s3d_encoder_layer_fwd(const S3dEncShape* shape, const S3dEncParams* params, const S3dEncActs* acts,
                           s3d_stream_t stream);

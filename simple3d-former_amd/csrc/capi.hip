@@ -376,7 +376,7 @@ int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, h
     S3D_TRY(s3d_launch_ln_fwd(ln, s));
     g = gemm_zero();                                // f = relu(x1 @ W1^T + b1)
     g.A_hi = a.x1_hi; g.A_lo = a.x1_lo; g.lda = D; g.B_hi = p.l1_w_hi; g.B_lo = p.l1_w_lo; g.ldb = D;
-    g.M = (int)M; g.N = F; g.K = D; g.bias = p.l1_b; g.aux = a.fpre; g.ldaux = F; g.O_hi = a.f_hi; g.O_lo = split ? a.f_lo : nullptr; g.ldo = F;
+    g.M = (int)M; g.N = F; g.K = D; g.bias = p.l1_b; g.aux = a.fpre; g.aux_lo = a.fpre_lo; g.ldaux = F; g.O_hi = a.f_hi; g.O_lo = split ? a.f_lo : nullptr; g.ldo = F;
     SET_DROP(g, 2);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RELU, g, 1, s));
     g = gemm_zero();                                // s2 = x1 + drop(f @ W2^T + b2)
@@ -395,44 +395,62 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
     const long M = (long)sh.G * sh.Nb;
     const int D = sh.D, F = sh.Dff;
     const DropCfg dc = drop_cfg(sh);
+    // sp: split-precision parity mode (S3dBlockScratch::dx_a_lo) -- every GEMM a three-MFMA split product on hi + lo operands, no
+    // split-K, fp32 attention backward, gradients as hi + lo pairs; the chain itself is the same
+    const bool sp = w.dx_a_lo != nullptr;
+    if (sp) S3D_REQUIRE(w.dx_b_lo && w.dh_lo && w.dqkv_lo && w.datt_lo && a.fpre_lo && a.xin_lo && a.x1_lo && a.f_lo && a.att_lo && a.qkv_lo,
+                        "split-precision backward of the encoder layer: every lo plane is required");
+    auto wgrad_x = [&](const bf16_t* dy_hi, const bf16_t* dy_lo, int out, const bf16_t* x_hi, const bf16_t* x_lo, int in, float* dW, float* db) {
+        GemmArgs g = wgrad_args(dy_hi, out, x_hi, in, M, dW, db);
+        if (!sp) return s3d_launch_gemm(true, true, false, EPI_ATOMIC, g, 0, s);
+        g.A_lo = dy_lo; g.B_lo = x_lo;
+        return s3d_launch_gemm(true, true, true, EPI_ATOMIC, g, 1, s);
+    };
     LnBwdArgs lb;                                   // ds2 = LN2'(dx_out)            -> dx_b (+bf16, masked by site 3)
     memset(&lb, 0, sizeof(lb));
     SET_DROP(lb, 3);
     lb.dy = w.dx_a; lb.lddy = D; lb.x = a.s2; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.n2_w;
-    lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.lddxbf = D; lb.dgamma = gr.n2_w; lb.dbeta = gr.n2_b; lb.rows = M; lb.D = D;
+    lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = w.dx_b_bf; lb.dx_bf_lo = sp ? w.dx_b_lo : nullptr; lb.lddxbf = D;
+    lb.dgamma = gr.n2_w; lb.dbeta = gr.n2_b; lb.rows = M; lb.D = D;
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
-    S3D_TRY(wgrad(w.dx_b_bf, D, a.f_hi, F, M, gr.l2_w, gr.l2_b, s));
+    S3D_TRY(wgrad_x(w.dx_b_bf, w.dx_b_lo, D, a.f_hi, a.f_lo, F, gr.l2_w, gr.l2_b));
     GemmArgs g = gemm_zero();                       // df = (ds2 @ W2) * relu'(fpre)   -> dh
     g.A_hi = w.dx_b_bf; g.lda = D; g.B_hi = p.l2_w_hi; g.ldb = F; g.M = (int)M; g.N = F; g.K = D;
     g.aux = a.fpre; g.ldaux = F; g.O_hi = w.dh; g.ldo = F;
+    if (sp) { g.A_lo = w.dx_b_lo; g.B_lo = p.l2_w_lo; g.aux_lo = a.fpre_lo; g.O_lo = w.dh_lo; }
     SET_DROP(g, 2);
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DRELU, g, 1, s));
-    S3D_TRY(wgrad(w.dh, F, a.x1_hi, D, M, gr.l1_w, gr.l1_b, s));
+    S3D_TRY(s3d_launch_gemm(false, true, sp, EPI_DRELU, g, 1, s));
+    S3D_TRY(wgrad_x(w.dh, w.dh_lo, F, a.x1_hi, a.x1_lo, D, gr.l1_w, gr.l1_b));
     g = gemm_zero();                                // g1 = df @ W1 + ds2              -> dxn
     g.A_hi = w.dh; g.lda = F; g.B_hi = p.l1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = F; g.R = w.dx_b; g.ldr = D;
     g.C = w.dxn; g.ldc = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_RESID, g, 1, s));
+    if (sp) { g.A_lo = w.dh_lo; g.B_lo = p.l1_w_lo; }
+    S3D_TRY(s3d_launch_gemm(false, true, sp, EPI_RESID, g, 1, s));
     lb.dy = w.dxn; lb.x = a.s1; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.n1_w; lb.dx = w.dx_a; lb.dx_bf = w.dx_a_bf;
+    lb.dx_bf_lo = sp ? w.dx_a_lo : nullptr;
     lb.dgamma = gr.n1_w; lb.dbeta = gr.n1_b;        // ds1 = LN1'(g1)                  -> dx_a (+bf16, masked by site 1)
     SET_DROP(lb, 1);
     S3D_TRY(s3d_launch_ln_bwd(lb, s));
-    S3D_TRY(wgrad(w.dx_a_bf, D, a.att_hi, D, M, gr.out_w, gr.out_b, s));
+    S3D_TRY(wgrad_x(w.dx_a_bf, w.dx_a_lo, D, a.att_hi, a.att_lo, D, gr.out_w, gr.out_b));
     g = gemm_zero();                                // datt = ds1 @ Wo
     g.A_hi = w.dx_a_bf; g.lda = D; g.B_hi = p.out_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_BF16_BIAS, g, 1, s));
+    if (sp) { g.A_lo = w.dx_a_lo; g.B_lo = p.out_w_lo; g.O_lo = w.datt_lo; }
+    S3D_TRY(s3d_launch_gemm(false, true, sp, EPI_BF16_BIAS, g, 1, s));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+    if (sp) { at.dout_lo = w.datt_lo; at.dqkv_lo = w.dqkv_lo; }
     SET_DROP(at, 0);
     S3D_TRY(s3d_launch_attention_bwd(at, s));
-    S3D_TRY(wgrad(w.dqkv, 3 * D, a.xin_hi, D, M, gr.in_w, gr.in_b, s));
+    S3D_TRY(wgrad_x(w.dqkv, w.dqkv_lo, 3 * D, a.xin_hi, a.xin_lo, D, gr.in_w, gr.in_b));
     g = gemm_zero();                                // dx = dqkv @ Win + ds1           -> dx_b (+bf16 copy)
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.in_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.R = w.dx_a; g.ldr = D;
     g.C = w.dx_b; g.ldc = D; g.O_hi = w.dx_b_bf; g.ldo = D;
-    S3D_TRY(s3d_launch_gemm(false, true, false, EPI_RESID, g, 1, s));
+    if (sp) { g.A_lo = w.dqkv_lo; g.B_lo = p.in_w_lo; g.O_lo = w.dx_b_lo; }
+    S3D_TRY(s3d_launch_gemm(false, true, sp, EPI_RESID, g, 1, s));
     return 0;
 }
 

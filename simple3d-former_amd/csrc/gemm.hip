@@ -1848,6 +1848,8 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
                 case EPI_F32: return launch_tiles<false, true, true, EPI_F32>(t, a, 1, stream);
                 case EPI_DGELU: return launch_tiles<false, true, true, EPI_DGELU>(t, a, 1, stream);
                 case EPI_BF16_BIAS: return launch_tiles<false, true, true, EPI_BF16_BIAS>(t, a, 1, stream);
+                case EPI_DRELU: return launch_tiles<false, true, true, EPI_DRELU>(t, a, 1, stream);
+                case EPI_RESID: return launch_tiles<false, true, true, EPI_RESID>(t, a, 1, stream);
                 default: s3d_set_error("gemm: epilogue %d not available for the split-precision NN product", epi); return 2;
             }
         }

@@ -278,11 +278,10 @@ class VoxelEngine:
         self.split = bool(split)
         # Parity mode: the backward (train_cls_voxel.py:287) in split precision -- every dgrad / wgrad a three-MFMA product on hi + lo
         # operands without split-K, fp32 attention backward, gradients carried as hi + lo pairs -- so that gradients can be held to
-        # ~1e-4 of the reference instead of the plain-bf16 noise floor.  Several times slower; the timm-block path (default positional
-        # embedding) only.  Tests only.
+        # ~1e-4 of the reference instead of the plain-bf16 noise floor.  Several times slower.  Tests only.
         self.precise = bool(precise_backward)
-        if self.precise and (pos_embedding == 'group_embed' or image_branch or not split):
-            raise NotImplementedError('precise_backward covers the split-bf16 default-positional-embedding path')
+        if self.precise and (image_branch or not split):
+            raise NotImplementedError('precise_backward covers the split-bf16 voxel path (no image branch)')
         self.ln_fuse = ln_fuse              # None: S3D_LN_FUSE decides (default off, see LN_FUSE above)
         self.conv_key = 'voxel_embed.proj.conv2d_1' if embed_layer == 'VoxelNaiveProjection' else 'voxel_embed.proj.conv3d_1'
         self.shapes = voxel_param_shapes(backbone=backbone, embed_layer=embed_layer, cell=cell, patch=patch,
@@ -433,19 +432,21 @@ class VoxelEngine:
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)
-            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY)
+            ws.blocks2 = _BlockWorkspace(self.depth, B, self.ntok2, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY,
+                                         precise=self.precise)
             ws.M2 = B * self.ntok2
-            ws.sc2, ws._cls2 = _cls_scratch(ws.scratch.c, ws.M2, D, dev) if CLS_ONLY else (ws.scratch.c, None)    # ... of pass 2
+            ws.sc2, ws._cls2 = _cls_scratch(ws.scratch.c, ws.M2, D, dev, self.precise) if CLS_ONLY else (ws.scratch.c, None)    # ... of pass 2
             e = type('ENC', (), {})()
             e.x_in = torch.empty(M, D, **f32); e.s1 = torch.empty(M, D, **f32); e.x1 = torch.empty(M, D, **f32)
             e.s2 = torch.empty(M, D, **f32); e.stats = torch.empty(4, M, **f32)
             e.lse = torch.empty(self.ntok * self.enc_heads * G, **f32)
             e.xin = torch.empty(2, M, D, **b16); e.qkv = torch.empty(2, M, 3 * D, **b16); e.att = torch.empty(2, M, D, **b16)
             e.x1p = torch.empty(2, M, D, **b16); e.fpre = torch.empty(M, D, **b16); e.f = torch.empty(2, M, D, **b16)
+            e.fpre_lo = torch.empty(M, D, **b16) if self.precise else None
             e.acts = L.fill(L.S3dEncActs(), x_in=e.x_in, s1=e.s1, x1=e.x1, s2=e.s2, x_out=ws.blocks.x[0], mean1=e.stats[0],
                             rstd1=e.stats[1], mean2=e.stats[2], rstd2=e.stats[3], lse=e.lse, xin_hi=e.xin[0], xin_lo=e.xin[1],
                             qkv_hi=e.qkv[0], qkv_lo=e.qkv[1], att_hi=e.att[0], att_lo=e.att[1], x1_hi=e.x1p[0], x1_lo=e.x1p[1],
-                            fpre=e.fpre, f_hi=e.f[0], f_lo=e.f[1])
+                            fpre=e.fpre, f_hi=e.f[0], f_lo=e.f[1], fpre_lo=e.fpre_lo)
             e.shape = L.S3dEncShape(G=G, Nb=self.ntok, D=D, H=self.enc_heads, Dff=D, eps=1e-5, split=1 if self.split else 0,
                                     dropout_p=self.dropout_p, seed=self.dropout_seed.data_ptr())
             ws.enc = e
@@ -599,7 +600,7 @@ class VoxelEngine:
                 L.check(self.lib.s3d_encoder_layer_bwd(ctypes.byref(ws.enc.shape), ctypes.byref(self.eparams),
                                                        ctypes.byref(self.egrads), ctypes.byref(ws.enc.acts),
                                                        ctypes.byref(sc.c), L.current_stream()), 'encoder_layer_bwd')
-                self._tokenizer_backward(ws, dx=sc.dx_b, dx_bf=sc.dx_b_bf)
+                self._tokenizer_backward(ws, dx=sc.dx_b, dx_bf=sc.dx_b_bf, dx_lo=sc.dx_b_lo if self.precise else None)
             else:
                 self._tokenizer_backward(ws)
 
@@ -619,7 +620,7 @@ class VoxelEngine:
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dgfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
                     mean=ws.gstats[0], rstd=ws.gstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,
                     dx_bf=sc.dx_a_bf, lddxbf=self.ntok * D, dgamma=a.grad('norm.weight'), dbeta=a.grad('norm.bias'),
-                    rows=ws.G, D=D)
+                    rows=ws.G, D=D, dx_bf_lo=sc.dx_a_lo if self.precise else None)
         L.check(lib.s3d_layernorm_bwd(ctypes.byref(lb), s), 'pass-1 final norm bwd')
 
     def backward(self, B, dlogits=None, *, segments=None, on_segment=None):
@@ -659,9 +660,10 @@ class VoxelEngine:
         L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
                                         ctypes.byref(ws.sc1), first, last, L.current_stream()), 'blocks_bwd')
 
-    def _tokenizer_backward(self, ws, dx=None, dx_bf=None):
+    def _tokenizer_backward(self, ws, dx=None, dx_bf=None, dx_lo=None):
         lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
         dx = sc.dx_a if dx is None else dx
+        dx_lo = (sc.dx_a_lo if self.precise else None) if dx_bf is None else dx_lo
         dx_bf = sc.dx_a_bf if dx_bf is None else dx_bf
         ck = self.conv_key
         padded = self.Kpad != self.Kc
@@ -671,7 +673,7 @@ class VoxelEngine:
         g = L.fill(L.S3dGemmArgs(), A_hi=dx_bf, lda=D, B_hi=ws.a[0], ldb=self.Kpad, M=D, N=self.Kpad, K=ws.M,
                    C=gw, ldc=self.Kpad, alpha=(1.0 / self.P if self.fold_mode == 0 else 1.0))
         if self.precise:
-            L.fill(g, A_lo=sc.dx_a_lo, B_lo=ws.a[1])
+            L.fill(g, A_lo=dx_lo, B_lo=ws.a[1])
         L.check(lib.s3d_gemm(1, 1, 1 if self.precise else 0, 6, ctypes.byref(g), 0, s), 'tokenizer wgrad')
         if padded:
             a.grad(ck + '.weight').view(D, self.Kc).add_(self.conv_gpad[:, :self.Kc])
