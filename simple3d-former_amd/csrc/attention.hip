@@ -1103,7 +1103,14 @@ void set_lds(K kern, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// waves per workgroup of the cooperative long-sequence kernels: S3D_ATTN_COOP_WAVES=4|8
+// waves per workgroup of the cooperative long-sequence kernels: S3D_ATTN_COOP_WAVES=4|8 in the tuning builds (measured and rejected,
+// the hd = 192 / 256 kernels spill at the 256 registers an eight-wave workgroup leaves them); the product library
+// does not even instantiate the eight-wave kernels
+#ifdef S3D_EXPERIMENTAL_TILES
+#define S3D_COOP8(HD) ((HD) <= 192 && coop_waves() == 8)
+#else
+#define S3D_COOP8(HD) false
+#endif
 static int coop_waves() {
     static const int w = s3d_tune_int("S3D_ATTN_COOP_WAVES") == 8 ? 8 : 4;
     return w;
@@ -1112,9 +1119,12 @@ static int coop_waves() {
 template <int HD>
 int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
-    if (use_coop(a.N)) {                                        // long sequences: four query tiles share one key stream
+    // (not at hd = 256: the cooperative forward needs 540 registers there -- 28 B of scratch per lane with, 152 B with the dropout
+    // mask -- and its only user, the 197-token second pass of group_embed, is 0.1 % of the cfg-3 step on the per-wave kernel)
+    if constexpr (HD < 256) if (use_coop(a.N)) {                // long sequences: four query tiles share one key stream
         const int QT = (a.N + 31) / 32;
-        if (HD <= 192 && coop_waves() == 8) {                   // two waves per SIMD (the hd = 256 kernels are register-bound at one)
+#ifdef S3D_EXPERIMENTAL_TILES
+        if (S3D_COOP8(HD)) {                                    // two waves per SIMD (the hd = 256 kernels are register-bound at one)
             dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 7) / 8)));
             if (split) {
                 const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
@@ -1128,6 +1138,7 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
             S3D_CHECK_LAUNCH("attention_fwd_coop8");
             return 0;
         }
+#endif
         dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
         if (split) {
             const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
@@ -1203,11 +1214,14 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     const int KT = (a.N + 31) / 32;
     if (use_coop(a.N)) {
         const int lds = 2 * CoopStage<HD, 2>::BUF_BYTES;
-        if (HD <= 192 && coop_waves() == 8) {
+#ifdef S3D_EXPERIMENTAL_TILES
+        if (S3D_COOP8(HD)) {
             set_lds((attn_bwd_dq_coop_kernel<HD, 8>), lds);
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)));
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 8>), g, dim3(512), lds, s, a);
-        } else {
+        } else
+#endif
+        {
             set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
@@ -1223,23 +1237,28 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
         const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256);
-        if (HD <= 192 && coop_waves() == 8) {
+#ifdef S3D_EXPERIMENTAL_TILES
+        if (S3D_COOP8(HD)) {
             set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), lds);
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)), DSPLIT);
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), g2, dim3(512), lds, s, a);
-        } else {
+        } else
+#endif
+        {
             set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
         }
         S3D_CHECK_LAUNCH("attention_bwd_dkv_coop");
     } else {
+        // the per-wave kernel splits the d range in two from hd = 192 on (one half = 252 registers + 60 B of scratch there)
+        constexpr int DS = HD >= 192 ? 2 : DSPLIT;
         const int lds = wpb * (2 * 32 * HD * 2 + 256);
-        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT>, 4 * (2 * 32 * HD * 2 + 256));
-        set_lds(attn_bwd_dkv_kernel<HD, DSPLIT, true>, 4 * (2 * 32 * HD * 2 + 256));
-        dim3 g2(grid.x, DSPLIT);
-        if (a.seg) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT, true>), g2, dim3(64 * wpb), lds, s, a);
-        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DSPLIT>), g2, dim3(64 * wpb), lds, s, a);
+        set_lds(attn_bwd_dkv_kernel<HD, DS>, 4 * (2 * 32 * HD * 2 + 256));
+        set_lds(attn_bwd_dkv_kernel<HD, DS, true>, 4 * (2 * 32 * HD * 2 + 256));
+        dim3 g2(grid.x, DS);
+        if (a.seg) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DS, true>), g2, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DS>), g2, dim3(64 * wpb), lds, s, a);
         S3D_CHECK_LAUNCH("attention_bwd_dkv");
     }
     return 0;

@@ -1417,13 +1417,17 @@ int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if constexpr (EPI == EPI_RESID)
+        if constexpr (EPI == EPI_RESID && BM * BN <= 128 * 128)
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    if constexpr (EPI == EPI_RESID) {
+    // (the fused-LayerNorm tail is not built for the fat 128x256 tiles: 28 B of scratch per lane there; s3d_gemm_ln_fusable says no)
+    if constexpr (EPI == EPI_RESID && BM * BN <= 128 * 128) {
         if (a.ln_tickets) kern = gemm_nt_dma_kernel<SPLIT, EPI, NS, BK, BM, BN, WM, WN, ILV, true>;
+    } else if (a.ln_tickets) {
+        s3d_set_error("gemm: the fused LayerNorm epilogue is not built for %dx%d tiles", BM, BN);
+        return 2;
     }
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, 1);
     constexpr long long KEY = 300000000000LL + BM * 100000000LL + BN * 100000LL + (SPLIT ? 100 : 0) + EPI;
@@ -1771,6 +1775,8 @@ bool s3d_gemm_ln_fusable(bool split, const GemmArgs& a) {
     if (a.N % 4 != 0 || a.N > 1024 || a.ldc % 4 != 0 || a.drop_thr != 0) return false;
     static const int forced_nt = env_int("S3D_GEMM_NT_TILE"), dma = env_int("S3D_GEMM_DMA"), dma_small = env_int("S3D_GEMM_DMA_SMALL");
     const int tile = forced_nt >= 0 ? forced_nt : s3d_gemm_pick_tile(a.M, a.N, 1, split);
+    if (split && tile == 2 && a.M >= long_rows() && a.K >= 512 && (a.N & 255) == 0 && (long)((a.M + 127) / 128) * (a.N / 256) >= 512)
+        return false;                                   // launch_nt_epi sends these to the fat 128x256 tiles, which carry no LayerNorm tail
     if (tile == 2) return dma != 0 && (a.K & (split ? 31 : 63)) == 0 && (a.N & 7) == 0;
     return split && dma_small != 0 && (a.K & 63) == 0 && (a.N & 7) == 0;
 }
