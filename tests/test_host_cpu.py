@@ -32,6 +32,56 @@ def test_library_exports_every_declared_symbol(built):
         assert built.s3d_sizeof(n.encode()) == ctypes.sizeof(S), n
 
 
+def _gfx950_code_objects(path):
+    """Every gfx950 ELF inside the library's .hip_fatbin section (uncompressed clang offload bundles, one per translation unit)."""
+    import struct
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fb = os.path.join(td, 'fb.bin')
+        subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objcopy', f'--dump-section=.hip_fatbin={fb}', path, os.path.join(td, 'copy.so')], check=True)
+        blob = open(fb, 'rb').read()
+    magic, out, at = b'__CLANG_OFFLOAD_BUNDLE__', [], 0
+    while (at := blob.find(magic, at)) >= 0:
+        n = struct.unpack_from('<Q', blob, at + 24)[0]
+        q = at + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from('<QQQ', blob, q)
+            triple = blob[q + 24:q + 24 + tl].decode()
+            q += 24 + tl
+            if 'gfx950' in triple and size:
+                out.append(blob[at + off:at + off + size])
+        at += 24
+    return out
+
+
+def test_no_kernel_of_the_product_library_uses_scratch(built, tmp_path):
+    """private segment = 0 for every kernel -- a spilling kernel is a design error here
+    (512 registers per lane), and scratch traffic does not show in the algorithmic-bytes accounting of the roofline."""
+    import subprocess
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf'):
+        pytest.skip('no llvm-readelf')
+    objs = _gfx950_code_objects(L.LIB_PATH)
+    assert len(objs) >= 6
+    kernels, bad = 0, []
+    for i, o in enumerate(objs):
+        f = tmp_path / f'co{i}.elf'
+        f.write_bytes(o)
+        notes = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-readelf', '--notes', str(f)], capture_output=True, text=True, check=True).stdout
+        name = None
+        for ln in notes.splitlines():
+            m = re.match(r'\s*\.name:\s+(\S+)', ln)
+            if m and m.group(1).startswith('_Z'):
+                name = m.group(1)
+            m = re.match(r'\s*\.private_segment_fixed_size:\s+(\d+)', ln)
+            if m:
+                kernels += 1
+                if int(m.group(1)):
+                    bad.append((name, int(m.group(1))))
+    assert kernels > 100, kernels
+    assert not bad, bad
+
+
 def test_header_parser_handles_every_struct():
     assert {'S3dGemmArgs', 'S3dAttnArgs', 'S3dBlockActs', 'S3dAdamState'} <= set(L.STRUCTS)
     f = dict(L.S3dGemmArgs._fields_)
