@@ -250,6 +250,14 @@ typedef struct S3dAdamState {
 } S3dAdamState;
 int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, long n, S3dAdamState* state,
                   int zero_grad, s3d_stream_t stream);
+/* The same update in pieces, so that a slice of the arena can be updated as soon as ITS gradients are final -- on a second stream,
+ * beside the rest of loss.backward() (the update streams 36 bytes per parameter from HBM, the small-batch backward chain next to it is
+ * latency-bound): s3d_adam_begin advances the step count / bias corrections once per optimizer.step(); every s3d_adam_apply after
+ * it (any stream ordered behind the begin) updates [p, p + n) exactly as s3d_adam_step does.  g_wire may be null (fp32 gradient) or
+ * the bf16 wire buffer of the slice; max_workgroups <= 0 selects the default grid. */
+int s3d_adam_begin(S3dAdamState* state, s3d_stream_t stream);
+int s3d_adam_apply(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                   const S3dAdamState* state, int zero_grad, int max_workgroups, s3d_stream_t stream);
 /* Data-parallel gradient wire format (replaces DDP's fp32 bucket all-reduce, train_cls_voxel.py:155-159,287, by half the bytes
  * on xGMI): s3d_pack_bf16 rounds a finished gradient bucket to bf16 (rne; n % 8 == 0), the bf16 buffer is sum-all-reduced, and
  * s3d_adam_step_wire takes the gradient from it (g is only zeroed).  The averaging stays in S3dAdamState::grad_scale. */

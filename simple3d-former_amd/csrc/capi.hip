@@ -565,6 +565,15 @@ int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, flo
     S3D_REQUIRE(g_wire != nullptr, "s3d_adam_step_wire: the bf16 gradient buffer is required");
     return s3d_launch_adam(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, st(s));
 }
+int s3d_adam_begin(S3dAdamState* state, s3d_stream_t s) {
+    S3D_REQUIRE(state != nullptr, "s3d_adam_begin: null state");
+    return s3d_launch_adam_begin(state, st(s));
+}
+int s3d_adam_apply(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                   const S3dAdamState* state, int zero_grad, int max_workgroups, s3d_stream_t s) {
+    S3D_REQUIRE(p && g && m && v && hi && lo && state, "s3d_adam_apply: null pointer");
+    return s3d_launch_adam_apply(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, max_workgroups, st(s));
+}
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
 
 // ---- events recorded INSIDE a stream capture as external event-record nodes (see s3d_hip.h)

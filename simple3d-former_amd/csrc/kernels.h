@@ -40,6 +40,9 @@ int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s);
 
 // ---- fused Adam over a flat fp32 arena (+ split-bf16 shadow planes) ----
 typedef S3dAdamState AdamState;
+int s3d_launch_adam_begin(AdamState* st, hipStream_t s);
+int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, const AdamState* st,
+                          int zero_grad, const bf16_t* g_wire, int max_blocks, hipStream_t s);
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
                     int zero_grad, const bf16_t* g_wire, hipStream_t s);
 int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);

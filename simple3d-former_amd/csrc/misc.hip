@@ -541,15 +541,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     // thing this 0.8 GB stream leaves in the 256 MB Infinity Cache -- where the next step's forward looks for them first
     for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long)gridDim.x * 256) {
         const long i = n4 - 1 - j;
-        float4 P = reinterpret_cast<float4*>(p)[i], G;
+        const f32x4 Pn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
+        float4 P = make_float4(Pn[0], Pn[1], Pn[2], Pn[3]), G;
         if (gw) {                                       // bf16 wire format: the all-reduced gradient arrives as bf16 (uniform branch)
             union { uint2 u; bf16_t h[4]; } W;
             W.u = reinterpret_cast<const uint2*>(gw)[i];
             G = make_float4(bf2f(W.h[0]), bf2f(W.h[1]), bf2f(W.h[2]), bf2f(W.h[3]));
         } else {
-            G = reinterpret_cast<float4*>(g)[i];
+            const f32x4 Gn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+            G = make_float4(Gn[0], Gn[1], Gn[2], Gn[3]);
         }
-        float4 M = reinterpret_cast<float4*>(m)[i], Vv = reinterpret_cast<float4*>(v)[i];
+        const f32x4 Mn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
+        const f32x4 Vn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
+        float4 M = make_float4(Mn[0], Mn[1], Mn[2], Mn[3]), Vv = make_float4(Vn[0], Vn[1], Vn[2], Vn[3]);
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gs, G.y * gs, G.z * gs, G.w * gs};
         float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
         union { uint2 u; bf16_t h[4]; } H, L;
@@ -561,10 +565,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
             pp[k] -= step_size * (mm[k] / denom);
             split_bf16(pp[k], H.h[k], L.h[k]);
         }
-        reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-        if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // p / m / v / g are touched once per step: non-temporal, so that the 0.7 GB they stream does not push the weight planes and
+        // the saved activations out of L2 / the Infinity Cache
+        __builtin_nontemporal_store(f32x4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f32x4*>(p) + i);
+        __builtin_nontemporal_store(f32x4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(m) + i);
+        __builtin_nontemporal_store(f32x4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(v) + i);
+        if (zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g) + i);
         if (hi) reinterpret_cast<uint2*>(hi)[i] = H.u;
         if (lo) reinterpret_cast<uint2*>(lo)[i] = L.u;
     }
@@ -686,15 +692,27 @@ int s3d_launch_head_loss(const S3dHeadLossArgs& a, hipStream_t s) {
     return 0;
 }
 
-int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
-                    int zero_grad, const bf16_t* g_wire, hipStream_t s) {
-    S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
+int s3d_launch_adam_begin(AdamState* st, hipStream_t s) {
     hipLaunchKernelGGL(adam_prelude_kernel, dim3(1), dim3(1), 0, s, st);
+    S3D_CHECK_LAUNCH("adam prelude");
+    return 0;
+}
+int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, const AdamState* st,
+                          int zero_grad, const bf16_t* g_wire, int max_blocks, hipStream_t s) {
+    S3D_REQUIRE(n % 4 == 0, "adam: slice length %ld must be a multiple of 4", n);
+    if (n == 0) return 0;
     long blocks = (n / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const long cap = max_blocks > 0 ? max_blocks : 2048;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire);
     S3D_CHECK_LAUNCH("adam");
     return 0;
+}
+int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
+                    int zero_grad, const bf16_t* g_wire, hipStream_t s) {
+    S3D_REQUIRE(n % 4 == 0, "adam: arena length %ld must be a multiple of 4", n);
+    if (int rc = s3d_launch_adam_begin(st, s)) return rc;
+    return s3d_launch_adam_apply(p, g, m, v, hi, lo, n, st, zero_grad, g_wire, 0, s);
 }
 
 // fp32 -> bf16 (rne), 8 elements per thread: the gradient wire format of the data-parallel trainer

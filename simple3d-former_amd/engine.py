@@ -180,6 +180,12 @@ FUSED_BLOCKS = os.environ.get('S3D_FUSED_BLOCKS', '1') != '0'
 # The last block's output is consumed at the class-token rows only (norm(x)[:, 0]): its row-local tail (proj, norm2, mlp) and their
 # backward run on those rows alone (S3dBlockShape::cls_only_block).  S3D_CLS_ONLY=0: dense, as the reference computes it.
 CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
+# Adam beside the backward (VoxelEngine.update_slices): the arena is updated in this many slices, each on a second stream as soon
+# as the backward segment that finishes its gradients has been enqueued (train_step only; 0 = one update after the whole backward).
+# Measured and NOT the default: the batch-64 step lives in L2 / the Infinity Cache, and the 0.7 GB
+# the update streams beside the backward chain slows that chain by more than the update takes (cfg-2: 1.85 -> 1.96 - 2.25 ms).
+UPDATE_OVERLAP = int(os.environ.get('S3D_UPDATE_OVERLAP', '0'))
+UPDATE_WORKGROUPS = int(os.environ.get('S3D_UPDATE_WORKGROUPS', '0'))
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
 
@@ -698,6 +704,18 @@ class VoxelEngine:
                                                 L.current_stream()), 'adam (bf16 wire)')
         self._refresh_conv_planes()
 
+    def adam_begin(self):
+        """optimizer.step() bookkeeping (step count, bias corrections) once per step; adam_apply slices follow it."""
+        L.check(self.lib.s3d_adam_begin(L.ptr(self.adam_state), L.current_stream()), 'adam begin')
+
+    def adam_apply(self, start, end, zero_grad=True, max_workgroups=0):
+        """Adam on the arena slice [start, end) on the current stream (gradients of the slice must be final there)."""
+        a = self.arena
+        off = lambda t, b: ctypes.c_void_p(t.data_ptr() + b * start)
+        L.check(self.lib.s3d_adam_apply(off(a.p, 4), off(a.g, 4), None, off(a.m, 4), off(a.v, 4), off(a.hi, 2), off(a.lo, 2),
+                                        ctypes.c_long(end - start), L.ptr(self.adam_state), 1 if zero_grad else 0,
+                                        int(max_workgroups), L.current_stream()), 'adam slice')
+
     def pack_grads(self, start, end, wire):
         """gradient arena [start, end) -> bf16 wire buffer [start, end) (round to nearest even), on the current stream."""
         a = self.arena
@@ -714,8 +732,25 @@ class VoxelEngine:
         B = x.shape[0]
         self.advance_dropout_seed()                       # fresh masks every step (device-side, graph-replay safe)
         loss = self.forward_loss(x, target, weight)
-        self.backward(B)
-        self.adam_step(zero_grad=True)
+        n_slices = getattr(self, 'update_slices', UPDATE_OVERLAP)
+        if n_slices <= 0 or self.precise:
+            self.backward(B)
+            self.adam_step(zero_grad=True)
+            return loss
+        main = torch.cuda.current_stream()
+        if getattr(self, '_update_stream', None) is None:
+            self._update_stream = torch.cuda.Stream()
+        side = self._update_stream
+        self.adam_begin()
+        segs, slices = self.grad_buckets(n_slices)
+
+        def update_slice(i):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self.adam_apply(*slices[i], max_workgroups=UPDATE_WORKGROUPS)
+        self.backward(B, segments=segs, on_segment=update_slice)
+        main.wait_stream(side)
+        self._refresh_conv_planes()
         return loss
 
     def forward_loss(self, x, target, weight=None):
@@ -746,7 +781,7 @@ class VoxelEngine:
 
     def capture_train_step(self, B, weight=None):
         """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""
-        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p)     # model.train() / .eval() toggles keep both captures
+        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p, getattr(self, 'update_slices', UPDATE_OVERLAP))     # model.train() / .eval() toggles keep both captures
         if key in self._graphs:
             return self._graphs[key]
         sx = torch.zeros(B, 1, self.V, self.V, self.V, dtype=torch.float32, device=self.device)

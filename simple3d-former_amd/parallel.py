@@ -175,6 +175,13 @@ class DataParallelTrainer:
             self._guarded_first_replay(g, state)
             return self._cap
         self._release_events()
+        if self.collectives_mode() == 'none' and self.wire is None:
+            # one replica, nothing to reduce: the engine's own step (with its update-beside-backward schedule) as ONE graph
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.train_step(sx, sy, weight)
+            self._cap = dict(B=B, graphs=[g], opt=None, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
+            return self._cap
         if self.event_graph:
             import ctypes
             from . import _lib as L
@@ -281,7 +288,8 @@ class DataParallelTrainer:
             g.replay()
             self.reducer.launch(k)          # RCCL all-reduce of bucket k overlaps the next segment's replay
         self.reducer.wait()
-        cap['opt'].replay()
+        if cap['opt'] is not None:
+            cap['opt'].replay()
         return cap['loss'][0]
 
     def step(self, x, y, weight=None):

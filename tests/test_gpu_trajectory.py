@@ -46,6 +46,32 @@ def test_deterministic_mode_makes_the_training_step_bitwise_reproducible(determi
     assert torch.equal(runs[0][1], runs[1][1]), 'parameters differ between two identical runs'
 
 
+def test_update_in_slices_beside_the_backward_equals_the_single_update(deterministic):
+    """s3d_adam_begin + s3d_adam_apply per arena slice on a second stream (VoxelEngine.update_slices) == one s3d_adam_step behind
+    the backward, bit for bit, eagerly and as a captured graph."""
+    sd = vo.init_state_dict(seed=9, exercise_all=True, **KW)
+    x, y = vo.synthetic_batch(8, 32, 40, seed=11)
+    x, y = x.to(DEV), y.to(DEV)
+    runs = []
+    for slices, graph in ((0, False), (3, False), (4, True)):
+        eng = _engine(sd)
+        eng.update_slices = slices
+        if graph:
+            g, sx, sy, loss = eng.capture_train_step(8)
+            sx.copy_(x); sy.copy_(y)
+            losses = []
+            for _ in range(5):
+                g.replay()
+                losses.append(float(loss))
+        else:
+            losses = [float(eng.train_step(x, y)) for _ in range(5)]
+        torch.cuda.synchronize()
+        runs.append((losses, eng.arena.p.clone(), eng.arena.hi.clone(), eng.arena.g.clone()))
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        assert torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and not r[3].any()
+
+
 def test_fifty_step_trajectory_tracks_the_oracle(deterministic):
     steps, B, nb = 50, 8, 5
     sd = vo.init_state_dict(seed=9, **KW)                       # the reference's own initialisation
