@@ -135,8 +135,16 @@ class ParamArena:
 class _BlockWorkspace:
     """Saved activations of `depth` consecutive blocks on M = Bb*N rows, plus the ctypes act table."""
 
-    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None, cls_only=False, fuse=None, precise=False):
+    def __init__(self, depth, Bb, N, D, H, hidden, device, split, ln_fuse=None, cls_only=False, fuse=None, precise=False,
+                 shared_lo=None):
+        """shared_lo (default: unless precise): the low planes of xn1 / qkv / xn2 / hact feed the NEXT forward launch's split product
+        and nothing else (the backward reads the high planes; att_lo stays per block, the attention backward's delta reads it), so
+        every block writes them to the same buffers instead of to `depth` of them -- 11.5 MB per cfg-2 block that would otherwise travel through L2 and the Infinity Cache to HBM once,
+        pushing out the saved activations the backward is about to read (the batch-64 step is cache-resident: DESIGN section 6)."""
         M = Bb * N
+        shared_lo = (not precise and os.environ.get('S3D_SHARED_LO', '1') != '0') if shared_lo is None else bool(shared_lo)
+        self.shared_lo = shared_lo
+        nlo = 1 if shared_lo else depth
         ln_fuse = LN_FUSE if ln_fuse is None else bool(ln_fuse)
         fuse = FUSED_BLOCKS if fuse is None else bool(fuse)
         self.cls_only = bool(cls_only)
@@ -147,20 +155,21 @@ class _BlockWorkspace:
         self.x_mid = [torch.empty(M, D, **f32) for _ in range(depth)]
         self.stats = torch.empty(depth, 4, M, **f32)
         self.lse = torch.empty(depth, Bb * H * N, **f32)
-        self.xn1 = torch.empty(depth, 2, M, D, **b16)
-        self.qkv = torch.empty(depth, 2, M, 3 * D, **b16)
-        self.att = torch.empty(depth, 2, M, D, **b16)
-        self.xn2 = torch.empty(depth, 2, M, D, **b16)
+        self.xn1, self.xn1_lo = torch.empty(depth, M, D, **b16), torch.empty(nlo, M, D, **b16)
+        self.qkv, self.qkv_lo = torch.empty(depth, M, 3 * D, **b16), torch.empty(nlo, M, 3 * D, **b16)
+        self.att, self.att_lo = torch.empty(depth, M, D, **b16), torch.empty(depth, M, D, **b16)       # delta = sum(dO * (O_hi + O_lo)) reads att_lo
+        self.xn2, self.xn2_lo = torch.empty(depth, M, D, **b16), torch.empty(nlo, M, D, **b16)
         self.hpre = torch.empty(depth, M, hidden, **b16)
-        self.hact = torch.empty(depth, 2, M, hidden, **b16)
+        self.hact, self.hact_lo = torch.empty(depth, M, hidden, **b16), torch.empty(nlo, M, hidden, **b16)
         self.hpre_lo = torch.empty(depth, M, hidden, **b16) if precise else None      # split-precision backward: hpre to 16 bits
         self.acts = (L.S3dBlockActs * depth)()
         for i in range(depth):
+            j = 0 if shared_lo else i
             L.fill(self.acts[i], x_in=self.x[i], x_mid=self.x_mid[i], x_out=self.x[i + 1],
                    mean1=self.stats[i, 0], rstd1=self.stats[i, 1], mean2=self.stats[i, 2], rstd2=self.stats[i, 3],
-                   lse=self.lse[i], xn1_hi=self.xn1[i, 0], xn1_lo=self.xn1[i, 1], qkv_hi=self.qkv[i, 0],
-                   qkv_lo=self.qkv[i, 1], att_hi=self.att[i, 0], att_lo=self.att[i, 1], xn2_hi=self.xn2[i, 0],
-                   xn2_lo=self.xn2[i, 1], hpre=self.hpre[i], hact_hi=self.hact[i, 0], hact_lo=self.hact[i, 1],
+                   lse=self.lse[i], xn1_hi=self.xn1[i], xn1_lo=self.xn1_lo[j], qkv_hi=self.qkv[i],
+                   qkv_lo=self.qkv_lo[j], att_hi=self.att[i], att_lo=self.att_lo[i], xn2_hi=self.xn2[i],
+                   xn2_lo=self.xn2_lo[j], hpre=self.hpre[i], hact_hi=self.hact[i], hact_lo=self.hact_lo[j],
                    hpre_lo=self.hpre_lo[i] if precise else None)
         # one ticket per 32-row band: the LayerNorms that follow attn.proj / mlp.fc2 run inside those GEMM launches (left zero)
         self.ln_tickets = torch.zeros((M + 31) // 32 + 8, dtype=torch.int32, device=device)

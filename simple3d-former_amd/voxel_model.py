@@ -123,7 +123,9 @@ def _fire_attention_hooks(model, bw):
         if not hooks:
             continue
         with torch.no_grad():
-            xn = (bw.xn1[i, 0].float() + bw.xn1[i, 1].float()).view(bw.Bb, bw.N, -1)
+            # norm1(x) recomputed from the saved fp32 block input (the engine keeps only the bf16 high plane per block)
+            xn = torch.nn.functional.layer_norm(bw.x[i], (bw.x[i].shape[-1],), blk.norm1.weight, blk.norm1.bias,
+                                                blk.norm1.eps).view(bw.Bb, bw.N, -1)
             out = (bw.x_mid[i] - bw.x[i]).view(bw.Bb, bw.N, -1)
         for h in hooks:
             h(blk.attn, (xn,), out)

@@ -518,8 +518,8 @@ def test_fused_block_launches_equal_the_seven_launch_sequence(D, H, N, Bb, depth
     x = torch.randn(M, D, generator=g)
     runs = {}
     for fuse in (False, True, True):
-        ws = _BlockWorkspace(depth, Bb, N, D, H, Hd, DEV, True, fuse=fuse)
-        for t in (ws.stats, ws.lse, ws.xn1, ws.qkv, ws.att, ws.xn2, ws.hpre, ws.hact):
+        ws = _BlockWorkspace(depth, Bb, N, D, H, Hd, DEV, True, fuse=fuse, shared_lo=False)
+        for t in (ws.stats, ws.lse, ws.xn1, ws.xn1_lo, ws.qkv, ws.att, ws.att_lo, ws.xn2, ws.xn2_lo, ws.hpre, ws.hact, ws.hact_lo):
             t.fill_(float('nan'))                                       # whatever the backward reads must have been written
         ws.x[0].copy_(x)
         L.check(L.lib().s3d_blocks_fwd(ctypes.byref(ws.shape), bp, ws.acts, depth, L.current_stream()), 'blocks_fwd')
@@ -545,14 +545,14 @@ def test_fused_block_launches_equal_the_seven_launch_sequence(D, H, N, Bb, depth
         close32(got.x_mid[i], ref.x_mid[i], f'x_mid[{i}]')
         close32(got.stats[i], ref.stats[i], f'mean / rstd [{i}]')
         close32(got.lse[i], ref.lse[i], f'lse[{i}]')
-        close16(got.xn1[i, 0], ref.xn1[i, 0], 'xn1_hi'); close16(got.xn2[i, 0], ref.xn2[i, 0], 'xn2_hi')
-        close32(got.xn1[i, 0].float() + got.xn1[i, 1].float(), ref.xn1[i, 0].float() + ref.xn1[i, 1].float(), 'xn1 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
-        close32(got.xn2[i, 0].float() + got.xn2[i, 1].float(), ref.xn2[i, 0].float() + ref.xn2[i, 1].float(), 'xn2 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
-        close16(got.qkv[i, 0], ref.qkv[i, 0], 'qkv_hi'); close16(got.att[i, 0], ref.att[i, 0], 'att_hi')
-        close32(got.att[i, 0].float() + got.att[i, 1].float(), ref.att[i, 0].float() + ref.att[i, 1].float(), 'att hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
-        close16(got.hpre[i], ref.hpre[i], 'hpre'); close16(got.hact[i, 0], ref.hact[i, 0], 'hact_hi')
-        close32(got.hact[i, 0].float() + got.hact[i, 1].float(), ref.hact[i, 0].float() + ref.hact[i, 1].float(), 'hact hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
-        assert torch.equal(got.x[i + 1], again.x[i + 1]) and torch.equal(got.hact[i], again.hact[i]) and torch.equal(got.att[i], again.att[i])
+        close16(got.xn1[i], ref.xn1[i], 'xn1_hi'); close16(got.xn2[i], ref.xn2[i], 'xn2_hi')
+        close32(got.xn1[i].float() + got.xn1_lo[i].float(), ref.xn1[i].float() + ref.xn1_lo[i].float(), 'xn1 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close32(got.xn2[i].float() + got.xn2_lo[i].float(), ref.xn2[i].float() + ref.xn2_lo[i].float(), 'xn2 hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close16(got.qkv[i], ref.qkv[i], 'qkv_hi'); close16(got.att[i], ref.att[i], 'att_hi')
+        close32(got.att[i].float() + got.att_lo[i].float(), ref.att[i].float() + ref.att_lo[i].float(), 'att hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        close16(got.hpre[i], ref.hpre[i], 'hpre'); close16(got.hact[i], ref.hact[i], 'hact_hi')
+        close32(got.hact[i].float() + got.hact_lo[i].float(), ref.hact[i].float() + ref.hact_lo[i].float(), 'hact hi + lo', rel=2e-5)        # the split itself resolves 2^-16 of the value
+        assert torch.equal(got.x[i + 1], again.x[i + 1]) and torch.equal(got.hact[i], again.hact[i]) and torch.equal(got.hact_lo[i], again.hact_lo[i]) and torch.equal(got.att[i], again.att[i])
 
 
 @pytest.mark.parametrize('D,G,Nb', [(192, 27, 4), (768, 40, 15), (384, 50, 6)])

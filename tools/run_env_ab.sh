@@ -6,6 +6,6 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 for i in 1 2 3; do
   for spec in "$@"; do
     label=${spec%%:*}; envs=${spec#*:}
-    ( IFS=,; for kv in $envs; do export "$kv"; done; python bench.py ${CFG:+--config $CFG} ${STEPS} --no-cpu-baseline --no-roofline 2>/dev/null | line "$label" )
+    ( IFS=,; for kv in $envs; do export "$kv"; done; unset IFS; python bench.py ${CFG:+--config $CFG} ${STEPS} --no-cpu-baseline --no-roofline 2>/dev/null | line "$label" )
   done
 done

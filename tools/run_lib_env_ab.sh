@@ -6,7 +6,7 @@ line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split
 for i in 1 2 3; do
   for spec in "$@"; do
     label=${spec%%:*}; envs=${spec#*:}
-    ( IFS=,; for kv in $envs; do export "$kv"; done
+    ( IFS=,; for kv in $envs; do export "$kv"; done; unset IFS
       S3D_LIB_PATH=$PWD/simple3d-former_amd/libs3d_hip_prev.so python bench.py ${CFG:+--config $CFG} ${STEPS} --no-cpu-baseline --no-roofline 2>/dev/null | line "prev $label"
       python bench.py ${CFG:+--config $CFG} ${STEPS} --no-cpu-baseline --no-roofline 2>/dev/null | line "new  $label" )
   done
