@@ -158,7 +158,7 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
             *reinterpret_cast<u32x4*>(at) = hi;
             *reinterpret_cast<u32x4*>(at + FB_APLANE) = lo;
             if (kp == kp_store && xn_hi != nullptr) {                      // block-uniform on kp_store, per-thread on the pointer
-                *reinterpret_cast<u32x4*>(xn_hi) = hi;
+                __builtin_nontemporal_store(hi, reinterpret_cast<u32x4*>(xn_hi));     // read next by the backward (wgrad operand)
                 *reinterpret_cast<u32x4*>(xn_lo) = lo;
             }
         }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
         const int sb = tile / 3, which = tile % 3, bb = 2 * pr + sb;
         if (bb < p.Bb && t < p.N) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + (tile * 2) * TILE + (t * QKV_PITCH + 8 * ch) * 2);
-            *reinterpret_cast<u32x4*>(p.qkv_hi + ((long)bb * p.N + t) * (3 * D) + which * D + 64 * h + 8 * ch) = v;
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.qkv_hi + ((long)bb * p.N + t) * (3 * D) + which * D + 64 * h + 8 * ch));
         }
     }
     // ---- attention: wave w < 2 owns sample w.  S^T = K Q^T on 32x32x16 MFMAs (every lane owns one query column), one key tile
@@ -405,7 +405,8 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
         if (r < RB && m0 + r < p.M) {
             const u32x4 v = *reinterpret_cast<const u32x4*>(smem + arr * TILE + (r * H_PITCH + 8 * ch) * 2);
             bf16_t* const out = arr == 0 ? p.hpre : arr == 1 ? p.hact_hi : p.hact_lo;
-            *reinterpret_cast<u32x4*>(out + (m0 + r) * p.hidden + FB_WROWS * js + 8 * ch) = v;
+            u32x4* const dst = reinterpret_cast<u32x4*>(out + (m0 + r) * p.hidden + FB_WROWS * js + 8 * ch);
+            if (arr == 0) __builtin_nontemporal_store(v, dst); else *dst = v;      // hpre: read next by the backward
         }
     }
 }

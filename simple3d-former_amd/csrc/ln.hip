@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
             for (int c = 0; c < MC; ++c) {
                 const int col = min(c * 256 + lane * 4, p.D - 4);
                 if (c < nchunk) {
-                    X[i][c] = *reinterpret_cast<const float4*>(p.x + row * p.ldx + col);
+                    {   // the saved block input is dead after this read: non-temporal, so that it does not outlive live data in L2
+                        const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.x + row * p.ldx + col));
+                        X[i][c] = make_float4(t[0], t[1], t[2], t[3]);
+                    }
                     DY[i][c] = *reinterpret_cast<const float4*>(p.dy + row * p.lddy + col);
                     R[i][c] = p.dres ? *reinterpret_cast<const float4*>(p.dres + row * p.lddres + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
