@@ -514,11 +514,14 @@ __global__ __launch_bounds__(256) void head_loss_reduce_kernel(const S3dHeadLoss
         else if (idx < nw + C + D) { if (p.dgamma) p.dgamma[idx - nw - C] += t; }
         else { if (p.dbeta) p.dbeta[idx - nw - C - D] += t; }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {      // the loss: B per-sample shares, added in order
-        float a = 0.f, den = (float)B;
-        for (int bb = 0; bb < B; ++bb) a += p.scratch[bb * st + 2 * D];
-        if (p.weight) { den = 0.f; for (int bb = 0; bb < B; ++bb) den += p.weight[p.target[bb]]; }
-        p.loss[0] = a; p.loss[1] = den;
+    if (blockIdx.x == gridDim.x - 1 && wave == 3) {      // the loss: B per-sample shares; lane-strided partials + a fixed butterfly
+        float a = 0.f, dn = 0.f;                           // (deterministic; one load per lane instead of a B-deep latency chain)
+        for (int bb = lane; bb < B; bb += 64) {
+            a += p.scratch[bb * st + 2 * D];
+            if (p.weight) dn += p.weight[p.target[bb]];
+        }
+        a = wave_sum(a); dn = wave_sum(dn);
+        if (lane == 0) { p.loss[0] = a; p.loss[1] = p.weight ? dn : (float)B; }
     }
 }
 

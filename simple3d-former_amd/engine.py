@@ -191,8 +191,9 @@ FUSED_BLOCKS = os.environ.get('S3D_FUSED_BLOCKS', '1') != '0'
 CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
 # Adam beside the backward (VoxelEngine.update_slices): the arena is updated in this many slices, each on a second stream as soon
 # as the backward segment that finishes its gradients has been enqueued (train_step only; 0 = one update after the whole backward).
-# Measured and NOT the default: the batch-64 step lives in L2 / the Infinity Cache, and the 0.7 GB
-# the update streams beside the backward chain slows that chain by more than the update takes (cfg-2: 1.85 -> 1.96 - 2.25 ms).
+# Measured and NOT the default: every node of a captured graph that lies in a region with two live
+# branches costs ~2.8 us more on this runtime (cfg-2: 1.85 -> 1.96 - 2.25 ms; the same with only ~25 us of small tail launches on the
+# second branch: 1.75 -> 2.17 ms), far more than the update's 0.13 ms.  A captured step has to stay ONE chain.
 UPDATE_OVERLAP = int(os.environ.get('S3D_UPDATE_OVERLAP', '0'))
 UPDATE_WORKGROUPS = int(os.environ.get('S3D_UPDATE_WORKGROUPS', '0'))
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches

@@ -32,6 +32,10 @@ from .engine import BACKBONES, LN_EPS, ParamArena, _BlockScratch, _BlockWorkspac
 KNN = 16
 BN_EPS = 1e-5
 GEOM_STREAM = os.environ.get('S3D_POINT_GEOM_STREAM', '1') != '0'    # geometry chain on a side stream (see PointEngine._geometry)
+# capture_train_step_pipelined: geometry and training step as TWO graphs replayed on two streams instead of one graph with a side
+# branch -- on this runtime a captured graph with two live branches anywhere runs ALL of its nodes in a slower mode (+1.2 us per
+# node on a chain of empty kernels, tools/probes/graph_branch_probe.py), a graph that is one dependency chain does not
+TWO_CHAINS = os.environ.get('S3D_POINT_TWO_CHAINS', '1') != '0'
 
 # levels: TransitionDown/Up pairs; first_div: td 0 keeps N / first_div points (models/3DViT/model.py:242 `npoints // 4 ** i`,
 # the variants `npoints // 4 ** (i + 1)`, 3DViT_1_layer/model.py:231); head: key of the point head; image: forward_images exists.
@@ -225,6 +229,23 @@ class _BatchNorm:
         args = self._args(x, rows, K, lddy=self.C, dx=dx, lddx=self.C, arg=arg, dgamma=a.grad(self.key + '.weight'),
                           dbeta=a.grad(self.key + '.bias'), sums=self.sums_b, **gkw)
         L.check(self.eng.lib.s3d_batchnorm_bwd(ctypes.byref(args), L.current_stream()), self.key + ' bwd')
+
+
+class _TwoChainStep:
+    """graphs[p] of PointEngine.capture_train_step_pipelined: replay() launches the geometry graph (next batch -> the other
+    geometry set) on the geometry stream and the training-step graph (this batch, this set) on the current stream.  Each is one
+    dependency chain; they overlap as two graph launches, ordered against each other at their boundaries only."""
+
+    def __init__(self, geometry, step, stream):
+        self.geometry, self.step, self.stream = geometry, step, stream
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        main.wait_stream(self.stream)          # this batch's geometry (the previous replay's geometry graph) is complete
+        self.stream.wait_stream(main)          # the previous step no longer reads the set the geometry graph overwrites
+        with torch.cuda.stream(self.stream):
+            self.geometry.replay()
+        self.step.replay()
 
 
 class PointEngine:
@@ -513,7 +534,7 @@ class PointEngine:
         for u, d in zip(ws.tu, g.tu):
             u.idx, u.w = d['idx'], d['w']
 
-    def _geometry(self, ws, B, x, starts, g):
+    def _geometry(self, ws, B, x, starts, g, serial=False):
         """Everything that depends on the coordinates only: per level FPS -> kNN(16) -> transposed neighbour lists, then the 3-NN
         tables of the TransitionUps.  FPS is `npoint` strictly sequential iterations on ONE workgroup per cloud (32 - 128
         workgroups on 256 CUs) and the kNN kernels are short, so the chain runs on a side stream next to the feature path (the
@@ -526,7 +547,7 @@ class PointEngine:
             g.xyz.copy_(x[..., :3])
             return
         side = None
-        if GEOM_STREAM:
+        if GEOM_STREAM and not serial:
             if getattr(self, '_side', None) is None:
                 self._side = torch.cuda.Stream(device=self.device)
             side = self._side
@@ -824,6 +845,26 @@ class PointEngine:
                     self.train_step_pipelined(xs[p], ys[p], starts[p], xs[1 - p], starts[1 - p], p)
             torch.cuda.current_stream().wait_stream(side)
         graphs = []
+        if TWO_CHAINS and self.levels > 0:
+            B = xs[0].shape[0]
+            ws = self.workspace(B)
+            if getattr(self, '_geo_stream', None) is None:
+                self._geo_stream = torch.cuda.Stream(device=self.device)
+            for p in (0, 1):
+                gg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gg):           # one chain: FPS -> kNN -> lists per level, 3-NN tables (set 1-p from buffers 1-p)
+                    self._geometry(ws, B, xs[1 - p], starts[1 - p], ws.geo[1 - p], serial=True)
+                ws.geo[p].events = [None] * (self.levels + 1)      # the step graph orders itself behind the geometry graph as a whole
+                sg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(sg):           # one chain: forward / loss / backward / update on batch p with geometry set p
+                    self.forward(xs[p], starts[p], geometry=ws.geo[p])
+                    loss = self.cross_entropy(B, ys[p])
+                    self.backward(B)
+                    self.sgd_step()
+                graphs.append(_TwoChainStep(gg, sg, self._geo_stream))
+            self.prepare_geometry(xs[0], starts[0], 0)
+            torch.cuda.current_stream().wait_stream(self._geo_stream)
+            return graphs, loss
         for p in (0, 1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
