@@ -337,7 +337,7 @@ def main_points(args):
 
         def step():
             graphs[state['p']].replay(); state['p'] ^= 1
-        launch = 'hipGraph replay, geometry (FPS/kNN) one step ahead on a side stream'
+        launch = 'hipGraph replay: two chain graphs per step on two streams (geometry FPS/kNN of the next batch | training step)'
     elif not args.no_graphs:
         graph, loss_t = eng.capture_train_step(x, y, starts)
         step = graph.replay
