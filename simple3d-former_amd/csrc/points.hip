@@ -431,6 +431,7 @@ __device__ __forceinline__ f32x4 ld_grad4(const float* dy, const bf16_t* dyb, lo
     return ld4(dy + off);
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_stats_vec_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
                                                                const unsigned char* __restrict__ arg, int K, long rows, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -444,33 +445,43 @@ __global__ __launch_bounds__(256) void bn_bwd_stats_vec_kernel(const float* __re
     for (int i = 0; i < 4; ++i) { a[i] = rs[i] * g[i]; b[i] = be[i] - m[i] * a[i]; }
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
     const long n = arg ? rows / K : rows;          // max mode iterates groups
-    for (long r = (long)blockIdx.x * l.rpb + l.sub; l.on && r < n; r += (long)gridDim.x * l.rpb) {
-        const f32x4 d = ld_grad4(dy, dyb, r * lddy + c);
-        f32x4 xv;
-        if (arg) {
-            const unsigned ab = *reinterpret_cast<const unsigned*>(arg + r * C + c);
+    const long stride = (long)gridDim.x * l.rpb;
+    for (long r0 = (long)blockIdx.x * l.rpb + l.sub; l.on && r0 < n; r0 += U * stride) {
+        f32x4 d[U], xv[U];                         // U rows per trip, all loads first: the pass runs on 1024 workgroups (atomics), i.e. 16 waves per CU
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] = x[(r * K + ((ab >> (8 * i)) & 255u)) * ld + c + i];
-        } else {
-            xv = ld4(x + r * ld + c);
+        for (int u = 0; u < U; ++u) {
+            const long r = min(r0 + u * stride, n - 1);
+            d[u] = ld_grad4(dy, dyb, r * lddy + c);
+            if (arg) {
+                const unsigned ab = *reinterpret_cast<const unsigned*>(arg + r * C + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xv[u][i] = x[(r * K + ((ab >> (8 * i)) & 255u)) * ld + c + i];
+            } else {
+                xv[u] = ld4(x + r * ld + c);
+            }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float gg = (xv[i] * a[i] + b[i] > 0.f) ? d[i] : 0.f;
-            s[i] += gg;
-            q[i] += (double)gg * (double)((xv[i] - m[i]) * rs[i]);
+        for (int u = 0; u < U; ++u) {
+            if (r0 + u * stride >= n) break;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float gg = (xv[u][i] * a[i] + b[i] > 0.f) ? d[u][i] : 0.f;
+                s[i] += gg;
+                q[i] += (double)gg * (double)((xv[u][i] - m[i]) * rs[i]);
+            }
         }
     }
     bn_fold_sums(l, C, s, q, sums);
 }
 
+template <int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ x, int ld, const float* __restrict__ dy, int lddy,
                                                                const unsigned char* __restrict__ arg, int K, long rows, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                const double* __restrict__ sums, bf16_t* __restrict__ dx, int lddx,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               const bf16_t* __restrict__ dyb) {
+                                                               const bf16_t* __restrict__ dyb, double inv_rows) {
     if (blockIdx.x == 0)
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             atomic_add_f32(dgamma + c, (float)sums[C + c]);
@@ -485,35 +496,44 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
     for (int i = 0; i < 4; ++i) {
         a[i] = rs[i] * g[i];
         b[i] = be[i] - m[i] * a[i];
-        s1[i] = (float)(sums[c + i] / rows);
-        s2[i] = (float)(sums[C + c + i] / rows);
+        s1[i] = (float)(sums[c + i] * inv_rows);        // (not "/ rows": eight fp64 divisions per thread in front of a ~13-trip row loop)
+        s2[i] = (float)(sums[C + c + i] * inv_rows);
     }
     const unsigned uK = (unsigned)(K > 0 ? K : 1);
     const int kshift = (uK & (uK - 1)) == 0 ? __builtin_ctz(uK) : -1;        // k = 16 neighbours: a shift, not a 64-bit division per row
-    for (long r = (long)blockIdx.x * l.rpb + l.sub; r < rows; r += (long)gridDim.x * l.rpb) {
-        const f32x4 xv = ld4(x + r * ld + c);
-        f32x4 gq = {0.f, 0.f, 0.f, 0.f};
-        if (arg) {
-            const long sg = kshift >= 0 ? (r >> kshift) : r / uK;
-            const unsigned kk = (unsigned)(r - sg * uK);
-            const unsigned ab = *reinterpret_cast<const unsigned*>(arg + sg * C + c);
-            const f32x4 d = ld_grad4(dy, dyb, sg * lddy + c);
+    // U rows per trip, every load of the trip in flight before the first use: one row per trip leaves a wave with 1.5 KB outstanding,
+    // and the pass ran at 2.9 TB/s -- latency x bytes in flight, not HBM
+    const long stride = (long)gridDim.x * l.rpb;
+    for (long r0 = (long)blockIdx.x * l.rpb + l.sub; r0 < rows; r0 += U * stride) {
+        f32x4 xv[U], d[U];
+        unsigned ab[U], kk[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (kk == ((ab >> (8 * i)) & 255u) && xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
-        } else {
-            const f32x4 d = ld_grad4(dy, dyb, r * lddy + c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (xv[i] * a[i] + b[i] > 0.f) gq[i] = d[i];
+        for (int u = 0; u < U; ++u) {
+            const long r = min(r0 + u * stride, rows - 1);
+            xv[u] = ld4(x + r * ld + c);
+            if (arg) {
+                const long sg = kshift >= 0 ? (r >> kshift) : r / uK;
+                kk[u] = (unsigned)(r - sg * uK);
+                ab[u] = *reinterpret_cast<const unsigned*>(arg + sg * C + c);
+                d[u] = ld_grad4(dy, dyb, sg * lddy + c);
+            } else {
+                d[u] = ld_grad4(dy, dyb, r * lddy + c);
+            }
         }
-        union { u32x2 u; bf16_t h[4]; } o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float xh = (xv[i] - m[i]) * rs[i];
-            o.h[i] = f2bf(a[i] * (gq[i] - s1[i] - xh * s2[i]));
+        for (int u = 0; u < U; ++u) {
+            const long r = r0 + u * stride;
+            if (r >= rows) break;
+            union { u32x2 w; bf16_t h[4]; } o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool on = xv[u][i] * a[i] + b[i] > 0.f && (!arg || kk[u] == ((ab[u] >> (8 * i)) & 255u));
+                const float gq = on ? d[u][i] : 0.f;
+                const float xh = (xv[u][i] - m[i]) * rs[i];
+                o.h[i] = f2bf(a[i] * (gq - s1[i] - xh * s2[i]));
+            }
+            *reinterpret_cast<u32x2*>(dx + r * lddx + c) = o.w;
         }
-        *reinterpret_cast<u32x2*>(dx + r * lddx + c) = o.u;
     }
 }
 
@@ -956,10 +976,27 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
     const long n = a.K > 0 ? a.rows / a.K : a.rows;
     if (vec) {
         const int rpb = 256 / (a.C / 4);
-        hipLaunchKernelGGL(bn_bwd_stats_vec_kernel, dim3(grid_for(n, rpb, bn_stats_blocks())), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,
-                           a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dy_bf);
-        hipLaunchKernelGGL(bn_bwd_apply_vec_kernel, dim3(grid_for(a.rows, rpb, 8192)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg,
-                           a.K, a.rows, a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta, a.dy_bf);
+        const long sblocks = bn_stats_blocks();
+        static const int stats_unroll = s3d_tune_int("S3D_BN_BSTATS_UNROLL");
+#define S3D_BN_BSTATS(U)                                                                                                                   \
+    hipLaunchKernelGGL(bn_bwd_stats_vec_kernel<U>, dim3(grid_for(n, rpb, sblocks)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K, a.rows, \
+                       a.C, a.mean, a.rstd, a.gamma, a.beta, a.sums, a.dy_bf)
+        if (stats_unroll == 1) S3D_BN_BSTATS(1);
+        else if (stats_unroll == 2) S3D_BN_BSTATS(2);
+        else if (stats_unroll == 8) S3D_BN_BSTATS(8);
+        else S3D_BN_BSTATS(4);
+#undef S3D_BN_BSTATS
+        static const int apply_blocks = s3d_tune_int("S3D_BN_APPLY_BLOCKS"), apply_unroll = s3d_tune_int("S3D_BN_APPLY_UNROLL");
+        const dim3 grid(grid_for(a.rows, rpb, apply_blocks > 0 ? apply_blocks : 8192));
+        const double inv_rows = 1.0 / (double)a.rows;
+#define S3D_BN_APPLY(U)                                                                                                                  \
+    hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<U>, grid, dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K, a.rows, a.C, a.mean, a.rstd, \
+                       a.gamma, a.beta, a.sums, a.dx, a.lddx, a.dgamma, a.dbeta, a.dy_bf, inv_rows)
+        if (apply_unroll == 4) S3D_BN_APPLY(4);
+        else if (apply_unroll == 2) S3D_BN_APPLY(2);
+        else if (apply_unroll == 8) S3D_BN_APPLY(8);
+        else S3D_BN_APPLY(1);
+#undef S3D_BN_APPLY
         S3D_CHECK_LAUNCH("batchnorm_bwd");
         return 0;
     }
