@@ -114,7 +114,7 @@ def rocprof_name(key):
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
 
 
-PMC_TRAFFIC_FILE = 'profiles/r03_pmc_step_traffic.json'
+PMC_TRAFFIC_FILE = 'profiles/r03_pmc_step_traffic.json'           # cfg-2; main() switches to ..._pmc_<config>_traffic.json for the others
 
 
 def pmc_traffic(key):
@@ -131,7 +131,9 @@ def pmc_traffic(key):
         prov = {'file': PMC_TRAFFIC_FILE, 'sha16': hashlib.sha256(raw).hexdigest()[:16], 'collected_at_head': doc.get('head'),
                 'collected_on': doc.get('date')}
         want = rocprof_name(key)
-        hits = [n for n in doc['kernels'] if n == want or n.startswith(want + '(')]
+        stem = want[:-1]            # the leading template arguments identify the instantiation; later ones (ring depth, wave grid,
+        hits = [n for n in doc['kernels']        # k-tail flag ...) were appended over the rounds -- exactly ONE entry may carry this stem
+                if n == want or n.startswith(want + '(') or (n.startswith(stem) and n[len(stem):len(stem) + 1] == ',')]
         if len(hits) != 1:
             return None, None, prov
         k = doc['kernels'][hits[0]]
@@ -492,8 +494,10 @@ def main():
     args = ap.parse_args()
     if args.config in POINT_CONFIGS:
         return main_points(args)
-    global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE
+    global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE, PMC_TRAFFIC_FILE
     conf = CONFIGS[args.config]
+    if args.config != 'cfg2':
+        PMC_TRAFFIC_FILE = f'profiles/r03_pmc_{args.config}_traffic.json'     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh
     CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
 
     import torch.distributed as dist

@@ -775,7 +775,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_dma_kernel(const GemmArg
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    // Panels of PM tile rows, walked m-first: the ~32 workgroups an XCD runs side by side then cover PM row tiles x 32 / PM column tiles
+    // instead of 32 / ntx x ntx -- each fetches PM A tiles + 32 / PM B tiles into its L2, which is least when the two are balanced
+    // (cfg-3 qkv: 3.5 x 9 tiles re-stream the 7 MB weight once per 3.5 row tiles; 8 x 4 once per 8).  p.kchunk carries PM (0: rows).
+    int tm = tile_id / ntx, tn = tile_id % ntx;
+    if (const int PM = p.kchunk; PM > 1) {
+        const int per = PM * ntx, pnl = tile_id / per, w = tile_id - pnl * per;
+        const int rows = min(PM, nty - pnl * PM);
+        tm = pnl * PM + w % rows;
+        tn = w / rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles = p.K / BK;                                       // K % BK == 0 (checked by the launcher)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     // 16-byte slot swizzle: 128-byte rows as in gemm_body; 64-byte rows (16 banks) repeat every 4 rows -> xor with (r >> 2) & 3
@@ -1403,9 +1413,20 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     return 0;
 }
 
+// tile rows per panel of the forward DMA kernels' tile walk (gemm_nt_dma_kernel: p.kchunk); 0 = plain row-major walk
+static int nt_panel(int M, int N, int BM, int BN) {
+    static const int forced = env_int("S3D_NT_PANEL");
+    if (forced >= 0) return forced;
+    // measured at cfg-3 (188 160 rows, 128x256 tiles, 9 / 12 column tiles): 312.8 ms per step with the row-major walk, 309.7 with panels
+    // of 4 - 8, 312.2 with 16, 319 with 32; cfg-2 (1664 rows, 32x32 tiles) loses 0.3 % with any panel
+    return (M >= 8192 && (N + BN - 1) / BN >= 6) ? 8 : 0;
+}
+
 // the forward DMA kernel on the small cfg-2 tiles (k = 64 stages)
 template <bool SPLIT, int EPI, int BM, int BN, int NS, int WM = 2, int WN = 2, int ILV = 0, int BK = 64>
-int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
+int launch_nt_dma_small(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    a.kchunk = nt_panel(a.M, a.N, BM, BN);
     constexpr int STAGE = (SPLIT ? 2 : 1) * (BM + BN) * BK * 2;
     constexpr int LDS = cmax(NS * STAGE, BM * (BN + 4) * 4);
     static_assert(LDS <= 160 * 1024, "stage ring exceeds the CU's LDS");
@@ -1449,7 +1470,9 @@ int launch_nt_dma_small(const GemmArgs& a, hipStream_t stream) {
 }
 
 template <bool SPLIT, int EPI>
-int launch_nt_dma(const GemmArgs& a, hipStream_t stream) {
+int launch_nt_dma(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    a.kchunk = nt_panel(a.M, a.N, 128, 128);
     // two workgroups per CU matter more than stage depth.  Measured at M = 65 536, deit_base shapes, TFLOP/s algorithmic
     // (register-staged kernel -> this one): plain bf16 qkv 575 -> 625, fc2 692 -> 761 with two 32 KB stages of k = 64 (three
     // stages = 96 KB = one workgroup per CU: 472 / 618, slower than register staging; four stages of k = 32: 529 / 661);
