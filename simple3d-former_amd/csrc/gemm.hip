@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void frags_kmajor_ab(const unsigned char* tA, int col
 // bytes per flop through the same pipe.
 template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char* smem, int tile_id, const int ntx, const int nty,
-                                               const int bz) {
+                                               const int bz, const bool xcd_remap = true) {
     constexpr int BK = 64;
     static_assert((BM == 64 || BM == 128 || BM == 256) && (BN == 64 || BN == 128 || BN == 256), "tile edges of 64 / 128 / 256");
     constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
     constexpr int FM = TM / 16, FN = TN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    {
+    if (xcd_remap) {
         const int ntile = ntx * nty;
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -1315,7 +1315,21 @@ __device__ __forceinline__ void gemm_dmat_body(const GemmArgs& p, unsigned char*
 template <bool TA, bool TB, int EPI, int NS, int BM = 128, int BN = 128, bool KTAIL = false, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dmat_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    gemm_dmat_body<TA, TB, EPI, NS, BM, BN, KTAIL, WM, WN>(p, smem, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x, gridDim.y, blockIdx.z);
+    int tile = blockIdx.y * gridDim.x + blockIdx.x, bz = blockIdx.z;
+    bool remap = true;
+    if constexpr (TA && TB) {
+        // wgrad: every tile of a k-slice reads the same K rows of both operands.  Spread over the eight XCDs (workgroup id mod 8) each
+        // XCD pulls the whole slice of the narrower operand into its own L2 -- PMC at cfg-3 (qkv wgrad): 2.9 GB fetched per launch for
+        // 1.16 GB of operands, 5.8 TB/s on the memory side of L2.  With the slice count a multiple of 8, slice s runs on XCD s mod 8.
+        if ((gridDim.z & 7) == 0) {
+            const int tiles = gridDim.x * gridDim.y;
+            const int lin = bz * tiles + tile, xcd = lin & 7, j = lin >> 3;
+            bz = xcd + 8 * (j / tiles);
+            tile = j % tiles;
+            remap = false;
+        }
+    }
+    gemm_dmat_body<TA, TB, EPI, NS, BM, BN, KTAIL, WM, WN>(p, smem, tile, gridDim.x, gridDim.y, bz, remap);
 }
 
 // dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
@@ -1693,6 +1707,7 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
         splitk = (int)((768 + tiles128 - 1) / tiles128);
         const int maxk = a.K / 2048;
         if (splitk > maxk) splitk = maxk;
+        if (splitk >= 8) splitk = max(8, min((splitk + 4) / 8 * 8, maxk / 8 * 8));     // whole k-slices per XCD (gemm_dmat_kernel)
         if (splitk < 1) splitk = 1;
     }
     if (splitk <= 0) {
@@ -1838,6 +1853,7 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
                 int sk = (int)((512 + tiles / 2) / tiles);               // about two workgroups per CU over the launch
                 sk = sk < 1 ? 1 : sk;
                 if (sk > a.K / 2048) sk = a.K / 2048;
+                if (sk >= 8) sk = max(8, min((sk + 4) / 8 * 8, a.K / 2048 / 8 * 8));      // whole k-slices per XCD (gemm_dmat_kernel)
                 a.kchunk = ((a.K + sk - 1) / sk + 63) / 64 * 64;
                 sk = (a.K + a.kchunk - 1) / a.kchunk;
                 if (fat == 3) {                                        // experiment: the wide way round (all long wgrads)
