@@ -108,7 +108,7 @@ def rocprof_name(key):
     if kind == 6:
         return f'gemm_pair_dmat_kernel<{epi}, 3>'
     if kind == 3:
-        return f'gemm_nt_dma_kernel<{tf(sp)}, {epi}, 2, {32 if (sp and b0 == 128) else 64}, {b0}, {b1}>'
+        return f'gemm_nt_dma_kernel<{tf(sp)}, {epi}, {3 if b1 == 256 else 2}, {32 if (sp and b0 == 128) else 64}, {b0}, {b1}>'     # 128x256: three-stage ring
     if kind == 4:
         return f'gemm_dmat_kernel<{tf(ta)}, {tf(tb)}, {epi}, {2 if b0 == 128 else 3}, {b0}, {b1}>'
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
