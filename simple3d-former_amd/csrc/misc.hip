@@ -705,7 +705,10 @@ int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf
     S3D_REQUIRE(n % 4 == 0, "adam: slice length %ld must be a multiple of 4", n);
     if (n == 0) return 0;
     long blocks = (n / 4 + 255) / 256;
-    const long cap = max_blocks > 0 ? max_blocks : 2048;
+    static const int tuned = s3d_tune_int("S3D_ADAM_BLOCKS");
+    // one float4 per thread up to 33 M parameters: with the non-temporal accesses the grid-stride walk on 2048 workgroups left the
+    // update at 5.3 TB/s (cfg-2 step 1.738 -> 1.712 ms with 32768; 16384: 1.717)
+    const long cap = max_blocks > 0 ? max_blocks : (tuned > 0 ? tuned : 32768);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire);
     S3D_CHECK_LAUNCH("adam");
