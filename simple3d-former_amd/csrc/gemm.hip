@@ -230,7 +230,8 @@ __device__ __forceinline__ void epi_prefetch(const GemmArgs& p, const int m, con
         if (with_bias && p.bias) ld_f32<W>(q.bq, p.bias + n);
     }
     if constexpr (EPI == EPI_RESID) ld_f32<W>(q.rr, p.R + (long)m * p.ldr + n);
-    if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU) ld_bf<W>(q.ax, p.aux + (long)m * p.ldaux + n);
+    if constexpr (EPI == EPI_DGELU || EPI == EPI_DRELU)          // the saved pre-activation is dead after this read: non-temporal
+        q.ax.u = __builtin_nontemporal_load(reinterpret_cast<const decltype(q.ax.u)*>(p.aux + (long)m * p.ldaux + n));
 }
 
 template <int EPI, int W>
