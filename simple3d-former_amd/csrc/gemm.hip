@@ -1695,7 +1695,7 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
 }
 
 // paired: the wgrad shares its launch with a dgrad that already supplies workgroups, so it needs fewer k-slices (fewer
-// fp32 atomics): full cfg-2 step 2.40 ms with the stand-alone target of 512 workgroups vs 2.33 ms with 256.
+// fp32 atomics): full cfg-2 step 2.40 ms with the stand-alone target of 512 workgroups vs 2.33 ms with 256 (round 1).
 static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
@@ -1713,7 +1713,9 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
     }
     if (splitk <= 0) {
         static const int target_env = env_int("S3D_GEMM_WGRAD_TARGET"), cap_env = env_int("S3D_GEMM_SPLITK_MAX");
-        const long target = target_env > 0 ? target_env : (paired ? 256 : 512);
+        // paired: 145 - 216 workgroups give cfg-2's wgrads 2 / 2 / 2 / 6 k-slices (fc1, fc2, qkv, proj) instead of 2 / 2 / 3 / 8 at 256:
+        // fewer fp32 atomics per element -- cfg-2 1.718 -> 1.698 ms, cfg-5 9.71 -> 9.63 ms (round 3; 128 puts fc1 / fc2 on ONE slice: 1.75)
+        const long target = target_env > 0 ? target_env : (paired ? 192 : 512);
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         splitk = (int)((target + tiles64 - 1) / tiles64);
         const int cap = cap_env > 0 ? cap_env : 0;
