@@ -77,6 +77,12 @@ typedef struct S3dGemmArgs {
  * fp32 atomics into C, optional bias_grad = column sums of dy).  split: three-MFMA split-bf16 product -- the forward's precision;
  * for (0,1) / (1,1) it is the split-precision BACKWARD of the parity mode (both operands need their lo planes, no split-K). */
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int splitk, s3d_stream_t stream);
+/* One launch = the dgrad "dx = dy @ W" (NN, epilogue epi_dgrad: F32 / DGELU / DRELU / RESID / BF16_BIAS) of a Linear layer AND the wgrad
+ * "dW += dy^T x, db += colsum(dy)" (TN, split-K fp32 atomics) that consumes the same dy: workgroups [0, nA) of the grid run the first
+ * problem, the rest the second.  This is how s3d_block_bwd issues every Linear backward of the small-batch configurations (each half
+ * alone under-fills the chip at 1664 token rows); shapes that want 128x128 tiles fall back to two launches.  The library picks the
+ * wgrad's k-split (kchunk of both argument structs is ignored). */
+int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, s3d_stream_t stream);
 /* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
 /* 1 if a forward (0,0) F32-epilogue launch of this shape accumulates S3dGemmArgs::col_sums (128x128 tiles, N % 8 == 0); the caller
@@ -91,6 +97,12 @@ int s3d_gemm_col_sums_ok(int split, int M, int N);
  * the median time between two events recorded back-to-back on the stream with nothing in between (microseconds). */
 int s3d_prof_enable(int on);
 int s3d_prof_collect(double* rows, int cap);
+/* Launch coverage (test aid): while enabled, every kernel launch notes "family:instantiation key".  s3d_cov_enable(1) clears and starts,
+ * s3d_cov_enable(0) stops; s3d_cov_collect copies the newline-separated list "family:key:launches" (NUL-terminated, truncated to cap)
+ * and returns the buffer size the full list needs.  tests/test_gpu_zz_coverage.py uses it to prove that every kernel instantiation a
+ * benched training step dispatches has also run inside a test that compares with the oracle. */
+int s3d_cov_enable(int on);
+long s3d_cov_collect(char* buf, long cap);
 /* Deterministic mode (default: environment S3D_DETERMINISTIC=1, else off).  On: no reduction combines partial sums from several
  * workgroups with fp32 atomics -- wgrads run without split-K, the token / conv-bias gradients, the loss and the final-norm
  * gamma / beta gradients take single-writer kernels -- so a training step (train_cls_voxel.py:277-288) is bitwise reproducible
@@ -262,6 +274,8 @@ int s3d_adam_apply(float* p, float* g, const uint16_t* g_wire, float* m, float* 
  * on xGMI): s3d_pack_bf16 rounds a finished gradient bucket to bf16 (rne; n % 8 == 0), the bf16 buffer is sum-all-reduced, and
  * s3d_adam_step_wire takes the gradient from it (g is only zeroed).  The averaging stays in S3dAdamState::grad_scale. */
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t stream);
+int s3d_adam_step_wire(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
+                       S3dAdamState* state, int zero_grad, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ mid-graph events for data parallelism
  * DDP (train_cls_voxel.py:155-159, :287) all-reduces gradient buckets while backward is still running.  With HIP graphs that used to

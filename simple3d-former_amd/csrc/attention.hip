@@ -1159,7 +1159,7 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
                 hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 4, false>), g, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH("attention_fwd_coop");
+        S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + (split ? 10 : 0) + (a.drop_thr ? 1 : 0));
         return 0;
     }
     const int wpb = waves_per_block(W);
@@ -1186,7 +1186,7 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
         if (a.seg) hipLaunchKernelGGL((attn_fwd_kernel<HD, false, true>), grid, dim3(64 * wpb), lds, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(64 * wpb), lds, s, a);
     }
-    S3D_CHECK_LAUNCH("attention_fwd");
+    S3D_CHECK_LAUNCH_V("attention_fwd", HD * 1000 + (split ? 100 : 0) + (a.seg ? 10 : 0) + (a.drop_thr ? 1 : 0));
     return 0;
 }
 
@@ -1207,7 +1207,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
             set_lds(attn_bwd_small_kernel<HD, true>, MAXW * WAVE_LDS);
             if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
             else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
-            S3D_CHECK_LAUNCH("attention_bwd_small");
+            S3D_CHECK_LAUNCH_V("attention_bwd_small", HD * 10 + (a.seg ? 1 : 0));
             return 0;
         }
     }
@@ -1226,14 +1226,14 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
         }
-        S3D_CHECK_LAUNCH("attention_bwd_dq_coop");
+        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD);
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
         set_lds(attn_bwd_dq_kernel<HD, true>, 4 * 32 * HD * 2);
         if (a.seg) hipLaunchKernelGGL((attn_bwd_dq_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
         else hipLaunchKernelGGL((attn_bwd_dq_kernel<HD>), grid, dim3(64 * wpb), lds, s, a);
-        S3D_CHECK_LAUNCH("attention_bwd_dq");
+        S3D_CHECK_LAUNCH_V("attention_bwd_dq", HD * 10 + (a.seg ? 1 : 0));
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
         const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256);
@@ -1249,7 +1249,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
         }
-        S3D_CHECK_LAUNCH("attention_bwd_dkv_coop");
+        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 10 + DSPLIT);
     } else {
         // the per-wave kernel splits the d range in two from hd = 192 on (one half = 252 registers + 60 B of scratch there)
         constexpr int DS = HD >= 192 ? 2 : DSPLIT;
@@ -1259,7 +1259,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
         dim3 g2(grid.x, DS);
         if (a.seg) hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DS, true>), g2, dim3(64 * wpb), lds, s, a);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD, DS>), g2, dim3(64 * wpb), lds, s, a);
-        S3D_CHECK_LAUNCH("attention_bwd_dkv");
+        S3D_CHECK_LAUNCH_V("attention_bwd_dkv", HD * 100 + DS * 10 + (a.seg ? 1 : 0));
     }
     return 0;
 }

@@ -4,6 +4,8 @@
 #include <string.h>
 #include <stdlib.h>
 
+#include <map>
+#include <string>
 #include <vector>
 
 #include "attention.h"
@@ -21,6 +23,11 @@ bool s3d_deterministic() {
     }
     return g_deterministic != 0;
 }
+
+// ---- launch coverage (common.h: S3D_CHECK_LAUNCH_V)
+bool g_s3d_cov_on = false;
+static std::map<std::pair<std::string, long long>, long> g_cov;
+void s3d_cov_note(const char* name, long long variant) { ++g_cov[{std::string(name), variant}]; }
 
 void s3d_set_error(const char* fmt, ...) {
     va_list ap;
@@ -497,6 +504,31 @@ int s3d_prof_event_overhead(s3d_stream_t stream, double* us) {
 int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* a, int splitk, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_gemm: null args");
     return s3d_launch_gemm(ta != 0, tb != 0, split != 0, epi, *a, splitk, st(s));
+}
+int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, s3d_stream_t s) {
+    S3D_REQUIRE(dgrad != nullptr && wgrad != nullptr, "s3d_gemm_pair: null args");
+    S3D_REQUIRE(dgrad->M > 0 && dgrad->N > 0 && dgrad->K > 0 && wgrad->M > 0 && wgrad->N > 0 && wgrad->K > 0, "s3d_gemm_pair: empty problem");
+    S3D_REQUIRE(wgrad->C != nullptr, "s3d_gemm_pair: the wgrad half accumulates into C");
+    return s3d_launch_gemm_pair(epi_dgrad, *dgrad, *wgrad, st(s));
+}
+int s3d_cov_enable(int on) {
+    if (on) g_cov.clear();
+    g_s3d_cov_on = on != 0;
+    return 0;
+}
+long s3d_cov_collect(char* buf, long cap) {
+    std::string out;
+    for (const auto& kv : g_cov) {
+        char line[160];
+        snprintf(line, sizeof(line), "%s:%lld:%ld\n", kv.first.first.c_str(), kv.first.second, kv.second);
+        out += line;
+    }
+    if (buf != nullptr && cap > 0) {
+        const long n = (long)out.size() < cap - 1 ? (long)out.size() : cap - 1;
+        memcpy(buf, out.data(), (size_t)n);
+        buf[n] = 0;
+    }
+    return (long)out.size() + 1;
 }
 int s3d_gemm_col_sums_ok(int split, int M, int N) {
     static const bool forced = s3d_tune_int("S3D_GEMM_NT_TILE") >= 0;

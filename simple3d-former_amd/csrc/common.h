@@ -165,14 +165,22 @@ void s3d_set_error(const char* fmt, ...);
 // with fp32 atomics from several workgroups (split-K wgrads, token / bias gradients, loss, final-norm gamma/beta) takes a
 // single-writer path instead, so a training step is bitwise reproducible run to run.  Slower; for parity tests.
 bool s3d_deterministic();
-#define S3D_CHECK_LAUNCH(name)                                                         \
+// Launch coverage (s3d_cov_enable / s3d_cov_collect, tests/test_gpu_zz_coverage.py): while enabled, every launcher notes the kernel
+// family it dispatched to and an instantiation key (GEMMs: the profiling key = tiles | transposes | split | epilogue; attention /
+// LayerNorm / BatchNorm: the template choice), so that a test can prove that every kernel variant a benched training step launches
+// has also been launched inside a test that compares with the oracle.  One predictable branch per launch when off.
+extern bool g_s3d_cov_on;
+void s3d_cov_note(const char* name, long long variant);
+#define S3D_CHECK_LAUNCH_V(name, variant)                                              \
     do {                                                                               \
+        if (g_s3d_cov_on) s3d_cov_note(name, (long long)(variant));                    \
         hipError_t e__ = hipGetLastError();                                            \
         if (e__ != hipSuccess) {                                                       \
             s3d_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));      \
             return 1;                                                                  \
         }                                                                              \
     } while (0)
+#define S3D_CHECK_LAUNCH(name) S3D_CHECK_LAUNCH_V(name, 0)
 #define S3D_REQUIRE(cond, ...)            \
     do {                                  \
         if (!(cond)) {                    \

@@ -429,7 +429,7 @@ int launch_attn(const FusedAttnArgs& a, hipStream_t s) {
     s3d_prof_begin(KEY, 2.0 * M * 3 * D * D + 4.0 * a.Bb * a.N * a.N * D, s);       // qkv GEMM + (q k^T, p v) of every head
     hipLaunchKernelGGL((blk_attn_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
     s3d_prof_end(s);
-    S3D_CHECK_LAUNCH("blk_attn");
+    S3D_CHECK_LAUNCH_V("blk_attn", D);
     return 0;
 }
 template <int D>
@@ -444,7 +444,7 @@ int launch_mlp1(const FusedMlpArgs& a, hipStream_t s) {
     s3d_prof_begin(KEY, 2.0 * (double)a.M * a.hidden * D, s);
     hipLaunchKernelGGL((blk_mlp1_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
     s3d_prof_end(s);
-    S3D_CHECK_LAUNCH("blk_mlp1");
+    S3D_CHECK_LAUNCH_V("blk_mlp1", D);
     return 0;
 }
 

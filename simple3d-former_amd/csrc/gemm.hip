@@ -1394,7 +1394,7 @@ int launch_pair_one(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_
     } else {
         hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
     }
-    S3D_CHECK_LAUNCH("gemm_pair");
+    S3D_CHECK_LAUNCH_V("gemm_pair", KEY);
     return 0;
 }
 
@@ -1424,7 +1424,7 @@ int launch_one(const GemmArgs& a, int splitk, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
     }
-    S3D_CHECK_LAUNCH("gemm");
+    S3D_CHECK_LAUNCH_V("gemm", KEY);
     return 0;
 }
 
@@ -1480,7 +1480,7 @@ int launch_nt_dma_small(const GemmArgs& a_in, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
     }
-    S3D_CHECK_LAUNCH("gemm_nt_dma_small");
+    S3D_CHECK_LAUNCH_V("gemm_nt_dma_small", KEY * 1000 + NS * 100 + WN * 10 + (a.ln_tickets ? 1 : 0));
     return 0;
 }
 
@@ -1533,7 +1533,7 @@ int launch_nt_dma(const GemmArgs& a_in, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a);
     }
-    S3D_CHECK_LAUNCH("gemm_nt_dma");
+    S3D_CHECK_LAUNCH_V("gemm_nt_dma", KEY * 10 + (a.ln_tickets ? 1 : 0));
     return 0;
 }
 
@@ -1567,7 +1567,7 @@ int launch_dmat(const GemmArgs& a, int splitk, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), LDS, stream, a);
     }
-    S3D_CHECK_LAUNCH("gemm_dmat");
+    S3D_CHECK_LAUNCH_V("gemm_dmat", KEY * 10 + (KTAIL ? 1 : 0));
     return 0;
 }
 
@@ -1761,7 +1761,7 @@ int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream
     } else {
         hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
     }
-    S3D_CHECK_LAUNCH("gemm_pair_dmat");
+    S3D_CHECK_LAUNCH_V("gemm_pair_dmat", KEY * 10 + (KTAIL ? 1 : 0));
     return 0;
 }
 

@@ -189,7 +189,7 @@ int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
     if (a.D <= 256) hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, a);
     else if (a.D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, s, a);
-    S3D_CHECK_LAUNCH("ln_fwd");
+    S3D_CHECK_LAUNCH_V("ln_fwd", a.D <= 256 ? 1 : a.D <= 512 ? 2 : 4);
     return 0;
 }
 
@@ -221,7 +221,7 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     else if (rpw == 2) S3D_LN_BWD(2);
     else S3D_LN_BWD(1);
 #undef S3D_LN_BWD
-    S3D_CHECK_LAUNCH("ln_bwd");
+    S3D_CHECK_LAUNCH_V("ln_bwd", (rpw >= 4 ? 4 : rpw) * 100 + (a.D <= 256 ? 1 : a.D <= 512 ? 2 : 4) * 10 + (a.partial ? 1 : 0));
     return 0;
 }
 

@@ -961,7 +961,7 @@ int s3d_launch_bn_fwd(const S3dBnArgs& a, hipStream_t s) {
             hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(a.rows * a.C)), dim3(256), 0, s, a.x, a.rows, a.C, a.ldx, a.mean, a.rstd,
                                a.gamma, a.beta, a.y, a.y_hi, a.y_lo, a.ldo);
     }
-    S3D_CHECK_LAUNCH("batchnorm_fwd");
+    S3D_CHECK_LAUNCH_V("batchnorm_fwd", (bn_vec_ok(a) ? 1000 : 0) + (a.eval_mode ? 200 : a.have_sums ? 100 : 0) + (a.K > 0 ? 10 : 0));
     return 0;
 }
 int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
@@ -997,7 +997,7 @@ int s3d_launch_bn_bwd(const S3dBnArgs& a, hipStream_t s) {
         else if (apply_unroll == 8) S3D_BN_APPLY(8);
         else S3D_BN_APPLY(1);
 #undef S3D_BN_APPLY
-        S3D_CHECK_LAUNCH("batchnorm_bwd");
+        S3D_CHECK_LAUNCH_V("batchnorm_bwd", 100 + (a.K > 0 ? 10 : 0) + (a.dy_bf ? 1 : 0));
         return 0;
     }
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3(grid_for(n, per, 1024)), dim3(256), 0, s, a.x, a.ldx, a.dy, a.lddy, arg, a.K,

@@ -16,6 +16,7 @@ if torch.cuda.is_available():
 
 from oracle import point_oracle as po
 from oracle import voxel_oracle as vo
+from tests._util import check_grads_against_oracle
 
 DEV = 'cuda'
 LOGIT_TOL = 1e-3
@@ -139,3 +140,76 @@ def test_cfg4_full_size_properties():
 def test_cfg5_full_size_properties():
     """BASELINE cfg-5: PointTransformerSeg, 2048 points x 22 channels, 50 parts, batch 32 (513-token sequences, 65 536 head rows)."""
     _point_fullsize('seg', 2048, 22, 50, 32, n_slice=2)
+
+
+def _point_fullsize_parity(task, n_points, d_points, n_classes, B):
+    """One TRAINING-mode step at the benched size in the DEFAULT dispatch (split-K atomic wgrads, column sums from the GEMM epilogues,
+    2.1 M-row BatchNorm kernels, cooperative long-sequence attention): logits, loss, BatchNorm batch statistics and EVERY gradient
+    tensor against the CPU oracle's forward + autograd of the same batch (train_cls.py:119-123 / train_partseg.py:143-150)."""
+    backbone = 'deit_tiny_patch16_224'
+    sd = po.init_state_dict(backbone=backbone, n_classes=n_classes, d_points=d_points, seed=9)
+    x, y, starts = po.synthetic_points(B, n_points, d_points, n_classes, task, seed=9)
+    eng = PointEngine(backbone=backbone, n_points=n_points, d_points=d_points, n_classes=n_classes, task=task, device=DEV)
+    eng.load_state_dict(sd)
+    xd, yd, sts = x.to(DEV), y.to(DEV), tuple(s.to(DEV) for s in starts)
+    ref_logits, ref_loss, ref_grads, ref_stats = po.loss_and_grads(sd, x, y, task=task, backbone=backbone, starts=starts)
+    logits = eng.forward(xd, sts).cpu().reshape(ref_logits.shape)
+    err = float((logits - ref_logits).abs().max())
+    assert err <= LOGIT_TOL, f'logits max abs err {err:.3e}'
+    top2 = ref_logits.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_TOL
+    assert float(clear.float().mean()) > 0.8
+    assert torch.equal(logits.argmax(-1)[clear], ref_logits.argmax(-1)[clear])
+    loss = float(eng.cross_entropy(B, yd))
+    assert abs(loss - float(ref_loss)) <= LOGIT_TOL, (loss, float(ref_loss))
+    eng.zero_grad()
+    eng.backward(B)
+    grads = {k: eng.arena.grad(k) for k in eng.shapes}
+    # biases that feed a train-mode BatchNorm (and norm.bias, which reaches the loss only through one) have a theoretically ZERO
+    # gradient: both sides return rounding noise there (tests/test_gpu_points.py)
+    zero_theory = ('mlp_convs.0.bias', 'mlp_convs.1.bias', 'fc1.0.bias', 'fc2.0.bias', 'norm.bias')
+    skip = {k for k in ref_grads if k.endswith(zero_theory) and (k.startswith('transition_') or k == 'norm.bias')} | {'fc1.2.bias', 'fc_pos_embed.2.bias'}
+    stats = check_grads_against_oracle(grads, {k: v for k, v in ref_grads.items() if k not in skip}, rtol=3e-3, atol=3e-7)
+    worst = max(stats.items(), key=lambda kv: kv[1][0])
+    print(f'{task} B={B}: logits err {err:.2e}, worst grad rms err / rms {worst[1][0]:.4f} ({worst[0]}), worst entry {max(v[2] for v in stats.values()):.3f}')
+
+
+def test_cfg4_full_size_parity():
+    _point_fullsize_parity('cls', 1024, 6, 40, 128)
+
+
+def test_cfg5_full_size_parity():
+    _point_fullsize_parity('seg', 2048, 22, 50, 32)
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.1])
+def test_cfg3_reduced_batch_training_step_matches_oracle(dropout):
+    """BASELINE cfg-3 in its real geometry (deit_base H=3, 128^3 grid, cell 9, patch 14, group_embed) at batch 4: 11 760 pass-1 token
+    rows (the 'long' GEMM dispatch from 8192 rows: 128x256 / 256x128 tiles, 128x128 split-K wgrads), 784 keys per (position, head) in
+    the seq-first encoder layer (cooperative long-sequence attention kernels), packed 15-token pairs in pass 1 -- i.e. the kernel
+    instantiations of the benched batch-64 step -- one full training-mode step against the CPU oracle: logits, loss, every gradient.
+    dropout = 0.1: nn.TransformerEncoderLayer's training mode with the counter-based mask the oracle shares."""
+    kw = dict(backbone='deit_base_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=128, cell=9, patch=14, n_classes=55)
+    B = 4
+    sd = vo.init_state_dict(seed=9, pos_embedding='group_embed', exercise_all=True, **kw)
+    x, y = vo.synthetic_batch(B, 128, 55, seed=9)
+    eng = s3d.VoxelEngine(device=DEV, pos_embedding='group_embed', **kw)
+    eng.load_state_dict(sd)
+    okw = dict(backbone=kw['backbone'], embed_layer=kw['embed_layer'], cell=9, patch=14, pos_embedding='group_embed')
+    if dropout > 0:
+        eng.set_dropout(dropout, seed=77)
+        okw.update(training=True, dropout_p=dropout, hash_seed=77)
+    ref_logits, ref_loss, ref_grads = vo.loss_and_grads(sd, x, y, **okw)
+    xd, yd = x.to(DEV), y.to(DEV)
+    eng.zero_grad()
+    loss = float(eng.forward_loss(xd, yd))
+    logits = eng.workspace(B).logits.cpu()
+    err = float((logits - ref_logits).abs().max())
+    assert err <= LOGIT_TOL, f'logits max abs err {err:.3e}'
+    assert abs(loss - float(ref_loss)) <= LOGIT_TOL
+    eng.backward(B)
+    grads = {k: eng.arena.grad(k) for k in eng.shapes}
+    assert set(grads) == set(ref_grads)
+    stats = check_grads_against_oracle(grads, ref_grads, rtol=3e-3)
+    worst = max(stats.items(), key=lambda kv: kv[1][0])
+    print(f'cfg-3 B=4 dropout {dropout}: logits err {err:.2e}, worst grad rms err / rms {worst[1][0]:.4f} ({worst[0]}), worst entry {max(v[2] for v in stats.values()):.3f}')

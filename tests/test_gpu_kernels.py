@@ -107,6 +107,71 @@ def test_gemm_wgrad_tn_with_bias_grad(rows, O, I):
     assert rel_err(dW, 2 * (dyh.double().t() @ xh.double())) < 2e-5
 
 
+def _gelu_grad(pre):
+    a = pre.double().clone().requires_grad_(True)
+    return torch.autograd.grad(F.gelu(a).sum(), a)[0]
+
+
+@pytest.mark.parametrize('rows,O,I,epi,ld_scale', [
+    (1664, 1152, 384, 'F32', 1),         # cfg-2 qkv:  dxn1 = dqkv @ Wqkv        || dWqkv += dqkv^T xn1      -> gemm_pair_dmat_kernel<4,3>
+    (1664, 1536, 384, 'F32', 1),         # cfg-2 fc1:  dxn2 = dh @ W1            || dW1 += dh^T xn2          -> <4,3>
+    (1664, 384, 1536, 'DGELU', 1),       # cfg-2 fc2:  dh = (dxo @ W2) gelu'     || dW2 += dxo^T hact        -> <5,3>
+    (1664, 384, 384, 'BF16_BIAS', 1),    # cfg-2 proj: datt = dxm @ Wproj        || dWproj += dxm^T att      -> <0,3>
+    (4104, 576, 192, 'F32', 1),          # cfg-5 (Bb=8 x 513 tokens, deit_tiny)
+    (4104, 192, 768, 'DGELU', 1),
+    (4104, 192, 192, 'BF16_BIAS', 1),
+    (1672, 1152, 384, 'F32', 1),         # ragged last row tile / partial last k-tile of the wgrad (1672 = 26 * 64 + 8)
+    (64, 384, 1536, 'DGELU', 26),        # the class-rows-only last block: 64 rows at pitch 26 * D (register-staged pair kernel, 32-row tiles)
+    (64, 1536, 384, 'F32', 26),
+    (64, 384, 384, 'BF16_BIAS', 26),
+    (208, 576, 192, 'F32', 1),           # cfg-1-sized (Bb = 8): 32 / 64-row register-staged pair kernels
+])
+def test_gemm_pair_dgrad_and_wgrad_tight(rows, O, I, epi, ld_scale):
+    """s3d_gemm_pair -- the launcher every Linear backward of s3d_block_bwd goes through -- at the shapes the benched configurations
+    dispatch (cfg-2: 1664 token rows -> gemm_pair_dmat_kernel; class rows / small batches -> gemm_pair_kernel): both halves against
+    fp64 products of the SAME bf16-rounded operands, so the only admissible error is fp32 accumulation order (F32 epilogue, wgrad:
+    rel 2e-5) or the final bf16 rounding of the output (DGELU / BF16_BIAS epilogues: within one bf16 ulp of the fp64 value)."""
+    g = torch.Generator().manual_seed(100 + rows + O)
+    ld_dy, ld_x, ld_out = O * ld_scale, I * ld_scale, I * ld_scale
+    dy = torch.zeros(rows, ld_dy); dy[:, :O] = torch.randn(rows, O, generator=g)
+    x = torch.zeros(rows, ld_x); x[:, :I] = torch.randn(rows, I, generator=g)
+    w = torch.randn(O, I, generator=g) * 0.05                       # nn.Linear weight [out][in]: the dgrad's k-major B operand
+    pre = torch.zeros(rows, ld_out); pre[:, :I] = torch.randn(rows, I, generator=g)
+    dyh = dy.to(DEV).to(torch.bfloat16); xh = x.to(DEV).to(torch.bfloat16); wh = w.to(DEV).to(torch.bfloat16)
+    aux = pre.to(DEV).to(torch.bfloat16)
+    dW = torch.zeros(O, I, dtype=torch.float32, device=DEV); db = torch.zeros(O, dtype=torch.float32, device=DEV)
+    dg = L.fill(L.S3dGemmArgs(), A_hi=dyh, lda=ld_dy, B_hi=wh, ldb=I, M=rows, N=I, K=O, alpha=1.0)
+    out32 = out16 = None
+    if epi == 'F32':
+        out32 = torch.full((rows, ld_out), float('nan'), dtype=torch.float32, device=DEV)
+        L.fill(dg, C=out32, ldc=ld_out)
+    else:
+        out16 = torch.full((rows, ld_out), float('nan'), dtype=torch.bfloat16, device=DEV)
+        L.fill(dg, O_hi=out16, ldo=ld_out)
+        if epi == 'DGELU':
+            L.fill(dg, aux=aux, ldaux=ld_out)
+    wg = L.fill(L.S3dGemmArgs(), A_hi=dyh, lda=ld_dy, B_hi=xh, ldb=ld_x, M=O, N=I, K=rows, C=dW, ldc=I, bias_grad=db, alpha=1.0)
+    for rep in (1, 2):                                               # the wgrad half accumulates, the dgrad half overwrites
+        L.check(L.lib().s3d_gemm_pair(ops.EPI[epi], ctypes.byref(dg), ctypes.byref(wg), L.current_stream()), 'gemm_pair')
+        ref_w = rep * (dyh[:, :O].double().t() @ xh[:, :I].double())
+        assert rel_err(dW, ref_w) < 2e-5, f'wgrad half (pass {rep})'
+        assert rel_err(db, rep * dyh[:, :O].double().sum(0)) < 2e-5, f'bias gradient (pass {rep})'
+        ref = dyh[:, :O].double() @ wh.double()
+        if epi == 'F32':
+            assert rel_err(out32[:, :I], ref) < 1e-5, 'dgrad half'
+        else:
+            if epi == 'DGELU':
+                ref = ref * _gelu_grad(aux[:, :I])
+            got = out16[:, :I].double()
+            assert not torch.isnan(got).any()
+            ulp = ref.abs() * 2.0 ** -8 + 1e-6 * float(ref.abs().max())          # half-ulp rounding + the kernel's fast erf / exp (1e-6)
+            assert bool(((got - ref).abs() <= ulp).all()), f'dgrad half: max {(got - ref).abs().max():.3e}'
+            assert rms_err(got, ref) < 3e-3                                      # uniform rounding noise: 2^-9 / sqrt(3)
+        if ld_scale > 1:                                                         # nothing outside the addressed columns was touched
+            rest = (out32 if out32 is not None else out16)[:, I:]
+            assert bool(torch.isnan(rest.float()).all())
+
+
 @pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40), (66000, 192, 192), (33000, 192, 96)])   # k = 40: register-staged kernel
 def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
     """S3dGemmArgs::col_sums: the F32 epilogue of a point-path convolution also accumulates sum(y) and sum(y^2) per output channel
@@ -430,7 +495,8 @@ def test_adam_matches_torch_and_refreshes_planes():
     assert int(state[7]) == 4
 
 
-@pytest.mark.parametrize('D,H,N,Bb', [(384, 6, 26, 8), (192, 3, 10, 3), (768, 3, 15, 5)])
+@pytest.mark.parametrize('D,H,N,Bb', [(384, 6, 26, 8), (192, 3, 10, 3), (768, 3, 15, 5),
+                                      (384, 6, 26, 64), (192, 3, 513, 8)])     # the benched cfg-2 block (1664 rows: gemm_pair_dmat_kernel, fused forward) and a cfg-5 slice (513 tokens)
 def test_block_fwd_bwd_matches_oracle(D, H, N, Bb):
     """One timm Block through s3d_block_fwd / s3d_block_bwd vs autograd on the oracle restatement."""
     from oracle import voxel_oracle as vo

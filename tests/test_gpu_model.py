@@ -17,7 +17,7 @@ if torch.cuda.is_available():
     from simple3d_former_amd import _lib as L
 
 from oracle import voxel_oracle as vo
-from tests._util import MODEL_KEYS, check_grads_against_golden, fwd_kwargs, load_case, rebuild_inputs
+from tests._util import MODEL_KEYS, check_grads_against_golden, check_grads_against_oracle, fwd_kwargs, load_case, rebuild_inputs
 
 DEV = 'cuda'
 LOGIT_TOL = 1e-3
@@ -196,6 +196,48 @@ def test_cfg2_full_size_properties():
     for _ in range(10):
         l1 = float(eng.train_step(xd, yd))
     assert l1 < l0, f'loss did not decrease: {l0} -> {l1}'
+
+
+@pytest.mark.parametrize('init', ['reference', 'exercise_all'])
+def test_cfg2_full_size_parity(init):
+    """BASELINE configs[1] at its FULL size -- deit_small + VoxelEmbed 32^3, batch 64 (1664 token rows) -- in the DEFAULT mode, i.e.
+    exactly the launches bench.py times (fused block forward, gemm_pair_dmat_kernel dgrad || wgrad pairs with split-K atomics,
+    attn_bwd_small_kernel, class-rows-only last block, fused loss end): all 64 x 40 logits, every clear-cut class decision, the
+    loss and EVERY gradient tensor against the CPU oracle's forward + autograd of the same batch (train_cls_voxel.py:277-287).
+    'reference' = the reference's own initialisation (zero positional embedding, unit LayerNorm gains: what the bench runs),
+    'exercise_all' = every zero / one-initialised tensor perturbed so that bias / affine / positional paths carry signal."""
+    kw = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=32, cell=6, patch=5, n_classes=40)
+    sd = vo.init_state_dict(seed=9, exercise_all=(init == 'exercise_all'), **kw)
+    x, y = vo.synthetic_batch(64, 32, 40, seed=9)
+    assert not L.lib().s3d_get_deterministic()
+    eng = s3d.VoxelEngine(device=DEV, **kw)
+    eng.load_state_dict(sd)
+    xd, yd = x.to(DEV), y.to(DEV)
+    ref_logits, ref_loss, ref_grads = vo.loss_and_grads(sd, x, y, backbone=kw['backbone'], embed_layer='VoxelEmbed', cell=6, patch=5)
+    # (1) the inference entry points
+    logits = eng.forward(xd).cpu()
+    err = float((logits - ref_logits).abs().max())
+    assert err <= LOGIT_TOL, f'logits max abs err {err:.3e}'
+    top2 = ref_logits.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * LOGIT_TOL
+    assert int(clear.sum()) >= 56, 'too few clear-cut decisions for the argmax check to mean anything'
+    assert torch.equal(logits.argmax(1)[clear], ref_logits.argmax(1)[clear])
+    # (2) the training entry point bench.py times: fused loss end + backward, default (atomic split-K) dispatch
+    eng.zero_grad()
+    loss = float(eng.forward_loss(xd, yd))
+    assert abs(loss - float(ref_loss)) <= LOGIT_TOL, (loss, float(ref_loss))
+    assert float((eng.workspace(64).logits.cpu() - ref_logits).abs().max()) <= LOGIT_TOL
+    eng.backward(64)
+    grads = {k: eng.arena.grad(k) for k in eng.shapes}
+    assert set(grads) == set(ref_grads)
+    stats = check_grads_against_oracle(grads, ref_grads, rtol=3e-3)
+    worst = max(stats.items(), key=lambda kv: kv[1][0])
+    print(f'cfg-2 B=64 [{init}]: logits err {err:.2e}, loss err {abs(loss - float(ref_loss)):.2e}, worst grad rms err / rms '
+          f'{worst[1][0]:.4f} ({worst[0]}), worst block {max(v[1] for v in stats.values()):.4f}, worst entry {max(v[2] for v in stats.values()):.3f}')
+    # (3) the unfused chain (forward + cross_entropy + backward from d(logits)) lands on the same gradients
+    eng.zero_grad()
+    eng.forward(xd); eng.cross_entropy(64, yd); eng.backward(64)
+    check_grads_against_oracle({k: eng.arena.grad(k) for k in eng.shapes}, ref_grads, rtol=3e-3)
 
 
 @pytest.mark.parametrize('weighted', [False, True])
