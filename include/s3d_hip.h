@@ -219,6 +219,22 @@ typedef struct S3dHeadArgs {
 int s3d_head_fwd(const S3dHeadArgs* args, s3d_stream_t stream);
 int s3d_head_bwd(const S3dHeadArgs* args, s3d_stream_t stream);
 
+/* AMSoftmaxLayer as a PER-ROW head (models/3DViT/model.py:123-142, selected by cfg.model.head == 'AMSoftmax' at :230-231 / :427-428: the
+ * per-point head of PointTransformerSeg, B*N rows): logits = s * (x / max(|x|, 1e-12)) @ (W / max(|W[:, c]|, 1e-12)), W [D][C].  Factored
+ * as a row normalisation around the ordinary Linear GEMMs (s3d_gemm forward / dgrad / wgrad) on the weight Wl[c][d] = s * W[d][c] / |W[:, c]|:
+ *   s3d_l2norm_rows_fwd   xn = x / |x| as split-bf16 operand planes (lo may be NULL), inv_norm[r] = 1 / max(|x_r|, 1e-12)
+ *   s3d_l2norm_rows_bwd   dx = (dxn - xn (xn . dxn)) * inv_norm            (dx may alias dxn)
+ *   s3d_am_weight_fwd     Wl fp32 [C][ldw] (pad columns untouched) and inv_w[c] = 1 / max(|W[:, c]|, 1e-12)
+ *   s3d_am_weight_bwd     dW[d][c] += s * (dWl[c][d] - wn[d][c] (wn[:, c] . dWl[c][:])) * inv_w[c]
+ * (s3d_head_fwd / s3d_head_bwd with am_softmax = 1 are the small-batch form used by the voxel head.) */
+int s3d_l2norm_rows_fwd(const float* x, long ldx, long rows, int D, float* inv_norm, uint16_t* hi, uint16_t* lo, long ldo,
+                        s3d_stream_t stream);
+int s3d_l2norm_rows_bwd(const float* dxn, long lddxn, const float* x, long ldx, const float* inv_norm, long rows, int D, float* dx,
+                        long lddx, s3d_stream_t stream);
+int s3d_am_weight_fwd(const float* W, int D, int C, float scale, float* Wl, int ldw, float* inv_w, s3d_stream_t stream);
+int s3d_am_weight_bwd(const float* dWl, int ldw, const float* W, const float* inv_w, int D, int C, float scale, float* dW,
+                      s3d_stream_t stream);
+
 typedef struct S3dCeArgs {
     const float* logits; const long long* target; const float* weight;
     long rows; int C;
@@ -349,9 +365,24 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
     /* Split-precision backward (parity mode; train_cls_voxel.py:287 checked to ~1e-4 instead of the bf16 noise floor): low planes of every
      * bf16 gradient buffer above.  When dx_a_lo is set (then all of them must be, and acts->hpre_lo / the lo planes of the saved
      * activations), s3d_block(s)_bwd run every dgrad / wgrad as a three-MFMA split product on hi + lo operands without split-K, the
-     * attention backward in fp32, and keep every intermediate gradient as a hi + lo pair.  Several times slower; tests only. */
+     * attention backward in fp32, and keep every intermediate gradient as a hi + lo pair.  Several times slower; tests only.
+     * The forward that precedes it must have written PER-BLOCK low planes (xn1_lo, qkv_lo, xn2_lo, hact_lo of every S3dBlockActs entry
+     * distinct buffers) with S3dBlockShape::fuse = -1: the fused launches do not write qkv_lo, and low planes shared between blocks hold
+     * the LAST block's data -- the library can only check that the pointers are set. */
     uint16_t *dx_a_lo, *dx_b_lo, *dh_lo, *dqkv_lo, *datt_lo, *dx_b_lo_cls, *datt_lo_cls;
 } S3dBlockScratch;
+/* Workspace layout for callers that do not want to re-derive it (the shipped Python host allocates the same buffers one by one,
+ * simple3d-former_amd/engine.py::_BlockWorkspace / _BlockScratch): ONE device allocation holds the saved activations of `depth`
+ * consecutive blocks (acts[i].x_out aliases acts[i+1].x_in; low planes of xn1 / qkv / xn2 / hact shared by all blocks -- they only feed the
+ * next forward launch) and, with with_backward != 0, the backward scratch incl. the LayerNorm partial sums and, when
+ * shape->cls_only_block != 0, the class-row buffers.  s3d_block_workspace_bytes returns the size (0 on a bad shape); s3d_block_workspace_carve
+ * fills acts[0 .. depth) and *scratch (may be NULL when with_backward == 0) with pointers into `base` (256-byte aligned pieces; host-side
+ * arithmetic only, nothing is enqueued) and reports the sub-range [*zero_offset, *zero_offset + *zero_bytes) that the caller must clear
+ * ONCE before the first backward (the class-row buffers: only their class rows are ever written).  Split-precision parity mode (the *_lo
+ * gradient planes, hpre_lo) is not laid out here. */
+size_t s3d_block_workspace_bytes(const S3dBlockShape* shape, int depth, int with_backward);
+int s3d_block_workspace_carve(const S3dBlockShape* shape, int depth, int with_backward, void* base, size_t bytes, S3dBlockActs* acts,
+                              S3dBlockScratch* scratch, size_t* zero_offset, size_t* zero_bytes);
 int s3d_block_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts,
                   s3d_stream_t stream);
 /* in: d(x_out) in scratch->dx_a (+ bf16 copy dx_a_bf); out: d(x_in) in scratch->dx_a / dx_a_bf again. */

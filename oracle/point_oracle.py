@@ -171,7 +171,19 @@ def forward(sd, x, *, task, variant='3DViT', **kw):
     if task == 'cls':
         feats = feats.mean(1)
     hk = VARIANTS[variant]['head']
+    if hk + '.W' in sd:                   # cfg.model.head == 'AMSoftmax' (models/3DViT/model.py:230-231, 427-428)
+        return am_softmax_rows(feats, sd[hk + '.W'])
     return feats @ sd[hk + '.weight'].t() + sd[hk + '.bias']
+
+
+def am_softmax_rows(x, W, s=30.0):
+    """AMSoftmaxLayer.forward, models/3DViT/model.py:134-142: `B, N, C = x.shape` -- a 3-D input, i.e. the per-point head of
+    PointTransformerSeg (PointTransformerCls hands it the 2-D x.mean(1) and fails on that unpack in the reference itself)."""
+    B, N, C = x.shape
+    x2 = x.reshape(-1, C)
+    xn = x2 / torch.norm(x2, p=2, dim=1, keepdim=True).clamp(min=1e-12)
+    wn = W / torch.norm(W, p=2, dim=0, keepdim=True).clamp(min=1e-12)
+    return (xn @ wn * s).view(B, N, -1)
 
 
 def forward_images(sd, img, *, backbone, bf16=False):
@@ -252,7 +264,7 @@ def part_iou(logits, target, seg_classes):
 
 
 # ----------------------------------------------------------------------------- parameters / inputs
-def init_state_dict(*, backbone, n_classes, d_points, seed=9, variant='3DViT'):
+def init_state_dict(*, backbone, n_classes, d_points, seed=9, variant='3DViT', head='default'):
     """Deterministic (integer-hash) parameters with the reference's key names and shapes for every tensor the point
     forward touches (+ BatchNorm buffers).  Unused reference parameters (pos_embed, patch_embed.*, sa.last_pos_embed.*)
     are not generated."""
@@ -301,7 +313,10 @@ def init_state_dict(*, backbone, n_classes, d_points, seed=9, variant='3DViT'):
         p = f'transition_ups.{j}.'
         lin(p + 'fc1.0', ch, ch * 2); bn(p + 'fc1.2', ch)
         lin(p + 'fc2.0', ch, ch); bn(p + 'fc2.2', ch)
-    lin(vv['head'], n_classes, C0)
+    if head == 'AMSoftmax':               # AMSoftmaxLayer.W [in_feats][n_classes], xavier_normal_ (models/3DViT/model.py:132-133)
+        sd[vv['head'] + '.W'] = u((C0, n_classes), math.sqrt(6.0 / (C0 + n_classes)))
+    else:
+        lin(vv['head'], n_classes, C0)
     if vv['image']:                       # timm's 2-D stem / head, kept by the variants for forward_images
         sd['patch_embed.proj.weight'] = u((D, 3, 16, 16), 1.0 / math.sqrt(768)); sd['patch_embed.proj.bias'] = u((D,), 1.0 / math.sqrt(768))
         sd['pos_embed'] = u((1, 197, D), 0.02 * math.sqrt(3))

@@ -463,6 +463,63 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
 
 }  // namespace
 
+// ---- workspace layout of a block stack (mirrors engine.py::_BlockWorkspace / _BlockScratch; one allocation instead of ~25)
+namespace {
+struct Carver {
+    unsigned char* base; size_t off = 0;
+    template <typename T> T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (count * sizeof(T) + 255) / 256 * 256;
+        return p;
+    }
+};
+// LayerNorm-backward partial rows per LayerNorm: engine.py::ln_partial_blocks
+int ws_ln_partial_blocks(long rows) { return rows <= 8192 ? 208 : 416; }
+size_t block_ws_layout(const S3dBlockShape& sh, int depth, bool bwd, void* base, S3dBlockActs* acts, S3dBlockScratch* sc, size_t* zoff, size_t* zbytes) {
+    const size_t M = (size_t)sh.Bb * sh.N, D = sh.D, Hd = sh.hidden, BHN = (size_t)sh.Bb * sh.H * sh.N;
+    Carver c{static_cast<unsigned char*>(base)};
+    std::vector<float*> x(depth + 1);
+    for (int i = 0; i <= depth; ++i) x[i] = c.take<float>(M * D);
+    uint16_t* xn1_lo = c.take<uint16_t>(M * D); uint16_t* qkv_lo = c.take<uint16_t>(M * 3 * D);
+    uint16_t* xn2_lo = c.take<uint16_t>(M * D); uint16_t* hact_lo = c.take<uint16_t>(M * Hd);
+    for (int i = 0; i < depth; ++i) {
+        S3dBlockActs a;
+        memset(&a, 0, sizeof(a));
+        a.x_in = x[i]; a.x_out = x[i + 1]; a.x_mid = c.take<float>(M * D);
+        a.mean1 = c.take<float>(M); a.rstd1 = c.take<float>(M); a.mean2 = c.take<float>(M); a.rstd2 = c.take<float>(M);
+        a.lse = c.take<float>(BHN);
+        a.xn1_hi = c.take<uint16_t>(M * D); a.xn1_lo = xn1_lo; a.qkv_hi = c.take<uint16_t>(M * 3 * D); a.qkv_lo = qkv_lo;
+        a.att_hi = c.take<uint16_t>(M * D); a.att_lo = c.take<uint16_t>(M * D);         // att_lo per block: the attention backward's delta reads it
+        a.xn2_hi = c.take<uint16_t>(M * D); a.xn2_lo = xn2_lo;
+        a.hpre = c.take<uint16_t>(M * Hd); a.hact_hi = c.take<uint16_t>(M * Hd); a.hact_lo = hact_lo;
+        if (acts) acts[i] = a;
+    }
+    if (zoff) *zoff = 0;
+    if (zbytes) *zbytes = 0;
+    if (bwd) {
+        S3dBlockScratch s;
+        memset(&s, 0, sizeof(s));
+        s.dxn = c.take<float>(M * D); s.dx_a = c.take<float>(M * D); s.dx_b = c.take<float>(M * D);
+        s.dx_a_bf = c.take<uint16_t>(M * D); s.dx_b_bf = c.take<uint16_t>(M * D);
+        s.dh = c.take<uint16_t>(M * Hd); s.dqkv = c.take<uint16_t>(M * 3 * D); s.datt = c.take<uint16_t>(M * D);
+        s.delta = c.take<float>(BHN);
+        s.ln_partial_blocks = ws_ln_partial_blocks((long)M);
+        s.ln_partial = c.take<float>((size_t)2 * depth * s.ln_partial_blocks * 2 * D);
+        if (sh.cls_only_block) {
+            const size_t z0 = c.off;
+            s.dx_b_cls = c.take<float>(M * D); s.dx_b_bf_cls = c.take<uint16_t>(M * D); s.datt_cls = c.take<uint16_t>(M * D);
+            if (zoff) *zoff = z0;
+            if (zbytes) *zbytes = c.off - z0;
+        }
+        if (sc) *sc = s;
+    }
+    return c.off;
+}
+bool block_ws_shape_ok(const S3dBlockShape* sh, int depth) {
+    return sh && depth >= 1 && depth <= 64 && sh->Bb > 0 && sh->N > 0 && sh->D > 0 && sh->H > 0 && sh->hidden > 0 && sh->D % 8 == 0 && sh->hidden % 8 == 0;
+}
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------- extern "C"
 extern "C" {
 
@@ -580,6 +637,19 @@ int s3d_head_loss_fused(const S3dHeadLossArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_head_loss_fused: null args");
     return s3d_launch_head_loss(*a, st(s));
 }
+int s3d_l2norm_rows_fwd(const float* x, long ldx, long rows, int D, float* inv_norm, uint16_t* hi, uint16_t* lo, long ldo, s3d_stream_t s) {
+    return s3d_launch_l2norm_rows_fwd(x, ldx, rows, D, inv_norm, hi, lo, ldo, st(s));
+}
+int s3d_l2norm_rows_bwd(const float* dxn, long lddxn, const float* x, long ldx, const float* inv_norm, long rows, int D, float* dx, long lddx,
+                        s3d_stream_t s) {
+    return s3d_launch_l2norm_rows_bwd(dxn, lddxn, x, ldx, inv_norm, rows, D, dx, lddx, st(s));
+}
+int s3d_am_weight_fwd(const float* W, int D, int C, float scale, float* Wl, int ldw, float* inv_w, s3d_stream_t s) {
+    return s3d_launch_am_weight_fwd(W, D, C, scale, Wl, ldw, inv_w, st(s));
+}
+int s3d_am_weight_bwd(const float* dWl, int ldw, const float* W, const float* inv_w, int D, int C, float scale, float* dW, s3d_stream_t s) {
+    return s3d_launch_am_weight_bwd(dWl, ldw, W, inv_w, D, C, scale, dW, st(s));
+}
 int s3d_cross_entropy(const S3dCeArgs* a, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr, "s3d_cross_entropy: null args");
     return s3d_launch_ce(*a, st(s));
@@ -681,6 +751,20 @@ int s3d_stream_wait_event(s3d_stream_t s, void* ev) {
     return 0;
 }
 
+size_t s3d_block_workspace_bytes(const S3dBlockShape* sh, int depth, int with_backward) {
+    if (!block_ws_shape_ok(sh, depth)) { s3d_set_error("s3d_block_workspace_bytes: bad shape / depth"); return 0; }
+    return block_ws_layout(*sh, depth, with_backward != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+int s3d_block_workspace_carve(const S3dBlockShape* sh, int depth, int with_backward, void* base, size_t bytes, S3dBlockActs* acts,
+                              S3dBlockScratch* scratch, size_t* zero_offset, size_t* zero_bytes) {
+    S3D_REQUIRE(block_ws_shape_ok(sh, depth), "s3d_block_workspace_carve: bad shape / depth");
+    S3D_REQUIRE(base != nullptr && acts != nullptr && (!with_backward || scratch != nullptr), "s3d_block_workspace_carve: base, acts (and scratch with with_backward) required");
+    S3D_REQUIRE(((uintptr_t)base & 255) == 0, "s3d_block_workspace_carve: base must be 256-byte aligned");
+    const size_t need = block_ws_layout(*sh, depth, with_backward != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    S3D_REQUIRE(bytes >= need, "s3d_block_workspace_carve: %zu bytes given, %zu needed", bytes, need);
+    block_ws_layout(*sh, depth, with_backward != 0, base, acts, scratch, zero_offset, zero_bytes);
+    return 0;
+}
 int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
     S3D_REQUIRE(sh && p && a, "s3d_block_fwd: null args");
     return block_fwd(*sh, *p, *a, st(s));

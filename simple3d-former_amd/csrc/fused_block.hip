@@ -451,7 +451,10 @@ int launch_mlp1(const FusedMlpArgs& a, hipStream_t s) {
 }  // namespace
 
 bool s3d_fused_attn_ok(int Bb, int N, int D, int H) {
-    return (D == 192 || D == 384) && H * 64 == D && N >= 1 && N <= 32 && Bb >= 1;
+    // small-batch shapes only, like the MLP half: with 1e4 - 1e5 short sequences (group_embed pass 1 on a deit_tiny / deit_small backbone)
+    // every pair of sequences would re-stream its head's 192-row weight slice and recompute norm1 H times, where the 128-row GEMM tiles
+    // re-read the weights 4x less often; only cfg-1 / cfg-2 sizes were measured in favour of the fused launch
+    return (D == 192 || D == 384) && H * 64 == D && N >= 1 && N <= 32 && Bb >= 1 && (long)Bb * N <= 8192;
 }
 bool s3d_fused_mlp1_ok(long M, int D, int hidden) {
     // small-batch shapes only: from ~8 k rows on the 128-row GEMM tiles re-read the weights less often than 64-row bands do

@@ -46,6 +46,11 @@ int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
                     int zero_grad, const bf16_t* g_wire, hipStream_t s);
 int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
+int s3d_launch_l2norm_rows_fwd(const float* x, long ldx, long rows, int D, float* inv_norm, bf16_t* hi, bf16_t* lo, long ldo, hipStream_t s);
+int s3d_launch_l2norm_rows_bwd(const float* dxn, long lddxn, const float* x, long ldx, const float* inv_norm, long rows, int D, float* dx, long lddx,
+                               hipStream_t s);
+int s3d_launch_am_weight_fwd(const float* W, int D, int C, float scale, float* Wl, int ldw, float* inv_w, hipStream_t s);
+int s3d_launch_am_weight_bwd(const float* dWl, int ldw, const float* W, const float* inv_w, int D, int C, float scale, float* dW, hipStream_t s);
 
 // ---- point-cloud operators (points.hip) ----
 int s3d_launch_fps(const float* xyz, long xyz_ld, const long long* start, int B, int N, int npoint, int* out_idx,

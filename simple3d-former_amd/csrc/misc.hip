@@ -741,3 +741,94 @@ int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s) {
     S3D_CHECK_LAUNCH("pack_bf16");
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------- AM-softmax as a per-row head
+// AMSoftmaxLayer.forward (models/3DViT/model.py:134-142; the same class at models/vit_3d_2d_pretrain.py:50-56) on many rows (the
+// per-point head of PointTransformerSeg: B*N = 65 536 rows): logits = s * (x / max(|x|, 1e-12)) @ (W / max(|W[:, c]|, 1e-12)).
+// Factored as a row normalisation (these kernels) around the ordinary Linear-layer GEMMs with the weight Wl[c][d] = s * W[d][c] / |W[:, c]|:
+//   s3d_l2norm_rows_fwd   xn = x / |x|  -> split-bf16 GEMM operand planes, 1 / |x| saved per row
+//   s3d_l2norm_rows_bwd   dx = (dxn - xn (xn . dxn)) / |x|
+//   s3d_am_weight_fwd     Wl (fp32 [C][ldw]) and 1 / |W[:, c]|
+//   s3d_am_weight_bwd     dW[d][c] += s * (dWl[c][d] - wn[d][c] (wn[:, c] . dWl[c][:])) / |W[:, c]|
+// (the clamps are inactive for any non-degenerate input and, like autograd's, have no backward term.)
+__global__ __launch_bounds__(256) void l2norm_rows_fwd_kernel(const float* __restrict__ x, long ldx, long rows, int D, float* __restrict__ inv_norm,
+                                                              bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, long ldo) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const float* xr = x + r * ldx;
+        float ss = 0.f;
+        for (int d = lane; d < D; d += 64) ss += xr[d] * xr[d];
+        const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+        if (lane == 0) inv_norm[r] = inv;
+        for (int d = lane; d < D; d += 64) {
+            bf16_t h, l;
+            split_bf16(xr[d] * inv, h, l);
+            hi[r * ldo + d] = h;
+            if (lo) lo[r * ldo + d] = l;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ dxn, long lddxn, const float* __restrict__ x, long ldx,
+                                                              const float* __restrict__ inv_norm, long rows, int D, float* __restrict__ dx, long lddx) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const float inv = inv_norm[r];
+        float dot = 0.f;
+        for (int d = lane; d < D; d += 64) dot += x[r * ldx + d] * inv * dxn[r * lddxn + d];
+        dot = wave_sum(dot);
+        for (int d = lane; d < D; d += 64) dx[r * lddx + d] = (dxn[r * lddxn + d] - x[r * ldx + d] * inv * dot) * inv;   // in place is fine: one reader per entry
+    }
+}
+// one wave per class
+__global__ __launch_bounds__(256) void am_weight_fwd_kernel(const float* __restrict__ W, int D, int C, float s, float* __restrict__ Wl, int ldw,
+                                                            float* __restrict__ inv_w) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float ss = 0.f;
+    for (int d = lane; d < D; d += 64) { const float w = W[(long)d * C + c]; ss += w * w; }
+    const float inv = 1.0f / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    if (lane == 0) inv_w[c] = inv;
+    for (int d = lane; d < D; d += 64) Wl[(long)c * ldw + d] = s * W[(long)d * C + c] * inv;
+}
+__global__ __launch_bounds__(256) void am_weight_bwd_kernel(const float* __restrict__ dWl, int ldw, const float* __restrict__ W, const float* __restrict__ inv_w,
+                                                            int D, int C, float s, float* __restrict__ dW) {
+    const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const float inv = inv_w[c];
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += W[(long)d * C + c] * inv * dWl[(long)c * ldw + d];
+    dot = wave_sum(dot);
+    for (int d = lane; d < D; d += 64) dW[(long)d * C + c] += s * (dWl[(long)c * ldw + d] - W[(long)d * C + c] * inv * dot) * inv;
+}
+
+int s3d_launch_l2norm_rows_fwd(const float* x, long ldx, long rows, int D, float* inv_norm, bf16_t* hi, bf16_t* lo, long ldo, hipStream_t s) {
+    S3D_REQUIRE(x && inv_norm && hi && D > 0 && ldx >= D && ldo >= D, "l2norm_rows_fwd: x, inv_norm, hi required; ldx, ldo >= D = %d", D);
+    if (rows <= 0) return 0;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(l2norm_rows_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, rows, D, inv_norm, hi, lo, ldo);
+    S3D_CHECK_LAUNCH("l2norm_rows_fwd");
+    return 0;
+}
+int s3d_launch_l2norm_rows_bwd(const float* dxn, long lddxn, const float* x, long ldx, const float* inv_norm, long rows, int D, float* dx, long lddx,
+                               hipStream_t s) {
+    S3D_REQUIRE(dxn && x && inv_norm && dx && D > 0, "l2norm_rows_bwd: null pointer");
+    if (rows <= 0) return 0;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dxn, lddxn, x, ldx, inv_norm, rows, D, dx, lddx);
+    S3D_CHECK_LAUNCH("l2norm_rows_bwd");
+    return 0;
+}
+int s3d_launch_am_weight_fwd(const float* W, int D, int C, float scale, float* Wl, int ldw, float* inv_w, hipStream_t s) {
+    S3D_REQUIRE(W && Wl && inv_w && D > 0 && C > 0 && ldw >= D, "am_weight_fwd: W [D][C], Wl [C][ldw >= D], inv_w [C] required");
+    hipLaunchKernelGGL(am_weight_fwd_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, W, D, C, scale, Wl, ldw, inv_w);
+    S3D_CHECK_LAUNCH("am_weight_fwd");
+    return 0;
+}
+int s3d_launch_am_weight_bwd(const float* dWl, int ldw, const float* W, const float* inv_w, int D, int C, float scale, float* dW, hipStream_t s) {
+    S3D_REQUIRE(dWl && W && inv_w && dW && D > 0 && C > 0 && ldw >= D, "am_weight_bwd: null pointer / ldw < D");
+    hipLaunchKernelGGL(am_weight_bwd_kernel, dim3((unsigned)((C + 3) / 4)), dim3(256), 0, s, dWl, ldw, W, inv_w, D, C, scale, dW);
+    S3D_CHECK_LAUNCH("am_weight_bwd");
+    return 0;
+}

@@ -143,6 +143,10 @@ class _BlockWorkspace:
         pushing out the saved activations the backward is about to read (the batch-64 step is cache-resident: DESIGN section 6)."""
         M = Bb * N
         shared_lo = (not precise and os.environ.get('S3D_SHARED_LO', '1') != '0') if shared_lo is None else bool(shared_lo)
+        if precise and shared_lo:
+            # the split-precision backward reads every block's OWN xn1_lo / qkv_lo / xn2_lo / hact_lo (capi.hip block_bwd_split checks the
+            # pointers, it cannot check whose data they hold)
+            raise ValueError('_BlockWorkspace(precise=True) needs per-block low planes: shared_lo must be False')
         self.shared_lo = shared_lo
         nlo = 1 if shared_lo else depth
         ln_fuse = LN_FUSE if ln_fuse is None else bool(ln_fuse)

@@ -56,7 +56,7 @@ def level_plan(variant, D, n_points):
     return C0, [n_points // (v['first_div'] * 4 ** i) for i in range(v['levels'])], [C0 * 2 ** (i + 1) for i in range(v['levels'])]
 
 
-def point_param_shapes(backbone, n_classes, d_points, variant='3DViT'):
+def point_param_shapes(backbone, n_classes, d_points, variant='3DViT', head='default'):
     cfg = BACKBONES[backbone]
     D, depth = cfg['embed_dim'], cfg['depth']
     vv = VARIANTS[variant]
@@ -96,7 +96,10 @@ def point_param_shapes(backbone, n_classes, d_points, variant='3DViT'):
         sh[p + 'fc2.0.weight'] = (ch, ch); sh[p + 'fc2.0.bias'] = (ch,)
         sh[p + 'fc2.2.weight'] = (ch,); sh[p + 'fc2.2.bias'] = (ch,)
     hk = vv['head']
-    sh[hk + '.weight'] = (n_classes, C0); sh[hk + '.bias'] = (n_classes,)
+    if head == 'AMSoftmax':               # AMSoftmaxLayer.W [in_feats][n_classes] (models/3DViT/model.py:132, selected at :230-231 / :427-428)
+        sh[hk + '.W'] = (C0, n_classes)
+    else:
+        sh[hk + '.weight'] = (n_classes, C0); sh[hk + '.bias'] = (n_classes,)
     if vv['image']:
         sh.update(image_param_shapes(D)[1])
     return sh
@@ -169,6 +172,58 @@ class _Linear:
             g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kpad, K=self.opad,
                        alpha=1.0, **({'C': dx, 'ldc': self.kpad} if dx is not None else {}), **kw)
             L.check(lib.s3d_gemm(0, 1, 0, dx_epi, ctypes.byref(g), 1, s), self.key + ' dgrad')
+
+
+class _AmHead:
+    """AMSoftmaxLayer (models/3DViT/model.py:123-142; cfg.model.head == 'AMSoftmax', :427-428) as the per-point head of the
+    part-segmentation models: logits = 30 * (x / |x|) @ (W / |W[:, c]|), W [C0][n_classes].  Runs as a row normalisation
+    (s3d_l2norm_rows_fwd / _bwd) around the same GEMMs as the Linear head, on the derived weight Wl[c][d] = s * W[d][c] / |W[:, c]|
+    (s3d_am_weight_fwd, refreshed with the other weight planes; its gradient is mapped back onto W by s3d_am_weight_bwd)."""
+    SCALE = 30.0
+
+    def __init__(self, eng, key, out_pad):
+        a = eng.arena
+        self.key, self.eng = key, eng
+        self.inn, self.out = a.shapes[key + '.W']
+        self.kpad, self.opad = _round_up(self.inn, 8), out_pad
+        dev = eng.device
+        self.wl = torch.zeros(self.opad, self.kpad, dtype=torch.float32, device=dev)          # Wl; pad rows / columns stay zero
+        self.w = torch.zeros(2, self.opad, self.kpad, dtype=torch.bfloat16, device=dev)
+        self.inv_w = torch.empty(self.out, dtype=torch.float32, device=dev)
+        self.gpad = torch.zeros(self.opad, self.kpad, dtype=torch.float32, device=dev)
+        self.bias = torch.zeros(self.opad, dtype=torch.float32, device=dev)                   # the layer has no bias
+
+    def refresh(self):
+        a, lib, s = self.eng.arena, self.eng.lib, L.current_stream()
+        L.check(lib.s3d_am_weight_fwd(L.ptr(a.param(self.key + '.W')), self.inn, self.out, ctypes.c_float(self.SCALE), L.ptr(self.wl),
+                                      self.kpad, L.ptr(self.inv_w), s), 'am_weight_fwd')
+        L.check(lib.s3d_split_bf16(L.ptr(self.wl), L.ptr(self.w[0]), L.ptr(self.w[1]), ctypes.c_long(self.opad), ctypes.c_long(self.kpad),
+                                   ctypes.c_long(self.kpad), s), 'split Wl')
+
+    def normalise(self, x, rows, inv_norm, planes):
+        """x fp32 [rows][C0] -> x / |x| as the GEMM operand planes [rows][kpad]; keeps 1 / |x| for the backward."""
+        L.check(self.eng.lib.s3d_l2norm_rows_fwd(L.ptr(x), ctypes.c_long(self.inn), ctypes.c_long(rows), self.inn, L.ptr(inv_norm), L.ptr(planes[0]),
+                                                 L.ptr(planes[1]), ctypes.c_long(self.kpad), L.current_stream()), 'l2norm_rows_fwd')
+
+    def fwd(self, a_hi, a_lo, rows, epi, **kw):
+        g = L.fill(L.S3dGemmArgs(), A_hi=a_hi, A_lo=a_lo, lda=self.kpad, B_hi=self.w[0], B_lo=self.w[1], ldb=self.kpad,
+                   M=rows, N=self.opad, K=self.kpad, bias=self.bias, alpha=1.0, **kw)
+        L.check(self.eng.lib.s3d_gemm(0, 0, 1 if self.eng.split else 0, epi, ctypes.byref(g), 1, L.current_stream()), self.key)
+
+    def bwd(self, dy_bf, xn_hi, rows, x, inv_norm, dx):
+        """dy_bf [rows][opad] bf16, xn_hi the normalised rows; accumulates dW; dx (fp32 [rows][C0]) = gradient wrt the UN-normalised x."""
+        lib, s, a = self.eng.lib, L.current_stream(), self.eng.arena
+        self.gpad.zero_()
+        g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=xn_hi, ldb=self.kpad, M=self.opad, N=self.kpad, K=rows,
+                   C=self.gpad, ldc=self.kpad, alpha=1.0)
+        L.check(lib.s3d_gemm(1, 1, 0, 6, ctypes.byref(g), 0, s), self.key + ' wgrad')
+        L.check(lib.s3d_am_weight_bwd(L.ptr(self.gpad), self.kpad, L.ptr(a.param(self.key + '.W')), L.ptr(self.inv_w), self.inn, self.out,
+                                      ctypes.c_float(self.SCALE), L.ptr(a.grad(self.key + '.W')), s), 'am_weight_bwd')
+        g = L.fill(L.S3dGemmArgs(), A_hi=dy_bf, lda=self.opad, B_hi=self.w[0], ldb=self.kpad, M=rows, N=self.kpad, K=self.opad,
+                   alpha=1.0, C=dx, ldc=self.kpad)
+        L.check(lib.s3d_gemm(0, 1, 0, 4, ctypes.byref(g), 1, s), self.key + ' dgrad')
+        L.check(lib.s3d_l2norm_rows_bwd(L.ptr(dx), ctypes.c_long(self.kpad), L.ptr(x), ctypes.c_long(self.inn), L.ptr(inv_norm), ctypes.c_long(rows),
+                                        self.inn, L.ptr(dx), ctypes.c_long(self.kpad), s), 'l2norm_rows_bwd')
 
 
 class _GroupProj:
@@ -250,7 +305,7 @@ class _TwoChainStep:
 
 class PointEngine:
     def __init__(self, *, backbone='deit_tiny_patch16_224', n_points, d_points, n_classes, task='cls', device='cuda', split=True,
-                 lr=0.01, momentum=0.9, bn_momentum=0.1, variant='3DViT'):
+                 lr=0.01, momentum=0.9, bn_momentum=0.1, variant='3DViT', head='default'):
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")
         if task not in ('cls', 'seg'):
@@ -259,6 +314,14 @@ class PointEngine:
             raise ValueError(f'unknown point model {variant!r}; expected one of {sorted(VARIANTS)}')
         if variant != '3DViT' and task != 'seg':
             raise ValueError(f'models/{variant}/model.py defines PointTransformerSeg only')
+        if head not in ('default', 'AMSoftmax'):
+            raise ValueError(f'unknown head {head!r}')
+        if head == 'AMSoftmax' and task != 'seg':
+            # AMSoftmaxLayer.forward unpacks `B, N, C = x.shape` (models/3DViT/model.py:135); PointTransformerCls hands it the 2-D
+            # x.mean(1) (:325, :336), so the reference itself raises on the first forward -- there is nothing to be parity-compatible with
+            raise ValueError("head='AMSoftmax' with the classification model fails in the reference itself (AMSoftmaxLayer.forward "
+                             "needs a [B, N, C] input, models/3DViT/model.py:135); it is the per-point head of PointTransformerSeg")
+        self.am = head == 'AMSoftmax'
         self.lib = L.lib()
         self.device = torch.device(device)
         if self.device.type != 'cuda':
@@ -282,7 +345,7 @@ class PointEngine:
         self._hyper_host = [float(lr), float(momentum), 1.0, float(bn_momentum)]
         self.hyper = torch.tensor(self._hyper_host, dtype=torch.float32, device=self.device)
         self.training = True                # BatchNorm mode: batch statistics (model.train()) vs running statistics
-        self.shapes = point_param_shapes(backbone, n_classes, d_points, variant)
+        self.shapes = point_param_shapes(backbone, n_classes, d_points, variant, head)
         self.arena = ParamArena(self.shapes, self.device)
         self.buf = torch.zeros_like(self.arena.p)                   # SGD momentum buffer
         self.sgd_steps = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -303,7 +366,10 @@ class PointEngine:
             self.tu.append(dict(l1=_Linear(self, p + 'fc1.0'), b1=_BatchNorm(self, p + 'fc1.2', ch),
                                 l2=_Linear(self, p + 'fc2.0'), b2=_BatchNorm(self, p + 'fc2.2', ch), ch=ch))
         self.head_key = self.vv['head']
-        self.head = _Linear(self, self.head_key, out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
+        if self.am:
+            self.head = _AmHead(self, self.head_key, _round_up(n_classes, 8))
+        else:
+            self.head = _Linear(self, self.head_key, out_pad=_round_up(n_classes, 8)) if task == 'seg' else None
         self._linears = self.fc1 + self.fcp + [t['gp'] for t in self.td] + [t['c1'] for t in self.td] + \
             [t[k] for t in self.tu for k in ('l1', 'l2')] + ([self.head] if self.head else [])
         self.bns = {t[k].key: t[k] for t in self.td for k in ('b0', 'b1')}
@@ -480,7 +546,8 @@ class PointEngine:
             ws.logits = torch.empty(B, self.ncls, **f32); ws.dlogits = torch.empty(B, self.ncls, **f32)
         else:
             cp = self.head.opad
-            ws.v1p = torch.empty(2, BN, C0, **b16) if self.levels else None
+            ws.v1p = torch.empty(2, BN, C0, **b16) if (self.levels or self.am) else None
+            ws.inv_norm = torch.empty(BN, **f32) if self.am else None
             ws.logits = torch.empty(BN, cp, **f32); ws.dlogits = torch.empty(BN, cp, **f32)
             ws.dlb = torch.empty(BN, cp, **b16)
         self._ws[B] = ws
@@ -656,7 +723,10 @@ class PointEngine:
                 self._pack(u.out, ch, ch, B * u.Sf, ws.tu[j + 1].inp1)
                 coarse_planes = ws.tu[j + 1].inp1
         if nl == 0:                                              # 3DViT_0_layer: the head reads the tokens (C0 = D)
-            ws.v1p = ws.tp
+            if self.am:
+                self.head.normalise(ws.t, BN, ws.inv_norm, ws.v1p)
+            else:
+                ws.v1p = ws.tp
             self.head.fwd(ws.v1p[0], ws.v1p[1], BN, 4, C=ws.logits, ldc=self.head.opad)
             return ws.logits.view(B, N, self.head.opad)[..., :self.ncls]
         v1 = ws.tu[-1].out
@@ -664,7 +734,10 @@ class PointEngine:
             L.check(lib.s3d_mean_points(L.ptr(v1), B, N, C0, L.ptr(ws.feat), s), 'mean')
             L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
             return ws.logits
-        self._pack(v1, C0, C0, BN, ws.v1p)
+        if self.am:
+            self.head.normalise(v1, BN, ws.inv_norm, ws.v1p)
+        else:
+            self._pack(v1, C0, C0, BN, ws.v1p)
         self.head.fwd(ws.v1p[0], ws.v1p[1], BN, 4, C=ws.logits, ldc=self.head.opad)
         return ws.logits.view(B, N, self.head.opad)[..., :self.ncls]
 
@@ -711,7 +784,10 @@ class PointEngine:
         else:
             cp = self.head.opad
             self._pack_bf(ws.dlogits, cp, BN, ws.dlb)
-            self.head.bwd(ws.dlb, ws.v1p[0], BN, dx=ws.dv1 if self.levels else ws.dt, dx_epi=4)
+            if self.am:
+                self.head.bwd(ws.dlb, ws.v1p[0], BN, ws.tu[-1].out if self.levels else ws.t, ws.inv_norm, ws.dv1 if self.levels else ws.dt)
+            else:
+                self.head.bwd(ws.dlb, ws.v1p[0], BN, dx=ws.dv1 if self.levels else ws.dt, dx_epi=4)
         # transition ups (reverse)
         nl = self.levels
         dfine = ws.dv1                                           # gradient wrt the last tu's output [BN, C0]

@@ -174,9 +174,15 @@ class _PointTransformer(VisionTransformer):
             self.use_pos_embed = True
         else:
             self.patch_embed = PointEmbed(cfg)
-        if getattr(cfg.model, 'head', 'default') == 'AMSoftmax':
-            raise NotImplementedError('AM-softmax head on the point path is not built (config/model/3DViT*.yaml use head: default)')
-        setattr(self, vv['head'], nn.Linear(c0, n_c))
+        self._head_kind = 'AMSoftmax' if getattr(cfg.model, 'head', 'default') == 'AMSoftmax' else 'default'
+        if self._head_kind == 'AMSoftmax':                 # models/3DViT/model.py:230-231, 427-428 (new_head in the variants, e.g. 3DViT_1_layer:218-219)
+            if self._task != 'seg':
+                raise ValueError("cfg.model.head == 'AMSoftmax' with PointTransformerCls fails in the reference itself: AMSoftmaxLayer.forward "
+                                 "unpacks `B, N, C = x.shape` (models/3DViT/model.py:135) and the classifier feeds it the 2-D x.mean(1)")
+            from .voxel_model import AMSoftmaxLayer
+            setattr(self, vv['head'], AMSoftmaxLayer(c0, n_c))
+        else:
+            setattr(self, vv['head'], nn.Linear(c0, n_c))
         self.pos_embed_type = 'default'
         self.transition_downs = nn.ModuleList()
         for npoint, ch in zip(keep, chans):
@@ -195,7 +201,7 @@ class _PointTransformer(VisionTransformer):
         if self._engine is not None and self._engine.device == device:
             return self._engine
         eng = PointEngine(backbone=self.transformer_backbone, n_points=self._cfg_io[0], d_points=self._cfg_io[1],
-                          n_classes=self.n_classes, task=self._task, device=device, variant=self._variant)
+                          n_classes=self.n_classes, task=self._task, device=device, variant=self._variant, head=self._head_kind)
         own = dict(self.named_parameters())
         sd = {k: own[k].detach() for k in eng.shapes}
         bufs = dict(self.named_buffers())

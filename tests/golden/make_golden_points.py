@@ -37,6 +37,9 @@ CASES = {
                                    n_classes=50, batch=2),
     'pts_seg0_tiny_n64_b2': dict(task='seg', variant='3DViT_0_layer', backbone='deit_tiny_patch16_224', n_points=64, d_points=22,
                                  n_classes=50, batch=2),
+    # cfg.model.head == 'AMSoftmax' (models/3DViT/model.py:427-428): AMSoftmaxLayer as the per-point head
+    'pts_seg_tiny_n64_am_b2': dict(task='seg', backbone='deit_tiny_patch16_224', n_points=64, d_points=22, n_classes=50, batch=2,
+                                   head='AMSoftmax'),
     'pts_seglwf_tiny_n64_b2': dict(task='seg', variant='3DViT_LWF', backbone='deit_tiny_patch16_224', n_points=64, d_points=22,
                                    n_classes=50, batch=2, lwf=True, lambda_weight=0.1),
 }
@@ -49,7 +52,7 @@ def build_reference(cfg):
     variant = cfg.get('variant', '3DViT')
     mod = importlib.import_module(f'models.{variant}.model')
     c = types.SimpleNamespace(num_point=cfg['n_points'], num_class=cfg['n_classes'], input_dim=cfg['d_points'],
-                              model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head='default',
+                              model=types.SimpleNamespace(nblocks=4, nneighbor=16, transformer_dim=512, head=cfg.get('head', 'default'),
                                                           transformer_backbone=cfg['backbone'], pretrained=False, name=variant))
     return getattr(mod, 'PointTransformerCls' if cfg['task'] == 'cls' else 'PointTransformerSeg')(c)
 
@@ -57,7 +60,8 @@ def build_reference(cfg):
 def run_case(name, cfg):
     variant = cfg.get('variant', '3DViT')
     vv = po.VARIANTS[variant]
-    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9, variant=variant)
+    sd = po.init_state_dict(backbone=cfg['backbone'], n_classes=cfg['n_classes'], d_points=cfg['d_points'], seed=9, variant=variant,
+                            head=cfg.get('head', 'default'))
     model = build_reference(cfg)
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected, unexpected                      # every generated key exists in the reference (name + shape contract)

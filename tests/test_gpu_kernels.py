@@ -205,7 +205,8 @@ def test_gemm_wgrad_into_a_sub_matrix():
 
 
 @pytest.mark.parametrize('M,N,K', [(130, 192, 128),
-                                   (33003, 768, 512)])      # 128x256 sixteen-wave forward tiles / 256x128 eight-wave dgrad tiles
+                                   (33003, 768, 512),       # 128x256 sixteen-wave forward tiles / 256x128 eight-wave dgrad tiles
+                                   (33003, 768, 768)])      # the encoder layer's linear1 / linear2 at cfg-3 (k = D = 768)
 def test_gemm_epilogues_gelu_resid_token_dgelu(M, N, K):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(M, K, generator=g).to(DEV)
@@ -244,6 +245,12 @@ def test_gemm_epilogues_gelu_resid_token_dgelu(M, N, K):
     a = aux.double().requires_grad_(True)
     gp = torch.autograd.grad(F.gelu(a).sum(), a)[0]
     assert rms_err(o.float(), (dyh.double() @ w2h.double()) * gp) < 1e-2
+    # RELU (linear1 of the group_embed encoder layer, vit_3d_2d_pretrain.py:381): aux = bf16(pre), O = split(relu(pre)); DRELU: O = bf16(acc * (aux > 0))
+    ops.gemm(0, 0, 1, 'RELU', A_hi=xh, A_lo=xl, lda=K, B_hi=wh, B_lo=wl, ldb=K, M=M, N=N, K=K, bias=b, aux=aux, ldaux=N, O_hi=oh, O_lo=ol, ldo=N)
+    assert rel_err(oh.float() + ol.float(), F.relu(pre_ref)) < 5e-5
+    assert rel_err(aux.float(), pre_ref) < 1e-2
+    ops.gemm(0, 1, 0, 'DRELU', A_hi=dyh, lda=K, B_hi=w2h, ldb=N, M=M, N=N, K=K, aux=aux, ldaux=N, O_hi=o, ldo=N)
+    assert rms_err(o.float(), (dyh.double() @ w2h.double()) * (aux.double() > 0)) < 1e-2
 
 
 @pytest.mark.parametrize('rows,D', [(7, 192), (1664, 384), (333, 768), (40000, 192), (9, 256), (64, 1024), (5000, 512)])
@@ -693,3 +700,76 @@ def test_assemble_tokens_fwd_bwd():
     back = torch.empty_like(src)
     L.check(L.lib().s3d_assemble_tokens_bwd(L.ptr(out), L.ptr(back), ctypes.c_long(B), n, D, L.current_stream()), 'asm bwd')
     assert torch.equal(back.view(B, n, D), ref[:, 1:])
+
+
+def test_block_stack_on_a_carved_workspace_equals_the_engine_layout():
+    """s3d_block_workspace_bytes / _carve: a depth-3 block stack (cfg-2 block shape, class-rows-only last block) forward + backward on ONE
+    caller allocation laid out by the library vs the same calls on the Python host's own buffers (deterministic mode: bitwise)."""
+    from simple3d_former_amd.engine import ParamArena, _BlockWorkspace, _BlockScratch, _cls_scratch
+    lib = L.lib()
+    lib.s3d_block_workspace_bytes.restype = ctypes.c_size_t
+    g = torch.Generator().manual_seed(12)
+    D, H, N, Bb, depth = 384, 6, 26, 16, 3
+    Hd, M = 4 * D, Bb * N
+    shapes = {}
+    for i in range(depth):
+        p = f'blocks.{i}.'
+        shapes.update({p + 'norm1.weight': (D,), p + 'norm1.bias': (D,), p + 'attn.qkv.weight': (3 * D, D), p + 'attn.qkv.bias': (3 * D,),
+                       p + 'attn.proj.weight': (D, D), p + 'attn.proj.bias': (D,), p + 'norm2.weight': (D,), p + 'norm2.bias': (D,),
+                       p + 'mlp.fc1.weight': (Hd, D), p + 'mlp.fc1.bias': (Hd,), p + 'mlp.fc2.weight': (D, Hd), p + 'mlp.fc2.bias': (D,)})
+    sd = {k: (1 + 0.1 * torch.randn(shp, generator=g)) if ('norm' in k and k.endswith('weight')) else torch.randn(shp, generator=g) * 0.05
+          for k, shp in shapes.items()}
+    x = torch.randn(M, D, generator=g)
+    dy = torch.zeros(M, D); dy[::N] = torch.randn(Bb, D, generator=g) * 0.1           # d(x_out) lives on the class rows only
+    was = lib.s3d_get_deterministic()
+    lib.s3d_set_deterministic(1)
+    try:
+        results = []
+        for carved in (False, True):
+            arena = ParamArena(shapes, torch.device(DEV)); arena.load(sd); arena.refresh_planes()
+            bp, bg = (L.S3dBlockParams * depth)(), (L.S3dBlockGrads * depth)()
+            for i in range(depth):
+                p = f'blocks.{i}.'
+                L.fill(bp[i], ln1_w=arena.param(p + 'norm1.weight'), ln1_b=arena.param(p + 'norm1.bias'), ln2_w=arena.param(p + 'norm2.weight'),
+                       ln2_b=arena.param(p + 'norm2.bias'), qkv_b=arena.param(p + 'attn.qkv.bias'), proj_b=arena.param(p + 'attn.proj.bias'),
+                       fc1_b=arena.param(p + 'mlp.fc1.bias'), fc2_b=arena.param(p + 'mlp.fc2.bias'),
+                       qkv_w_hi=arena.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=arena.lo_of(p + 'attn.qkv.weight'),
+                       proj_w_hi=arena.hi_of(p + 'attn.proj.weight'), proj_w_lo=arena.lo_of(p + 'attn.proj.weight'),
+                       fc1_w_hi=arena.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=arena.lo_of(p + 'mlp.fc1.weight'),
+                       fc2_w_hi=arena.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=arena.lo_of(p + 'mlp.fc2.weight'))
+                L.fill(bg[i], ln1_w=arena.grad(p + 'norm1.weight'), ln1_b=arena.grad(p + 'norm1.bias'), ln2_w=arena.grad(p + 'norm2.weight'),
+                       ln2_b=arena.grad(p + 'norm2.bias'), qkv_w=arena.grad(p + 'attn.qkv.weight'), qkv_b=arena.grad(p + 'attn.qkv.bias'),
+                       proj_w=arena.grad(p + 'attn.proj.weight'), proj_b=arena.grad(p + 'attn.proj.bias'), fc1_w=arena.grad(p + 'mlp.fc1.weight'),
+                       fc1_b=arena.grad(p + 'mlp.fc1.bias'), fc2_w=arena.grad(p + 'mlp.fc2.weight'), fc2_b=arena.grad(p + 'mlp.fc2.bias'))
+            if carved:
+                shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=Hd, eps=1e-6, split=1, cls_only_block=depth, fuse=0)
+                nbytes = lib.s3d_block_workspace_bytes(ctypes.byref(shape), depth, 1)
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+                assert buf.data_ptr() % 256 == 0
+                acts, scr = (L.S3dBlockActs * depth)(), L.S3dBlockScratch()
+                zo, zb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+                L.check(lib.s3d_block_workspace_carve(ctypes.byref(shape), depth, 1, L.ptr(buf), ctypes.c_size_t(nbytes), acts, ctypes.byref(scr),
+                                                      ctypes.byref(zo), ctypes.byref(zb)), 'carve')
+                buf.fill_(0xff)                                                    # poison: whatever is read must have been written
+                buf[zo.value:zo.value + zb.value].zero_()
+                view = lambda ptr, n, dt: buf[ptr - buf.data_ptr():ptr - buf.data_ptr() + n * torch.empty(0, dtype=dt).element_size()].view(dt)
+                x0, dxa, dxa_bf = view(acts[0].x_in, M * D, torch.float32), view(scr.dx_a, M * D, torch.float32), view(scr.dx_a_bf, M * D, torch.bfloat16)
+                xl = view(acts[depth - 1].x_out, M * D, torch.float32)
+                keep = buf
+            else:
+                ws = _BlockWorkspace(depth, Bb, N, D, H, Hd, DEV, True, cls_only=True)
+                scp = _BlockScratch(M, D, H, Hd, Bb * H * N, DEV, depth=depth)
+                scr, keep = _cls_scratch(scp.c, M, D, DEV)
+                shape, acts = ws.shape, ws.acts
+                x0, dxa, dxa_bf, xl = ws.x[0].view(-1), scp.dx_a.view(-1), scp.dx_a_bf.view(-1), ws.x[depth].view(-1)
+            x0.copy_(x.reshape(-1))
+            L.check(lib.s3d_blocks_fwd(ctypes.byref(shape), bp, acts, depth, L.current_stream()), 'blocks_fwd')
+            dxa.copy_(dy.reshape(-1)); dxa_bf.copy_(dy.reshape(-1).to(torch.bfloat16))
+            L.check(lib.s3d_blocks_bwd(ctypes.byref(shape), bp, bg, acts, ctypes.byref(scr), depth - 1, 0, L.current_stream()), 'blocks_bwd')
+            torch.cuda.synchronize()
+            results.append((xl.view(M, D)[::N].clone(), dxa.clone(), arena.g.clone()))
+        (y0, d0, g0), (y1, d1, g1) = results
+        assert torch.equal(y0, y1) and torch.isfinite(y1).all()                    # class rows of the stack's output
+        assert torch.equal(d0, d1) and torch.equal(g0, g1) and float(g1.abs().sum()) > 0
+    finally:
+        lib.s3d_set_deterministic(was)

@@ -293,7 +293,7 @@ def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
 @pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire'])
 def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
     """DataParallelTrainer on one GPU with a (forced) RCCL all-reduce of each of 3 gradient buckets, vs the plain eager fused step.
-    event_graph (default): ONE natively assembled graph with an event behind every backward segment, collectives launched from a
+    event_graph (opt-in: an event-record node costs more than the graph boundary it replaces on this runtime): ONE natively assembled graph with an event behind every backward segment, collectives launched from a
     side stream on those events (s3d_graph_marker / s3d_graph_events_at_markers); segment_graphs: one graph per segment, collectives in between."""
     import os
     import torch.distributed as dist

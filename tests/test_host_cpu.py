@@ -289,3 +289,55 @@ def test_point_schedules_match_the_reference_formulas():
     e = Eng()
     s = sch.EpochSchedule.for_partseg(e)
     assert s.begin_epoch(40) == 0.0125 and e.lr == 0.0125 and e.bn == 0.225
+
+
+@pytest.mark.parametrize('Bb,N,D,H,depth,cls_only', [(64, 26, 384, 6, 12, True), (8, 513, 192, 3, 2, False), (3, 15, 768, 3, 1, True)])
+def test_block_workspace_layout_is_consistent(built, Bb, N, D, H, depth, cls_only):
+    """s3d_block_workspace_bytes / _carve (host-side arithmetic only, so it runs without a GPU): every buffer lies inside the
+    allocation, 256-byte aligned, no two distinct buffers overlap, the residual stream chains block to block, the forward-only low
+    planes are shared, and the range to clear covers exactly the class-row buffers."""
+    built.s3d_block_workspace_bytes.restype = ctypes.c_size_t
+    sh = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=4 * D, eps=1e-6, split=1, cls_only_block=depth if cls_only else 0, fuse=0)
+    fwd_only = built.s3d_block_workspace_bytes(ctypes.byref(sh), depth, 0)
+    total = built.s3d_block_workspace_bytes(ctypes.byref(sh), depth, 1)
+    assert 0 < fwd_only < total
+    base = 0x7f0000000000
+    acts = (L.S3dBlockActs * depth)()
+    sc = L.S3dBlockScratch()
+    zo, zb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    L.check(built.s3d_block_workspace_carve(ctypes.byref(sh), depth, 1, ctypes.c_void_p(base), ctypes.c_size_t(total), acts, ctypes.byref(sc),
+                                            ctypes.byref(zo), ctypes.byref(zb)), 'carve')
+    assert built.s3d_block_workspace_carve(ctypes.byref(sh), depth, 1, ctypes.c_void_p(base), ctypes.c_size_t(total - 1), acts, ctypes.byref(sc),
+                                           ctypes.byref(zo), ctypes.byref(zb)) != 0                  # too small -> error, not a silent overrun
+    M, Hd, BHN = Bb * N, 4 * D, Bb * H * N
+    size = dict(x_in=4 * M * D, x_mid=4 * M * D, x_out=4 * M * D, mean1=4 * M, rstd1=4 * M, mean2=4 * M, rstd2=4 * M, lse=4 * BHN,
+                xn1_hi=2 * M * D, xn1_lo=2 * M * D, qkv_hi=6 * M * D, qkv_lo=6 * M * D, att_hi=2 * M * D, att_lo=2 * M * D, xn2_hi=2 * M * D,
+                xn2_lo=2 * M * D, hpre=2 * M * Hd, hact_hi=2 * M * Hd, hact_lo=2 * M * Hd)
+    spans = {}
+    for i in range(depth):
+        assert acts[i].hpre_lo is None
+        for f, nbytes in size.items():
+            ptr = getattr(acts[i], f)
+            assert ptr is not None and ptr % 256 == 0 and base <= ptr and ptr + nbytes <= base + total, (i, f)
+            spans.setdefault(ptr, nbytes)
+            assert spans[ptr] == nbytes
+        if i + 1 < depth:
+            assert acts[i].x_out == acts[i + 1].x_in
+            for f in ('xn1_lo', 'qkv_lo', 'xn2_lo', 'hact_lo'):
+                assert getattr(acts[i], f) == getattr(acts[i + 1], f)
+            assert acts[i].att_lo != acts[i + 1].att_lo and acts[i].xn1_hi != acts[i + 1].xn1_hi
+    ssize = dict(dxn=4 * M * D, dx_a=4 * M * D, dx_b=4 * M * D, dx_a_bf=2 * M * D, dx_b_bf=2 * M * D, dh=2 * M * Hd, dqkv=6 * M * D, datt=2 * M * D,
+                 delta=4 * BHN, ln_partial=4 * 2 * depth * sc.ln_partial_blocks * 2 * D)
+    if cls_only:
+        ssize.update(dx_b_cls=4 * M * D, dx_b_bf_cls=2 * M * D, datt_cls=2 * M * D)
+        assert zo.value == sc.dx_b_cls - base and zo.value + zb.value == total
+    else:
+        assert sc.dx_b_cls is None and zb.value == 0
+    for f, nbytes in ssize.items():
+        ptr = getattr(sc, f)
+        assert ptr is not None and ptr % 256 == 0 and ptr >= base + fwd_only and ptr + nbytes <= base + total, f
+        spans[ptr] = nbytes
+    assert sc.dx_a_lo is None
+    order = sorted(spans.items())
+    for (p0, n0), (p1, _) in zip(order, order[1:]):
+        assert p0 + n0 <= p1, 'overlapping buffers'
