@@ -226,16 +226,23 @@ def collective_diagnostics(trainer, step, step_ms, world, force, reps=10):
             dist.barrier()
         ar_ms.append(round(timed(one, reps), 4))
         buf.copy_(keep)
-    red.skip = True
+    if trainer.graph_collectives:
+        # the all-reduces are nodes of the step graph: the yardstick is the single-replica step (one graph, no collective at all)
+        g1, sx1, sy1, _ = trainer.eng.capture_train_step(trainer._cap['B'])
+        sx1.copy_(trainer._cap['x']); sy1.copy_(trainer._cap['y'])
+        step_wo = g1.replay
+    else:
+        red.skip = True
+        step_wo = step
     for _ in range(3):
-        step()
+        step_wo()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     n = 30
     for _ in range(n):
-        step()
+        step_wo()
     torch.cuda.synchronize()
     t_skip = (time.perf_counter() - t0) / n * 1e3
     red.skip = False
@@ -251,7 +258,8 @@ def collective_diagnostics(trainer, step, step_ms, world, force, reps=10):
                 ms_per_step_without_collectives=round(t_skip, 4), exposed_comm_ms=round(exposed, 4),
                 overlap_frac=round(1.0 - min(1.0, exposed / total), 4) if total > 0 else None,
                 note='allreduce_ms: each bucket alone on an otherwise idle GPU; overlap_frac = 1 - (step - step without collectives) / '
-                     'sum(allreduce_ms)')
+                     'sum(allreduce_ms); "without collectives" = ' + ('the single-replica one-graph step' if trainer.graph_collectives else
+                                                                      'the same segmented step with the collectives suppressed'))
 
 
 def point_cpu_baseline(c, backbone, budget_s=15.0):
@@ -477,14 +485,15 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-collectives', action='store_true',
                     help='diagnostic: run the segmented multi-GPU step (RCCL calls between graph segments) even at N=1')
-    ap.add_argument('--graph-collectives', action='store_true',
-                    help='experimental: one HIP graph per step with the RCCL all-reduces captured inside (default: one graph per '
-                         'backward segment, collectives launched from the host in between)')
-    ap.add_argument('--buckets', type=int, default=4)
+    ap.add_argument('--graph-collectives', choices=['auto', 'on', 'off'], default='auto', nargs='?', const='on',
+                    help='one HIP graph per step with the RCCL all-reduces captured inside.  auto (default): after a child-process preflight '
+                         'on the same ranks / devices has shown that captured all-reduces replay correctly, else one graph per backward '
+                         'segment with the collectives launched from the host in between; on: no preflight; off: never')
+    ap.add_argument('--buckets', type=int, default=None, help='gradient buckets (default: 4 with captured collectives, 2 with host-launched ones)')
     ap.add_argument('--config', choices=sorted(CONFIGS) + sorted(POINT_CONFIGS), default='cfg2')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
     ap.add_argument('--wire', choices=['auto', 'fp32', 'bf16'], default='auto',
-                    help="gradient all-reduce format: fp32 (DDP's arithmetic) or bf16 (half the xGMI bytes); auto = bf16 when N > 1")
+                    help="gradient all-reduce format: fp32 (DDP's arithmetic; auto = fp32) or bf16 (half the xGMI bytes, narrower than the reference)")
     ap.add_argument('--event-graph', action='store_true',
                     help='ONE graph with an event-record node behind every backward segment, collectives launched from a side stream on '
                          'those events (measured slower than the default on this runtime: one graph per segment, collectives in between)')
@@ -528,11 +537,11 @@ def main():
     x, y = x_cpu.to(dev), y_cpu.to(dev)
     if conf.get('dropout') and os.environ.get('S3D_BENCH_NO_DROPOUT') != '1':          # (tuning aid: the cost of the dropout masks)
         eng.set_dropout(conf['dropout'], seed=9)                # model.train(): nn.TransformerEncoderLayer(dropout=0.1)
-    # auto: bf16 on the wire when there IS a wire (half the xGMI bytes; bounded against the fp32 wire by the two-rank real-engine
-    # test tests/test_gpu_dp_two_ranks.py::test_bf16_gradient_wire_tracks_the_fp32_wire_over_twenty_steps), fp32 = DDP's arithmetic
-    wire = ('bf16' if world > 1 else 'fp32') if args.wire == 'auto' else args.wire
+    # fp32 on the wire = what the reference's DDP all-reduces (train_cls_voxel.py:155-159); bf16 (half the xGMI bytes) is opt-in
+    wire = 'fp32' if args.wire == 'auto' else args.wire
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
-                                  force_collectives=args.force_collectives, graph_collectives=args.graph_collectives, wire=wire,
+                                  force_collectives=args.force_collectives,
+                                  graph_collectives={'auto': 'auto', 'on': True, 'off': False}[args.graph_collectives], wire=wire,
                                   event_graph=args.event_graph)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
     ident = rccl_identity(dev, world)
@@ -595,7 +604,9 @@ def main():
         'kernels_suppressed': bool(suppressed),
     }
 
-    if (world > 1 or args.force_collectives) and not args.no_diagnostics and not args.graph_collectives:
+    if trainer.preflight is not None:
+        out['graph_collectives_preflight'] = {'ok': bool(trainer.preflight[0]), 'detail': trainer.preflight[1]}
+    if (world > 1 or args.force_collectives) and not args.no_diagnostics:
         out.update(collective_diagnostics(trainer, step, ms, world, args.force_collectives))   # every rank takes part
     if rank == 0 and not args.no_roofline:
         # instrumented eager pass: HIP events around every GEMM launch, on the launch stream

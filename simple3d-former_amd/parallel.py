@@ -62,10 +62,50 @@ def broadcast_parameters(flat_param, src=0, group=None):
         dist.broadcast(flat_param, src=src, group=group)
 
 
+def graph_collectives_preflight(device_index, group=None, timeout_s=None):
+    """Can this job replay RCCL all-reduces captured in a HIP graph?  Every rank starts `_graph_collective_preflight.py` as a child
+    process on its own device (same RANK / WORLD_SIZE, rendezvous port MASTER_PORT + 13), waits at most timeout_s
+    (S3D_PREFLIGHT_TIMEOUT, default 150 s) and kills it otherwise; the verdicts are combined with a MIN all-reduce over the caller's
+    (eager) process group, so all ranks take the same branch.  Returns (ok, detail).  ~10 - 20 s, once per trainer."""
+    import os
+    import subprocess
+    import sys
+    timeout_s = float(os.environ.get('S3D_PREFLIGHT_TIMEOUT', '150')) if timeout_s is None else timeout_s
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    env = dict(os.environ)
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), S3D_PREFLIGHT_DEVICE=str(device_index),
+               MASTER_ADDR=env.get('MASTER_ADDR', '127.0.0.1'), MASTER_PORT=str(int(env.get('MASTER_PORT', '29500')) + 13))
+    env.pop('TORCHELASTIC_RUN_ID', None)
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_graph_collective_preflight.py')
+    detail = ''
+    try:
+        proc = subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        try:
+            out, _ = proc.communicate(timeout=timeout_s)
+            ok = proc.returncode == 0 and b'S3D_PREFLIGHT_OK' in out
+            if not ok:
+                detail = f'child exit code {proc.returncode}: ' + out.decode(errors='replace').strip().splitlines()[-1][-200:] if out.strip() else f'child exit code {proc.returncode}'
+        except subprocess.TimeoutExpired:
+            proc.kill()
+            proc.communicate()
+            ok, detail = False, f'no answer within {timeout_s:.0f} s (child killed)'
+    except OSError as e:
+        ok, detail = False, f'could not start the child: {e}'
+    if dist.is_initialized() and world > 1:
+        dev = torch.device('cuda', device_index) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if ok and int(flag.item()) == 0:
+            detail = 'another rank failed the preflight'
+        ok = bool(int(flag.item()))
+    return ok, detail
+
+
 class DataParallelTrainer:
     """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
 
-    def __init__(self, engine, n_buckets=3, group=None, use_graphs=True, force_collectives=False, graph_collectives=False,
+    def __init__(self, engine, n_buckets=None, group=None, use_graphs=True, force_collectives=False, graph_collectives='auto',
                  wire='fp32', event_graph=False):
         """event_graph (opt-in, with use_graphs): forward + the whole backward are captured as ONE flat graph with an external
         event-record node behind every backward segment (s3d_graph_marker / s3d_graph_events_at_markers); the all-reduce of bucket k is
@@ -79,12 +119,29 @@ class DataParallelTrainer:
         Adam kernel read the bf16 sum (s3d_adam_step_wire) -- gradient compression as in DDP's bf16_compress_hook.
         graph_collectives: capture the WHOLE step -- backward segments, the all-reduce of every bucket (RCCL calls are
         capturable: tools/probes/rccl_graph_probe.py), Adam -- into ONE HIP graph instead of one graph per segment with the
-        collectives launched from the host in between.  Removes the per-step launch overhead of the segmented mode (measured at
-        one rank); opt-in until it has run on a multi-GPU node."""
-        self.graph_collectives = bool(graph_collectives)
+        collectives launched from the host in between: the compute stream then never leaves the graph (leaving it costs ~0.11 ms of a
+        1.7 ms cfg-2 step, every further boundary ~0.02 ms: profiles/r03_dp_bucket_sweep.txt).  'auto' (default): when there are
+        collectives to issue over RCCL, a throw-away child process group first proves on the job's own ranks and devices that captured
+        all-reduces replay correctly (graph_collectives_preflight); only then is the step captured that way -- and still replayed once
+        under a watchdog -- otherwise the trainer falls back to one graph per segment.  True: no preflight; False: never.
+        Defaults (round 4): fp32 on the wire = DDP's own arithmetic (bf16 stays the flagged option); n_buckets = None picks 4 buckets
+        (blocks 11-6 | 5-3 | 2-1 | 0 + tokenizer) when the collectives are graph nodes -- extra buckets are free there (1.710 ms with 4
+        vs 1.714 with 2 at one rank) and the exposed last bucket shrinks from 43 MB to 7 MB -- and 2 when they are host-launched
+        (~0.02 ms per extra graph boundary): profiles/r04_dp_sweep.txt."""
         self.eng = engine
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.preflight = None               # (ok, detail) of the 'auto' decision, for bench.py's line
+        if graph_collectives == 'auto':
+            rccl = dist.is_initialized() and dist.get_backend(group) == 'nccl' and engine.device.type == 'cuda'
+            if use_graphs and rccl and (self.world > 1 or force_collectives) and not event_graph:
+                self.preflight = graph_collectives_preflight(engine.device.index if engine.device.index is not None else torch.cuda.current_device(), group)
+                graph_collectives = self.preflight[0]
+            else:
+                graph_collectives = False
+        self.graph_collectives = bool(graph_collectives)
+        if n_buckets is None:
+            n_buckets = 4 if (self.graph_collectives and use_graphs) else 2
         broadcast_parameters(engine.arena.p, 0, group)                 # DDP-constructor broadcast (C2)
         engine.refresh_weight_planes()
         self.segments, self.slices = engine.grad_buckets(n_buckets if (self.world > 1 or force_collectives) else 1)

@@ -290,7 +290,7 @@ def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
     assert rel < 2e-2, rel
 
 
-@pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire'])
+@pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire', 'auto'])
 def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
     """DataParallelTrainer on one GPU with a (forced) RCCL all-reduce of each of 3 gradient buckets, vs the plain eager fused step.
     event_graph (opt-in: an event-record node costs more than the graph boundary it replaces on this runtime): ONE natively assembled graph with an event behind every backward segment, collectives launched from a
@@ -307,16 +307,21 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
     try:
         ref = make_engine(cfg, sd)
         eng = make_engine(cfg, sd)
-        tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True, event_graph=mode != 'segment_graphs',
-                                 wire='bf16' if mode.endswith('bf16_wire') else 'fp32')
+        if mode == 'auto':      # the default: a child-process preflight on the same rank / device decides; with RCCL it passes -> captured collectives
+            tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
+            assert tr.preflight is not None and tr.preflight[0], tr.preflight
+            assert tr.collectives_mode() == 'captured in the step graph'
+        else:
+            tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True, event_graph=mode != 'segment_graphs',
+                                     graph_collectives=False, wire='bf16' if mode.endswith('bf16_wire') else 'fp32')
+            assert tr.collectives_mode() == ('host-launched between graph segments' if mode == 'segment_graphs' else 'host-launched on graph events')
         assert len(tr.slices) == 3 and tr.segments == [(11, 6), (5, 3), (2, 0)]
-        assert tr.collectives_mode() == ('host-launched between graph segments' if mode == 'segment_graphs' else 'host-launched on graph events')
         for step in range(4):
             l_ref = float(ref.train_step(x.to(DEV), y.to(DEV)))
             l_dp = float(tr.step(x.to(DEV), y.to(DEV)))
             assert abs(l_ref - l_dp) <= 2e-3, f'step {step}: {l_ref} vs {l_dp}'
         d = (eng.arena.p - ref.arena.p).abs().max()
-        assert ('fwd_bwd' in tr._cap) == (mode != 'segment_graphs')
+        assert ('fwd_bwd' in tr._cap) == (mode.startswith('event_graph')) and ('whole' in tr._cap) == (mode == 'auto')
         assert float(d) <= 8.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
         dist.destroy_process_group()
