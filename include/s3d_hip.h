@@ -286,6 +286,27 @@ int s3d_adam_step(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t
 int s3d_adam_begin(S3dAdamState* state, s3d_stream_t stream);
 int s3d_adam_apply(float* p, float* g, const uint16_t* g_wire, float* m, float* v, uint16_t* hi, uint16_t* lo, long n,
                    const S3dAdamState* state, int zero_grad, int max_workgroups, s3d_stream_t stream);
+/* The update of up to 64 disjoint float4-aligned ranges {offset, count} (in floats, host array ranges[2*n]) of the arena in ONE launch
+ * (after s3d_adam_begin): what S3dAdamFill below left over. */
+int s3d_adam_apply_ranges(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, const long* ranges, int n,
+                          const S3dAdamState* state, int zero_grad, s3d_stream_t stream);
+/* optimizer.step() as FILLER work inside loss.backward() (train_cls_voxel.py:287-288): the Adam update streams 40 bytes per parameter
+ * (0.86 GB, 7 % of a cfg-2 step as a launch of its own) while the small-batch backward is a chain of latency-bound launches that leaves
+ * the HBM idle.  With S3dBlockScratch::adam_fill set, s3d_blocks_bwd lets the update of the GEMM parameters (qkv / proj / fc1 / fc2
+ * weights and biases) of block i+1 -- final once that block's backward has retired -- ride on the launches of block i as extra workgroups
+ * behind their main grids (same stream, same kernels; bitwise the arithmetic of s3d_adam_apply).  Call s3d_adam_begin BEFORE the backward.
+ * p / g / m / v / hi / lo: the arena BASE pointers (the block gradients of S3dBlockGrads must lie inside g); filled: host array that
+ * receives the {offset, count} pairs (floats) of the ranges the call has updated, *n_filled their number (<= filled_cap / 2 pairs);
+ * everything else (LayerNorm parameters, the block processed last, parameters outside the blocks) is the caller's to update afterwards,
+ * e.g. with one s3d_adam_apply_ranges.  Not for gradients that still have to be all-reduced or accumulated (data parallel, group_embed's
+ * two passes). */
+typedef struct S3dAdamFill {
+    float* p; float* g; float* m; float* v;
+    uint16_t* hi; uint16_t* lo;
+    const S3dAdamState* state;
+    int zero_grad;
+    long* filled; int filled_cap; int* n_filled;       /* HOST memory */
+} S3dAdamFill;
 /* Data-parallel gradient wire format (replaces DDP's fp32 bucket all-reduce, train_cls_voxel.py:155-159,287, by half the bytes
  * on xGMI): s3d_pack_bf16 rounds a finished gradient bucket to bf16 (rne; n % 8 == 0), the bf16 buffer is sum-all-reduced, and
  * s3d_adam_step_wire takes the gradient from it (g is only zeroed).  The averaging stays in S3dAdamState::grad_scale. */
@@ -370,6 +391,7 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
      * distinct buffers) with S3dBlockShape::fuse = -1: the fused launches do not write qkv_lo, and low planes shared between blocks hold
      * the LAST block's data -- the library can only check that the pointers are set. */
     uint16_t *dx_a_lo, *dx_b_lo, *dh_lo, *dqkv_lo, *datt_lo, *dx_b_lo_cls, *datt_lo_cls;
+    const S3dAdamFill* adam_fill;                 /* optional (host pointer): the optimizer update rides on the backward launches, see S3dAdamFill */
 } S3dBlockScratch;
 /* Workspace layout for callers that do not want to re-derive it (the shipped Python host allocates the same buffers one by one,
  * simple3d-former_amd/engine.py::_BlockWorkspace / _BlockScratch): ONE device allocation holds the saved activations of `depth`

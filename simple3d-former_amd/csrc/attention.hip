@@ -12,6 +12,7 @@
 // Forward runs in split-bf16 (hi + lo planes, three MFMAs per product) so logits stay within 1e-3 of the fp32
 // reference; backward runs in plain bf16 on the hi planes.
 #include "attention.h"
+#include "adam_fill.h"
 #include "attn_frag.h"
 
 #include <stdint.h>
@@ -905,8 +906,12 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
 // phase A = the dQ kernel's body (lane = query; also yields delta), phase B = the dK/dV kernel's body (lane = key), with
 // delta / lse handed over through LDS instead of a global round trip.
 template <int HD, bool SEG = false>
-__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, const AdamFill fill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    {   // workgroups behind the main grid run a share of the optimizer update (adam_fill.h)
+        const int nmain = (int)gridDim.x - fill.blocks;
+        if ((int)blockIdx.x >= nmain) { adam_fill_run(fill, (int)blockIdx.x - nmain); return; }
+    }
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
     // hd = 192 / 256 (cfg-3's 15-token groups, 37 632 of them per block): the row fragments alone are 192 - 256 registers, so the
     // gradients are accumulated two d-blocks at a time; three waves (49 KB of tiles each) share a CU
@@ -1191,7 +1196,7 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
 }
 
 template <int HD, int DSPLIT>
-int bwd_hd(const AttnArgs& a, hipStream_t s) {
+int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
@@ -1205,8 +1210,11 @@ int bwd_hd(const AttnArgs& a, hipStream_t s) {
             dim3 gs((unsigned)((W + w - 1) / w));
             set_lds(attn_bwd_small_kernel<HD>, MAXW * WAVE_LDS);
             set_lds(attn_bwd_small_kernel<HD, true>, MAXW * WAVE_LDS);
-            if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
-            else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), gs, dim3(64 * w), w * WAVE_LDS, s, a);
+            AdamFill fill = adam_fill_none();
+            if (fillq) fill = fillq->take(64 * w);
+            gs.x += (unsigned)fill.blocks;
+            if (a.seg) hipLaunchKernelGGL((attn_bwd_small_kernel<HD, true>), gs, dim3(64 * w), w * WAVE_LDS, s, a, fill);
+            else hipLaunchKernelGGL((attn_bwd_small_kernel<HD>), gs, dim3(64 * w), w * WAVE_LDS, s, a, fill);
             S3D_CHECK_LAUNCH_V("attention_bwd_small", HD * 10 + (a.seg ? 1 : 0));
             return 0;
         }
@@ -1397,16 +1405,16 @@ int s3d_launch_attention_fwd(const AttnArgs& a0, bool split, hipStream_t s) {
     }
 }
 
-int s3d_launch_attention_bwd(const AttnArgs& a0, hipStream_t s) {
+int s3d_launch_attention_bwd(const AttnArgs& a0, hipStream_t s, AdamFillQueue* fillq) {
     if (int e = check(a0)) return e;
     const AttnArgs a = pack_pairs(a0);
     if (a.dqkv_lo != nullptr) return launch_bwd_ref(a, s);               // parity mode: fp32 reference kernels on hi + lo operands
     S3D_REQUIRE(a.lddo % 8 == 0 && a.lddq % 8 == 0, "attention: leading dims must be multiples of 8");
     switch (a.D / a.H) {
-        case 48: return bwd_hd<48, 1>(a, s);
-        case 64: return bwd_hd<64, 1>(a, s);
-        case 96: return bwd_hd<96, 1>(a, s);
-        case 192: return bwd_hd<192, 1>(a, s);   // 252 VGPRs, no recompute of S / dP per d-half: 262 -> 138 ms at cfg-3
-        default: return bwd_hd<256, 2>(a, s);
+        case 48: return bwd_hd<48, 1>(a, s, fillq);
+        case 64: return bwd_hd<64, 1>(a, s, fillq);
+        case 96: return bwd_hd<96, 1>(a, s, fillq);
+        case 192: return bwd_hd<192, 1>(a, s, fillq);   // 252 VGPRs, no recompute of S / dP per d-half: 262 -> 138 ms at cfg-3
+        default: return bwd_hd<256, 2>(a, s, fillq);
     }
 }

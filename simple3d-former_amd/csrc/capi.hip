@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "adam_fill.h"
 #include "attention.h"
 #include "fused_block.h"
 #include "gemm.h"
@@ -184,8 +185,8 @@ bool bwd_streams_enabled() {
     return on > 0;
 }
 // dgrad on `s`, wgrad on the side stream once everything `s` has enqueued so far (i.e. dy) is complete
-int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs) {
-    if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s);
+int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs, AdamFillQueue* fq = nullptr) {
+    if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s, fq);
     if (hipEventRecord(bs->ready, s) != hipSuccess || hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
         s3d_set_error("backward streams: fork failed");
         return 3;
@@ -287,9 +288,12 @@ int block_bwd_split(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
     return 0;
 }
 
+// fq: optimizer shares (adam_fill.h) that ride on this block's launches -- the GEMM parameters of the block whose backward has just retired.
+// Shares in sixteenths, roughly the launches' durations (16.8 / 12.9 / 6.0 / 7.5 / 7.9 / 12.9 / 6.0 us at cfg-2).
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
-              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false) {
+              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false, AdamFillQueue* fq = nullptr) {
     if (w.dx_a_lo != nullptr) return block_bwd_split(sh, p, gr, a, w, s, lp, cls_only);
+    auto share = [&](int sixteenths) { if (fq) fq->share16 = sixteenths; return fq; };
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
     // cls_only (see block_fwd): d(x_out) is non-zero at the class rows only and proj / norm2 / mlp are row-local -> their backward
@@ -305,37 +309,37 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)          || dW2 += dx_out^T hact
     g.A_hi = w.dx_a_bf; g.lda = pd; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M2; g.N = Hd; g.K = D;
     g.aux = a.hpre; g.ldaux = ph; g.O_hi = w.dh; g.ldo = ph;
-    S3D_TRY(dgrad_and_wgrad(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M2, gr.fc2_w, gr.fc2_b, pd, ph), s, bs));
+    S3D_TRY(dgrad_and_wgrad(EPI_DGELU, g, wgrad_args(w.dx_a_bf, D, a.hact_hi, Hd, M2, gr.fc2_w, gr.fc2_b, pd, ph), s, bs, share(4)));
     g = gemm_zero();            // dxn2 = dh @ W1                             || dW1 += dh^T xn2
     g.A_hi = w.dh; g.lda = ph; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = pd;
-    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M2, gr.fc1_w, gr.fc1_b, ph, pd), s, bs));
+    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dh, Hd, a.xn2_hi, D, M2, gr.fc1_w, gr.fc1_b, ph, pd), s, bs, share(3)));
     LnBwdArgs lb;
     memset(&lb, 0, sizeof(lb));
     lb.dy = w.dxn; lb.lddy = pd; lb.x = a.x_mid; lb.ldx = pd; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
     lb.dres = w.dx_a; lb.lddres = pd; lb.dx = dxb; lb.lddx = pd; lb.dx_bf = dxb_bf; lb.lddxbf = pd;
     lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M2; lb.D = D;
     if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
-    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    S3D_TRY(s3d_launch_ln_bwd(lb, s, share(1)));
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
     g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
     g.A_hi = dxb_bf; g.lda = pd; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D; g.O_hi = datt; g.ldo = pd;
-    S3D_TRY(dgrad_and_wgrad(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s, bs));
+    S3D_TRY(dgrad_and_wgrad(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s, bs, share(2)));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     at.dout = datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
-    S3D_TRY(s3d_launch_attention_bwd(at, s));
+    S3D_TRY(s3d_launch_attention_bwd(at, s, share(2)));
     g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s, bs));
+    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s, bs, share(3)));
     S3D_TRY(bwd_streams_join(s, bs));      // norm1 overwrites dx_a_bf (read by the fc2 wgrad); the next block reuses dh / dqkv / dx_b_bf
     lb.dy = w.dxn; lb.lddy = D; lb.ldx = D; lb.lddres = D; lb.lddx = D; lb.lddxbf = D; lb.rows = M;      // norm1 is dense again
     lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = dxb; lb.dx = w.dx_a;
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
     if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
-    S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    S3D_TRY(s3d_launch_ln_bwd(lb, s, share(16)));        // whatever is left of the current range
     return 0;
 }
 
@@ -531,7 +535,7 @@ size_t s3d_sizeof(const char* n) {
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dHeadLossArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
-    SZ(S3dGroupProjArgs);
+    SZ(S3dGroupProjArgs); SZ(S3dAdamFill);
 #undef SZ
     return 0;
 }
@@ -676,6 +680,11 @@ int s3d_adam_apply(float* p, float* g, const uint16_t* g_wire, float* m, float* 
     S3D_REQUIRE(p && g && m && v && hi && lo && state, "s3d_adam_apply: null pointer");
     return s3d_launch_adam_apply(p, g, m, v, hi, lo, n, state, zero_grad, g_wire, max_workgroups, st(s));
 }
+int s3d_adam_apply_ranges(float* p, float* g, float* m, float* v, uint16_t* hi, uint16_t* lo, const long* ranges, int n,
+                          const S3dAdamState* state, int zero_grad, s3d_stream_t s) {
+    S3D_REQUIRE(p && g && m && v && state && (ranges || n == 0), "s3d_adam_apply_ranges: null pointer");
+    return s3d_launch_adam_ranges(p, g, m, v, hi, lo, ranges, n, state, zero_grad, st(s));
+}
 int s3d_pack_bf16(const float* src, uint16_t* dst, long n, s3d_stream_t s) { return s3d_launch_pack_bf16(src, dst, n, st(s)); }
 
 // ---- events recorded INSIDE a stream capture as external event-record nodes (see s3d_hip.h)
@@ -794,12 +803,61 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     S3D_REQUIRE(sh && p && g && a && w, "s3d_blocks_bwd: null args");
     LnPartials lp;
     const bool partial = w->ln_partial != nullptr && w->ln_partial_blocks > 0;
+    // optimizer shares riding on the launches (S3dAdamFill): while block i runs, the GEMM parameters of block i + 1 are updated
+    const S3dAdamFill* af = (w->dx_a_lo == nullptr) ? w->adam_fill : nullptr;
+    AdamFillQueue fq;
+    int n_filled = 0;
+    if (af) {
+        S3D_REQUIRE(af->p && af->g && af->m && af->v && af->state && af->filled && af->n_filled && af->filled_cap >= 2,
+                    "s3d_blocks_bwd: S3dAdamFill needs the arena base pointers, the optimizer state and the `filled` report array");
+        fq.base = af;
+        *af->n_filled = 0;
+    }
+    auto drain = [&]() -> int {               // shares no launch could carry (a launch path without filler support): a plain update
+        while (af && !fq.empty()) {
+            fq.share16 = 16;
+            const AdamFill f = fq.take(256);
+            if (f.n4 == 0) break;
+            S3D_TRY(s3d_launch_adam_apply(f.p, f.g, f.m, f.v, f.hi, f.lo, f.n4 * 4, af->state, af->zero_grad, nullptr, 0, st(s)));
+        }
+        return 0;
+    };
     for (int i = first; i >= last; --i) {
         const bool cls_only = sh->cls_only_block == i + 1;
         if (cls_only) S3D_REQUIRE(w->dx_b_cls && w->dx_b_bf_cls && w->datt_cls, "s3d_blocks_bwd: cls_only_block needs the *_cls scratch buffers");
-        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only));
+        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, af ? &fq : nullptr));
         if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
+        if (af) {
+            S3D_TRY(drain());
+            fq.reset();
+            if (i > last) {
+                // block i's GEMM parameters are final now: qkv / proj / fc1 / fc2 weights and biases, merged into the contiguous
+                // ranges the caller's arena gives them (the LayerNorm gradients wait for the partial-sum reduction at the very end)
+                const S3dBlockGrads& b = g[i];
+                const long D = sh->D, Hd = sh->hidden;
+                struct T { float* q; long n; } t[8] = {{b.qkv_w, 3 * D * D}, {b.qkv_b, 3 * D}, {b.proj_w, D * D}, {b.proj_b, D},
+                                                       {b.fc1_w, Hd * D}, {b.fc1_b, Hd}, {b.fc2_w, D * Hd}, {b.fc2_b, D}};
+                for (int x = 1; x < 8; ++x) for (int y = x; y > 0 && t[y].q < t[y - 1].q; --y) { const T tmp = t[y]; t[y] = t[y - 1]; t[y - 1] = tmp; }
+                long off = -1, len = 0;
+                auto flush = [&]() {
+                    if (off >= 0 && len >= 4 && n_filled * 2 + 2 <= af->filled_cap && fq.nseg < 4) {
+                        const long n = len / 4 * 4;
+                        fq.push(off, n);
+                        af->filled[2 * n_filled] = off; af->filled[2 * n_filled + 1] = n;
+                        ++n_filled;
+                    }
+                };
+                for (int x = 0; x < 8; ++x) {
+                    const long o = t[x].q - af->g;
+                    if (t[x].q == nullptr || o < 0 || (o & 3) != 0 || (t[x].n & 3) != 0) { flush(); off = -1; len = 0; continue; }   // not ours to touch
+                    if (off >= 0 && o == off + len) len += t[x].n;              // adjacent in the arena: one range
+                    else { flush(); off = o; len = t[x].n; }
+                }
+                flush();
+            }
+        }
     }
+    if (af) { S3D_TRY(drain()); *af->n_filled = n_filled; }
     return lp.flush(*w, sh->D, st(s));
 }
 

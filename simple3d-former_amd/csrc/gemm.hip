@@ -11,6 +11,7 @@
 //     ds_read_b128 fragment reads are at most 2-way,
 //   * epilogues fuse bias / GELU / residual / token assembly / gelu' / split-K atomics / bias-gradient.
 #include "gemm.h"
+#include "adam_fill.h"
 #include "ln_row.h"
 #include "dma_tile.h"
 
@@ -1336,9 +1337,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dmat_kernel(const GemmArgs 
 // dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
 template <int EPIA, int NS, bool KTAIL = false>
 __global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, const GemmArgs pb, int nA, int ntxA, int ntyA,
-                                                             int ntxB, int ntyB) {
+                                                             int ntxB, int ntyB, const AdamFill fill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
+    {   // workgroups behind the two problems run a share of the optimizer update (adam_fill.h)
+        const int nmain = (int)gridDim.x - fill.blocks;
+        if (bid >= nmain) { adam_fill_run(fill, bid - nmain); return; }
+    }
     if (bid < nA) {
         gemm_dmat_body<false, true, EPIA, NS, 64, 64, KTAIL>(pa, smem, bid, ntxA, ntyA, 0);
     } else {
@@ -1732,9 +1737,9 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
 }
 
 template <int EPIA, bool KTAIL = false>
-int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream) {
+int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream, AdamFillQueue* fillq) {
     if constexpr (!KTAIL) {
-        if (((a.K | b.K) & 63) != 0) return launch_pair_dmat<EPIA, true>(a, b, splitk, stream);   // partial last k-tile
+        if (((a.K | b.K) & 63) != 0) return launch_pair_dmat<EPIA, true>(a, b, splitk, stream, fillq);   // partial last k-tile
     }
     // three 16 KB stages (A 64x64 + B 64x64 bf16): 2.04 ms per cfg-2 step; two stages 2.15 ms, four 2.07 ms
     constexpr int NS = 3;
@@ -1748,18 +1753,21 @@ int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream
     const int ntxA = (a.N + 63) / 64, ntyA = (a.M + 63) / 64, ntxB = (b.N + 63) / 64, ntyB = (b.M + 63) / 64;
     const int nA = ntxA * ntyA, nB = ntxB * ntyB * splitk;
     constexpr long long KEY = 600000000000LL + 64 * 100000000LL + 64 * 100000LL + EPIA;     // 6 | 064 | 064 | 000 | EPI dgrad
-    if (g_skip_key == KEY) return 0;
+    if (g_skip_key == KEY) return 0;          // (difference timing: the filler share stays in the queue and is drained by the caller)
+    AdamFill fill = adam_fill_none();
+    if (fillq) fill = fillq->take(256);
+    const dim3 grid(nA + nB + fill.blocks);
     if (g_prof_on) {
         ProfSlot sl;
         sl.key = KEY;
         sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
-        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill);
         (void)hipEventRecord(sl.e1, stream);
         g_prof.push_back(sl);
     } else {
-        hipLaunchKernelGGL(kern, dim3(nA + nB), dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill);
     }
     S3D_CHECK_LAUNCH_V("gemm_pair_dmat", KEY * 10 + (KTAIL ? 1 : 0));
     return 0;
@@ -1774,7 +1782,7 @@ static int launch_pair_tiles(int ta_, int tb_, const GemmArgs& a, const GemmArgs
 }
 
 // dgrad (NN, epilogue epi_a) + wgrad (TN atomic) in one launch; falls back to two launches for shapes that want 128x128 tiles
-int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
+int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream, AdamFillQueue* fillq) {
     static const int no_pair = env_int("S3D_GEMM_NOPAIR");
     GemmArgs a = a_in, b = b_in;
     int splitk = 0, kchunk = 0;
@@ -1793,9 +1801,9 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     static const int pair_dmat = env_int("S3D_GEMM_PAIR_DMAT");          // S3D_GEMM_PAIR_DMAT=0: register-staged pair kernel
     if (pair_dmat != 0 && tile_a == 1 && tile_b == 1 && (a.K & 7) == 0 && (b.K & 7) == 0 && (kchunk & 63) == 0) {
         switch (epi_a) {
-            case EPI_F32: return launch_pair_dmat<EPI_F32>(a, b, splitk, stream);
-            case EPI_DGELU: return launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream);
-            case EPI_BF16_BIAS: return launch_pair_dmat<EPI_BF16_BIAS>(a, b, splitk, stream);
+            case EPI_F32: return launch_pair_dmat<EPI_F32>(a, b, splitk, stream, fillq);
+            case EPI_DGELU: return launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream, fillq);
+            case EPI_BF16_BIAS: return launch_pair_dmat<EPI_BF16_BIAS>(a, b, splitk, stream, fillq);
             default: break;
         }
     }

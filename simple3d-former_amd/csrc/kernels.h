@@ -8,7 +8,8 @@ typedef S3dLnBwdArgs LnBwdArgs;
 int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s);
 int s3d_launch_ln_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
                               hipStream_t s);
-int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s);
+struct AdamFillQueue;        // adam_fill.h: optimizer shares that ride on this launch as filler workgroups (nullptr: none)
+int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s, AdamFillQueue* fill = nullptr);
 
 // ---- tokenizer patch gather ("fold"): voxel grid -> GEMM A operand (split-bf16 planes) ----
 enum { FOLD_ZMEAN = 0, FOLD_NAIVE = 1, FOLD_PATCH = 2, FOLD_PATCH_GROUP = 3 };
@@ -45,6 +46,8 @@ int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf
                           int zero_grad, const bf16_t* g_wire, int max_blocks, hipStream_t s);
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,
                     int zero_grad, const bf16_t* g_wire, hipStream_t s);
+int s3d_launch_adam_ranges(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, const long* ranges, int n, const AdamState* st,
+                           int zero_grad, hipStream_t s);
 int s3d_launch_pack_bf16(const float* src, bf16_t* dst, long n, hipStream_t s);
 int s3d_launch_l2norm_rows_fwd(const float* x, long ldx, long rows, int D, float* inv_norm, bf16_t* hi, bf16_t* lo, long ldo, hipStream_t s);
 int s3d_launch_l2norm_rows_bwd(const float* dxn, long lddxn, const float* x, long ldx, const float* inv_norm, long rows, int D, float* dx, long lddx,

@@ -2,6 +2,7 @@
 // Forward emits the normalised row as split-bf16 planes (GEMM A operand) and optionally fp32; backward fuses the
 // residual-gradient add, a bf16 copy of dx (operand of the next wgrad/dgrad GEMM) and the gamma/beta gradients.
 #include "kernels.h"
+#include "adam_fill.h"
 #include "ln_row.h"
 
 #include <stdlib.h>
@@ -39,11 +40,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LnArgs p) {
 constexpr int MAX_RPW = 4;
 
 template <int RPW, int MC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p) {
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p, const AdamFill fill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nmain = (int)gridDim.x - fill.blocks;       // workgroups behind the main grid run a share of the optimizer update (adam_fill.h)
+    if ((int)blockIdx.x >= nmain) { adam_fill_run(fill, (int)blockIdx.x - nmain); return; }
     float* red = reinterpret_cast<float*>(smem);          // [2][4 waves][D]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long nw = (long)gridDim.x * 4;
+    const long nw = (long)nmain * 4;
     float4 dg[MC], db[MC];
 #pragma unroll
     for (int c = 0; c < MC; ++c) dg[c] = db[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -193,7 +196,7 @@ int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
     return 0;
 }
 
-int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
+int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s, AdamFillQueue* fillq) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
     if (a.rows <= 0) return 0;
     long blocks = (a.rows + 4 * MAX_RPW - 1) / (4 * MAX_RPW);
@@ -209,11 +212,14 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s) {
     // rows each wave handles per trip: as many as the grid leaves it (clamped duplicate rows would only add loads)
     const long per_wave = (a.rows + blocks * 4 - 1) / (blocks * 4);
     const size_t lds = 2 * 4 * a.D * sizeof(float);
+    AdamFill fill = adam_fill_none();
+    if (fillq) fill = fillq->take(256);
+    const unsigned grid = (unsigned)blocks + (unsigned)fill.blocks;
 #define S3D_LN_BWD(RPW)                                                                                          \
     do {                                                                                                         \
-        if (a.D <= 256) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 1>), dim3((unsigned)blocks), dim3(256), lds, s, a);      \
-        else if (a.D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 2>), dim3((unsigned)blocks), dim3(256), lds, s, a); \
-        else hipLaunchKernelGGL((ln_bwd_kernel<RPW, 4>), dim3((unsigned)blocks), dim3(256), lds, s, a);                 \
+        if (a.D <= 256) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 1>), dim3(grid), dim3(256), lds, s, a, fill);      \
+        else if (a.D <= 512) hipLaunchKernelGGL((ln_bwd_kernel<RPW, 2>), dim3(grid), dim3(256), lds, s, a, fill); \
+        else hipLaunchKernelGGL((ln_bwd_kernel<RPW, 4>), dim3(grid), dim3(256), lds, s, a, fill);                 \
     } while (0)
     static const int forced_rpw = s3d_tune_int("S3D_LN_RPW") > 0 ? s3d_tune_int("S3D_LN_RPW") : 0;      // tuning builds only
     const int rpw = forced_rpw ? forced_rpw : (per_wave >= 3 ? 4 : per_wave == 2 ? 2 : 1);

@@ -1,6 +1,7 @@
 // Small HBM-bound kernels of the hot path: tokenizer patch gather, positional-embedding gradient, fp32->split-bf16,
 // classification head, cross-entropy, fused Adam.
 #include "kernels.h"
+#include "adam_fill.h"
 
 #include <string.h>
 
@@ -542,40 +543,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     const float step_size = st->step_size, bc2s = st->bc2_sqrt;
     // back to front: the arena is laid out in forward order, so the tokenizer's and the first blocks' weight planes are the LAST
     // thing this 0.8 GB stream leaves in the 256 MB Infinity Cache -- where the next step's forward looks for them first
-    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long)gridDim.x * 256) {
-        const long i = n4 - 1 - j;
-        const f32x4 Pn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p) + i);
-        float4 P = make_float4(Pn[0], Pn[1], Pn[2], Pn[3]), G;
-        if (gw) {                                       // bf16 wire format: the all-reduced gradient arrives as bf16 (uniform branch)
-            union { uint2 u; bf16_t h[4]; } W;
-            W.u = reinterpret_cast<const uint2*>(gw)[i];
-            G = make_float4(bf2f(W.h[0]), bf2f(W.h[1]), bf2f(W.h[2]), bf2f(W.h[3]));
-        } else {
-            const f32x4 Gn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
-            G = make_float4(Gn[0], Gn[1], Gn[2], Gn[3]);
-        }
-        const f32x4 Mn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(m) + i);
-        const f32x4 Vn = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(v) + i);
-        float4 M = make_float4(Mn[0], Mn[1], Mn[2], Mn[3]), Vv = make_float4(Vn[0], Vn[1], Vn[2], Vn[3]);
-        float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x * gs, G.y * gs, G.z * gs, G.w * gs};
-        float mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {Vv.x, Vv.y, Vv.z, Vv.w};
-        union { uint2 u; bf16_t h[4]; } H, L;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            mm[k] = mm[k] * b1 + (1.f - b1) * gg[k];
-            vv[k] = vv[k] * b2 + (1.f - b2) * gg[k] * gg[k];
-            const float denom = sqrtf(vv[k]) / bc2s + eps;
-            pp[k] -= step_size * (mm[k] / denom);
-            split_bf16(pp[k], H.h[k], L.h[k]);
-        }
-        // p / m / v / g are touched once per step: non-temporal, so that the 0.7 GB they stream does not push the weight planes and
-        // the saved activations out of L2 / the Infinity Cache
-        __builtin_nontemporal_store(f32x4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f32x4*>(p) + i);
-        __builtin_nontemporal_store(f32x4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f32x4*>(m) + i);
-        __builtin_nontemporal_store(f32x4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f32x4*>(v) + i);
-        if (zero_grad) __builtin_nontemporal_store(f32x4{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<f32x4*>(g) + i);
-        if (hi) reinterpret_cast<uint2*>(hi)[i] = H.u;
-        if (lo) reinterpret_cast<uint2*>(lo)[i] = L.u;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < n4; j += (long)gridDim.x * 256)
+        adam_update4(n4 - 1 - j, p, g, m, v, hi, lo, gw, b1, b2, eps, gs, step_size, bc2s, zero_grad);
+}
+// the same update over up to 64 disjoint ranges of the arena in ONE launch (what the filler shares of adam_fill.h left over: the
+// LayerNorm parameters of every block, the block whose backward ran last, tokenizer / head)
+struct AdamRanges { long off4[64]; long cum4[65]; int n; };
+__global__ __launch_bounds__(256) void adam_ranges_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, const AdamRanges r, const AdamState* st,
+                                                          int zero_grad) {
+    const float b1 = st->beta1, b2 = st->beta2, eps = st->eps, gs = st->grad_scale;
+    const float step_size = st->step_size, bc2s = st->bc2_sqrt;
+    const long total = r.cum4[r.n];
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long)gridDim.x * 256) {
+        int k = 0;
+        while (k + 1 < r.n && j >= r.cum4[k + 1]) ++k;                  // <= 64 entries, wave-mostly-uniform
+        adam_update4(r.off4[k] + (j - r.cum4[k]), p, g, m, v, hi, lo, nullptr, b1, b2, eps, gs, step_size, bc2s, zero_grad);
     }
 }
 
@@ -712,6 +695,25 @@ int s3d_launch_adam_apply(float* p, float* g, float* m, float* v, bf16_t* hi, bf
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, n / 4, st, zero_grad, g_wire);
     S3D_CHECK_LAUNCH("adam");
+    return 0;
+}
+int s3d_launch_adam_ranges(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, const long* ranges, int n, const AdamState* st,
+                           int zero_grad, hipStream_t s) {
+    S3D_REQUIRE(n >= 0 && n <= 64, "adam_ranges: %d ranges (at most 64)", n);
+    AdamRanges r;
+    memset(&r, 0, sizeof(r));
+    for (int i = 0; i < n; ++i) {
+        S3D_REQUIRE(ranges[2 * i] % 4 == 0 && ranges[2 * i + 1] % 4 == 0 && ranges[2 * i + 1] >= 0, "adam_ranges: range %d is not float4-aligned", i);
+        if (ranges[2 * i + 1] == 0) continue;
+        r.off4[r.n] = ranges[2 * i] / 4;
+        r.cum4[r.n + 1] = r.cum4[r.n] + ranges[2 * i + 1] / 4;
+        ++r.n;
+    }
+    if (r.n == 0) return 0;
+    long blocks = (r.cum4[r.n] + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(adam_ranges_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, hi, lo, r, st, zero_grad);
+    S3D_CHECK_LAUNCH("adam_ranges");
     return 0;
 }
 int s3d_launch_adam(float* p, float* g, float* m, float* v, bf16_t* hi, bf16_t* lo, long n, AdamState* st,

@@ -26,9 +26,15 @@ BACKBONES = {  # models/vit_3d_2d_pretrain.py:279-325 -- deit_base is built with
 }
 LN_EPS = 1e-6
 FOLD_MODE = {'VoxelEmbed': 0, 'VoxelNaiveProjection': 1, 'VoxelEmbed_no_average': 2}
-BLOCK_PARAM_ORDER = ['norm1.weight', 'norm1.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight',
-                     'attn.proj.bias', 'norm2.weight', 'norm2.bias', 'mlp.fc1.weight', 'mlp.fc1.bias',
-                     'mlp.fc2.weight', 'mlp.fc2.bias']
+# Arena order inside a block: both LayerNorms first, then the GEMM parameters as ONE contiguous range -- the range whose optimizer update
+# rides on the next block's backward launches (S3dAdamFill); the LayerNorm gradients are only final after the batched partial-sum
+# reduction at the end of s3d_blocks_bwd.
+BLOCK_PARAM_ORDER = ['norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias', 'attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight',
+                     'attn.proj.bias', 'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias']
+BLOCK_PARAM_SHAPE = {'norm1.weight': lambda D: (D,), 'norm1.bias': lambda D: (D,), 'norm2.weight': lambda D: (D,), 'norm2.bias': lambda D: (D,),
+                     'attn.qkv.weight': lambda D: (3 * D, D), 'attn.qkv.bias': lambda D: (3 * D,), 'attn.proj.weight': lambda D: (D, D),
+                     'attn.proj.bias': lambda D: (D,), 'mlp.fc1.weight': lambda D: (4 * D, D), 'mlp.fc1.bias': lambda D: (4 * D,),
+                     'mlp.fc2.weight': lambda D: (D, 4 * D), 'mlp.fc2.bias': lambda D: (D,)}
 
 
 def _round_up(x, m):
@@ -70,13 +76,8 @@ def voxel_param_shapes(*, backbone, embed_layer, cell, patch, n_classes, pos_emb
     shapes['cls_token'] = (1, 1, D)
     shapes['voxel_pos_embed'] = (1, ntok, D)
     for i in range(depth):
-        p = f'blocks.{i}.'
-        shapes[p + 'norm1.weight'] = (D,); shapes[p + 'norm1.bias'] = (D,)
-        shapes[p + 'attn.qkv.weight'] = (3 * D, D); shapes[p + 'attn.qkv.bias'] = (3 * D,)
-        shapes[p + 'attn.proj.weight'] = (D, D); shapes[p + 'attn.proj.bias'] = (D,)
-        shapes[p + 'norm2.weight'] = (D,); shapes[p + 'norm2.bias'] = (D,)
-        shapes[p + 'mlp.fc1.weight'] = (4 * D, D); shapes[p + 'mlp.fc1.bias'] = (4 * D,)
-        shapes[p + 'mlp.fc2.weight'] = (D, 4 * D); shapes[p + 'mlp.fc2.bias'] = (D,)
+        for k in BLOCK_PARAM_ORDER:
+            shapes[f'blocks.{i}.{k}'] = BLOCK_PARAM_SHAPE[k](D)
     shapes['norm.weight'] = (D,); shapes['norm.bias'] = (D,)
     if head == 'AMSoftmax':
         shapes['voxel_head.W'] = (D, n_classes)
@@ -200,6 +201,10 @@ CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'
 # second branch: 1.75 -> 2.17 ms), far more than the update's 0.13 ms.  A captured step has to stay ONE chain.
 UPDATE_OVERLAP = int(os.environ.get('S3D_UPDATE_OVERLAP', '0'))
 UPDATE_WORKGROUPS = int(os.environ.get('S3D_UPDATE_WORKGROUPS', '0'))
+# optimizer.step() as filler workgroups inside the backward launches (S3dAdamFill, csrc/adam_fill.h): built, bitwise equal to the single
+# update, measured 0.6 - 1.4 % SLOWER at cfg-2 (each launch slows down by what its share costs as a stream of its own:
+# profiles/r04_adam_fill.txt) -> opt-in (S3D_ADAM_FILL=1 / VoxelEngine.adam_fill = True).
+ADAM_FILL = os.environ.get('S3D_ADAM_FILL', '0') == '1'
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
 
@@ -677,8 +682,46 @@ class VoxelEngine:
         return segments, slices
 
     def blocks_backward_range(self, ws, first, last):
-        L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
-                                        ctypes.byref(ws.sc1), first, last, L.current_stream()), 'blocks_bwd')
+        fill = getattr(self, '_fill', None)
+        if fill is not None:
+            ws.sc1.adam_fill = ctypes.addressof(fill['args'])
+        try:
+            L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
+                                            ctypes.byref(ws.sc1), first, last, L.current_stream()), 'blocks_bwd')
+        finally:
+            ws.sc1.adam_fill = None
+        if fill is not None:
+            n = fill['n'].value
+            fill['done'] += [(int(fill['ranges'][2 * i]), int(fill['ranges'][2 * i + 1])) for i in range(n)]
+
+    def _adam_fill_begin(self):
+        """Arms S3dAdamFill for the backward that follows (after adam_begin): the update of every block's GEMM parameters rides on the
+        next block's backward launches."""
+        a = self.arena
+        ranges, n = (ctypes.c_long * 256)(), ctypes.c_int(0)
+        args = L.fill(L.S3dAdamFill(), p=a.p, g=a.g, m=a.m, v=a.v, hi=a.hi, lo=a.lo, state=self.adam_state, zero_grad=1,
+                      filled=ctypes.addressof(ranges), filled_cap=256, n_filled=ctypes.addressof(n))
+        self._fill = dict(args=args, ranges=ranges, n=n, done=[])
+
+    def _adam_fill_finish(self):
+        """The rest of optimizer.step(): ONE launch over everything the filler shares did not cover (LayerNorm parameters, the block
+        whose backward ran last, tokenizer / positional embedding / final norm / head)."""
+        fill, a = self._fill, self.arena
+        self._fill = None
+        rest, pos = [], 0
+        for off, cnt in sorted(fill['done']):
+            assert off >= pos and off % 4 == 0 and cnt % 4 == 0, 'filled ranges must be disjoint and float4-aligned'
+            if off > pos:
+                rest.append((pos, off - pos))
+            pos = off + cnt
+        if pos < a.numel:
+            rest.append((pos, a.numel - pos))
+        while len(rest) > 64:                    # (never at depth 12: 13 gaps) merge the smallest gap rather than fail
+            raise RuntimeError('adam fill: more than 64 leftover ranges')
+        flat = (ctypes.c_long * (2 * len(rest)))(*[v for r in rest for v in r])
+        L.check(self.lib.s3d_adam_apply_ranges(L.ptr(a.p), L.ptr(a.g), L.ptr(a.m), L.ptr(a.v), L.ptr(a.hi), L.ptr(a.lo), flat, len(rest),
+                                               L.ptr(self.adam_state), 1, L.current_stream()), 'adam ranges')
+        self.adam_fill_stats = dict(filled=sum(c for _, c in fill['done']), rest=sum(c for _, c in rest), ranges=len(rest))
 
     def _tokenizer_backward(self, ws, dx=None, dx_bf=None, dx_lo=None):
         lib, s, a, D, sc = self.lib, L.current_stream(), self.arena, self.D, ws.scratch
@@ -748,6 +791,18 @@ class VoxelEngine:
         loss = self.forward_loss(x, target, weight)
         n_slices = getattr(self, 'update_slices', UPDATE_OVERLAP)
         if n_slices <= 0 or self.precise:
+            if getattr(self, 'adam_fill', ADAM_FILL) and not self.precise and not self.group and self.images is None and self.world_size == 1:
+                # optimizer.step() inside loss.backward(): the bookkeeping first, the GEMM parameters of block i + 1 on block i's launches,
+                # the rest in one launch at the end (bitwise the results of adam_step)
+                self.adam_begin()
+                self._adam_fill_begin()
+                try:
+                    self.backward(B)
+                    self._adam_fill_finish()
+                finally:
+                    self._fill = None
+                self._refresh_conv_planes()
+                return loss
             self.backward(B)
             self.adam_step(zero_grad=True)
             return loss
@@ -795,7 +850,7 @@ class VoxelEngine:
 
     def capture_train_step(self, B, weight=None):
         """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""
-        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p, getattr(self, 'update_slices', UPDATE_OVERLAP))     # model.train() / .eval() toggles keep both captures
+        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p, getattr(self, 'update_slices', UPDATE_OVERLAP), getattr(self, 'adam_fill', ADAM_FILL))     # model.train() / .eval() toggles keep both captures
         if key in self._graphs:
             return self._graphs[key]
         sx = torch.zeros(B, 1, self.V, self.V, self.V, dtype=torch.float32, device=self.device)

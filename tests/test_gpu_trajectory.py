@@ -72,6 +72,41 @@ def test_update_in_slices_beside_the_backward_equals_the_single_update(determini
         assert torch.equal(r[1], runs[0][1]) and torch.equal(r[2], runs[0][2]) and not r[3].any()
 
 
+@pytest.mark.parametrize('B', [8, 64])
+def test_optimizer_update_inside_the_backward_launches_equals_the_single_update(deterministic, B):
+    """S3dAdamFill (csrc/adam_fill.h): the Adam update of block i + 1's GEMM parameters rides on block i's backward launches as filler
+    workgroups, the rest is one s3d_adam_apply_ranges launch == s3d_adam_step behind the backward, bit for bit (parameters, moments,
+    weight planes, zeroed gradients), eagerly and as a captured graph.  B = 64: the LDS-DMA pair kernels / LayerNorm / attention
+    backward carry the shares; B = 8: the register-staged pair kernels cannot, their shares are drained as plain launches."""
+    sd = vo.init_state_dict(seed=9, exercise_all=True, **KW)
+    x, y = vo.synthetic_batch(B, 32, 40, seed=11)
+    x, y = x.to(DEV), y.to(DEV)
+    runs = []
+    for fill, graph in ((False, False), (True, False), (True, True)):
+        eng = _engine(sd)
+        eng.adam_fill = fill
+        if graph:
+            g, sx, sy, loss = eng.capture_train_step(B)
+            sx.copy_(x); sy.copy_(y)
+            losses = []
+            for _ in range(4):
+                g.replay()
+                losses.append(float(loss))
+        else:
+            losses = [float(eng.train_step(x, y)) for _ in range(4)]
+        torch.cuda.synchronize()
+        if fill:
+            st = eng.adam_fill_stats
+            assert st['filled'] + st['rest'] == eng.arena.numel and st['filled'] > 0.85 * eng.arena.numel, st      # 11 of 12 blocks' GEMM parameters
+        runs.append((losses, eng.arena.p.clone(), eng.arena.m.clone(), eng.arena.v.clone(), eng.arena.hi.clone(), eng.arena.lo.clone(), eng.arena.g.clone()))
+        assert eng.optimizer_state()['step'] == 4
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        for a, b in zip(r[1:6], runs[0][1:6]):
+            assert torch.equal(a, b)
+        assert not r[6].any()
+
+
 def test_fifty_step_trajectory_tracks_the_oracle(deterministic):
     steps, B, nb = 50, 8, 5
     sd = vo.init_state_dict(seed=9, **KW)                       # the reference's own initialisation
