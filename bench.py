@@ -114,7 +114,7 @@ def rocprof_name(key):
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
 
 
-PMC_TRAFFIC_FILE = 'profiles/r03_pmc_step_traffic.json'           # cfg-2; main() switches to ..._pmc_<config>_traffic.json for the others
+PMC_TRAFFIC_FILE = 'profiles/r04_pmc_step_traffic.json'           # cfg-2; main() switches to ..._pmc_<config>_traffic.json for the others
 
 
 def pmc_traffic(key):

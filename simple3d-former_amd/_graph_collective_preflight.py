@@ -12,6 +12,9 @@ def main():
     import torch
     import torch.distributed as dist
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    if os.environ.get('S3D_PREFLIGHT_FORCE_FAIL') == '1':           # tests: exercise the parent's fallback path
+        print('S3D_PREFLIGHT_FORCED_FAILURE', flush=True)
+        sys.exit(5)
     torch.cuda.set_device(int(os.environ['S3D_PREFLIGHT_DEVICE']))
     dist.init_process_group(os.environ.get('S3D_PREFLIGHT_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank,
                             timeout=datetime.timedelta(seconds=float(os.environ.get('S3D_PREFLIGHT_INIT_TIMEOUT', '60'))))

@@ -290,7 +290,7 @@ def test_fused_layernorm_epilogue_equals_the_standalone_kernels():
     assert rel < 2e-2, rel
 
 
-@pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire', 'auto'])
+@pytest.mark.parametrize('mode', ['event_graph', 'segment_graphs', 'event_graph_bf16_wire', 'auto', 'auto_fallback'])
 def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
     """DataParallelTrainer on one GPU with a (forced) RCCL all-reduce of each of 3 gradient buckets, vs the plain eager fused step.
     event_graph (opt-in: an event-record node costs more than the graph boundary it replaces on this runtime): ONE natively assembled graph with an event behind every backward segment, collectives launched from a
@@ -311,6 +311,14 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
             tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
             assert tr.preflight is not None and tr.preflight[0], tr.preflight
             assert tr.collectives_mode() == 'captured in the step graph'
+        elif mode == 'auto_fallback':       # the preflight child fails (forced): the trainer must fall back to segment graphs, not hang or raise
+            os.environ['S3D_PREFLIGHT_FORCE_FAIL'] = '1'
+            try:
+                tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True)
+            finally:
+                del os.environ['S3D_PREFLIGHT_FORCE_FAIL']
+            assert tr.preflight is not None and not tr.preflight[0] and 'exit code 5' in tr.preflight[1], tr.preflight
+            assert tr.collectives_mode() == 'host-launched between graph segments'
         else:
             tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=True, force_collectives=True, event_graph=mode != 'segment_graphs',
                                      graph_collectives=False, wire='bf16' if mode.endswith('bf16_wire') else 'fp32')
@@ -322,6 +330,7 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
             assert abs(l_ref - l_dp) <= 2e-3, f'step {step}: {l_ref} vs {l_dp}'
         d = (eng.arena.p - ref.arena.p).abs().max()
         assert ('fwd_bwd' in tr._cap) == (mode.startswith('event_graph')) and ('whole' in tr._cap) == (mode == 'auto')
+        assert (len(tr._cap['graphs']) == 3) == (mode in ('segment_graphs', 'auto_fallback'))
         assert float(d) <= 8.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
         dist.destroy_process_group()
