@@ -83,6 +83,9 @@ int s3d_gemm(int ta, int tb, int split, int epi, const S3dGemmArgs* args, int sp
  * alone under-fills the chip at 1664 token rows); shapes that want 128x128 tiles fall back to two launches.  The library picks the
  * wgrad's k-split (kchunk of both argument structs is ignored). */
 int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, s3d_stream_t stream);
+/* the same launch carrying a SECOND wgrad (any layer whose dy and x are ready: s3d_block_bwd puts attn.proj's wgrad on the qkv pair
+ * launch once the proj dgrad has moved into the fused attention backward) */
+int s3d_gemm_pair3(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, const S3dGemmArgs* wgrad2, s3d_stream_t stream);
 /* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
 /* 1 if a forward (0,0) F32-epilogue launch of this shape accumulates S3dGemmArgs::col_sums (128x128 tiles, N % 8 == 0); the caller
@@ -347,7 +350,9 @@ typedef struct S3dBlockShape {
     int fuse;                     /* 0: the library picks the launch structure -- for the split-bf16 forward of small token counts (N <= 32
                                    * tokens per sequence, head dim 64, D = 192 / 384) norm1 + qkv + attention run as ONE launch per block and
                                    * norm2 + fc1 + GELU as another (four launches per block instead of seven; acts->qkv_lo is then not
-                                   * written); -1: always the seven-launch sequence */
+                                   * written), and in the backward attn.proj's dgrad runs inside the attention-backward launch with its wgrad
+                                   * on the qkv pair launch (six launches per block instead of seven; scratch->datt / delta are then not
+                                   * written); 1: the fused forward only; -1: always the seven-launch sequences */
     int* ln_tickets;              /* optional: >= ceil(Bb*N / 32) zero-initialised ints (left zero by every call).  When set, norm2 and
                                    * (in s3d_blocks_fwd) the NEXT block's norm1 run inside the attn.proj / mlp.fc2 GEMM launches
                                    * (S3dGemmArgs::ln_tickets) instead of as LayerNorm kernels of their own */

@@ -185,8 +185,10 @@ bool bwd_streams_enabled() {
     return on > 0;
 }
 // dgrad on `s`, wgrad on the side stream once everything `s` has enqueued so far (i.e. dy) is complete
-int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs, AdamFillQueue* fq = nullptr) {
-    if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s, fq);
+int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs, AdamFillQueue* fq = nullptr,
+                    const GemmArgs* wg2 = nullptr) {
+    if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s, fq, wg2);
+    if (wg2) S3D_TRY(s3d_launch_gemm(true, true, false, EPI_ATOMIC, *wg2, 0, bs->side));
     if (hipEventRecord(bs->ready, s) != hipSuccess || hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
         s3d_set_error("backward streams: fork failed");
         return 3;
@@ -321,19 +323,33 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
     S3D_TRY(s3d_launch_ln_bwd(lb, s, share(1)));
     // ---- attention branch: d(x_mid) is in dx_b / dx_b_bf
-    g = gemm_zero();            // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
-    g.A_hi = dxb_bf; g.lda = pd; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D; g.O_hi = datt; g.ldo = pd;
-    S3D_TRY(dgrad_and_wgrad(EPI_BF16_BIAS, g, wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd), s, bs, share(2)));
     AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
-    at.dout = datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
-    S3D_TRY(s3d_launch_attention_bwd(at, s, share(2)));
-    g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1
+    // Fused (S3dBlockShape::fuse == 0, small token counts, dense block): attn.proj's dgrad runs inside the attention-backward launch, head
+    // slice by head slice (fused_block.hip: blk_attn_bwd_kernel), and its wgrad rides on the qkv pair launch as a third problem: six
+    // launches per block instead of seven.
+    const bool fuse_bwd = sh.fuse == 0 && !cls_only && bs == nullptr && s3d_fused_attn_bwd_ok(sh.Bb, sh.N, D, sh.H);
+    const GemmArgs proj_wg = wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd);
+    if (fuse_bwd) {
+        FusedAttnBwdArgs fb;
+        fb.dxm = dxb_bf; fb.lddxm = D; fb.w_hi = p.proj_w_hi; fb.qkv_hi = a.qkv_hi;
+        fb.lse = a.lse; fb.dqkv = w.dqkv; fb.Bb = sh.Bb; fb.N = sh.N; fb.H = sh.H; fb.scale = at.scale;
+        fb.lse_packed = s3d_attention_pairs_packed(at) ? 1 : 0;
+        S3D_TRY(s3d_launch_fused_attn_bwd(fb, D, s));
+    } else {
+        g = gemm_zero();        // datt = dx_mid @ Wproj                      || dWproj += dx_mid^T att
+        g.A_hi = dxb_bf; g.lda = pd; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M2; g.N = D; g.K = D; g.O_hi = datt; g.ldo = pd;
+        S3D_TRY(dgrad_and_wgrad(EPI_BF16_BIAS, g, proj_wg, s, bs, share(2)));
+        at.dout = datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+        S3D_TRY(s3d_launch_attention_bwd(at, s, share(2)));
+    }
+    g = gemm_zero();            // dxn1 = dqkv @ Wqkv                         || dWqkv += dqkv^T xn1  [|| dWproj += dx_mid^T att]
     g.A_hi = w.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
-    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s, bs, share(3)));
+    S3D_TRY(dgrad_and_wgrad(EPI_F32, g, wgrad_args(w.dqkv, 3 * D, a.xn1_hi, D, M, gr.qkv_w, gr.qkv_b), s, bs, share(fuse_bwd ? 7 : 3),
+                            fuse_bwd ? &proj_wg : nullptr));
     S3D_TRY(bwd_streams_join(s, bs));      // norm1 overwrites dx_a_bf (read by the fc2 wgrad); the next block reuses dh / dqkv / dx_b_bf
     lb.dy = w.dxn; lb.lddy = D; lb.ldx = D; lb.lddres = D; lb.lddx = D; lb.lddxbf = D; lb.rows = M;      // norm1 is dense again
     lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = dxb; lb.dx = w.dx_a;
@@ -571,6 +587,11 @@ int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wg
     S3D_REQUIRE(dgrad->M > 0 && dgrad->N > 0 && dgrad->K > 0 && wgrad->M > 0 && wgrad->N > 0 && wgrad->K > 0, "s3d_gemm_pair: empty problem");
     S3D_REQUIRE(wgrad->C != nullptr, "s3d_gemm_pair: the wgrad half accumulates into C");
     return s3d_launch_gemm_pair(epi_dgrad, *dgrad, *wgrad, st(s));
+}
+int s3d_gemm_pair3(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, const S3dGemmArgs* wgrad2, s3d_stream_t s) {
+    S3D_REQUIRE(dgrad && wgrad && wgrad2, "s3d_gemm_pair3: null args");
+    S3D_REQUIRE(wgrad->C != nullptr && wgrad2->C != nullptr && wgrad2->M > 0 && wgrad2->N > 0 && wgrad2->K > 0, "s3d_gemm_pair3: both wgrads accumulate into C");
+    return s3d_launch_gemm_pair(epi_dgrad, *dgrad, *wgrad, st(s), nullptr, wgrad2);
 }
 int s3d_cov_enable(int on) {
     if (on) g_cov.clear();

@@ -24,6 +24,19 @@ struct FusedMlpArgs {
     long M; int hidden, nslice;           // nslice = hidden / 192
     int band_rows;                        // filled by the launcher: token rows per workgroup (<= 64)
 };
+// Backward counterpart of the attention half (round 4): attn.proj dgrad (this head's 64 input columns) -> attention backward, per
+// (pair of samples, head).  Replaces the dgrad half of the proj pair launch and the attention-backward launch; the proj wgrad rides on
+// the qkv pair launch as a third problem (s3d_launch_gemm_pair).
+struct FusedAttnBwdArgs {
+    const bf16_t* dxm; long lddxm;        // d(x_mid) as bf16 [M][D] (what LayerNorm-2 backward writes)
+    const bf16_t* w_hi;                   // attn.proj weight, high plane [D out][D in]
+    const bf16_t* qkv_hi;                 // saved q | k | v [M][3D]
+    const float* lse;                     // as written by the forward (lse_packed: see FusedAttnArgs)
+    bf16_t* dqkv;                         // out: d(q | k | v) [M][3D]
+    int Bb, N, H; float scale; int lse_packed;
+};
+bool s3d_fused_attn_bwd_ok(int Bb, int N, int D, int H);
+int s3d_launch_fused_attn_bwd(const FusedAttnBwdArgs& a, int D, hipStream_t s);
 bool s3d_fused_attn_ok(int Bb, int N, int D, int H);
 bool s3d_fused_mlp1_ok(long M, int D, int hidden);
 int s3d_launch_fused_attn(const FusedAttnArgs& a, int D, hipStream_t s);

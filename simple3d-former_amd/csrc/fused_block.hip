@@ -411,6 +411,220 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward of the attention half for TWO samples and one head (hd = 64, N <= 32 tokens): d(att) = d(x_mid) @ Wproj restricted to this
+// head's 64 input columns (attn.proj dgrad), then the attention backward on it -- dQ by one wave, dK / dV by another, per sample --
+// with d(att) handed over in LDS.  (timm Attention backward; unfused: s3d_gemm(0, 1, BF16_BIAS) + attn_bwd_small_kernel.)
+//   * the weight slice Wproj[:, 64 h .. 64 h + 63] (D rows of 128 bytes, 48 KB at D = 384) is staged once per workgroup; the rows of each
+//     32-row k-tile are stored in MFMA k-slot order (slot_key), so that the transposed LDS read delivers the B-side fragment whose k-slots
+//     are 8 CONSECUTIVE output features -- and the A-side fragment (d(x_mid) of this lane's token) is a plain 16-byte row read from memory;
+//   * 256 threads: wave (sample s, half) computes d(att)^T[32 features of its half][32 tokens] with 32x32x16 MFMAs, stores it as the bf16
+//     [32 tokens][64] tile the attention backward stages anyway, then runs phase A (half 0: lane = query, dQ) or phase B (half 1: lane = key,
+//     dK and dV) of attn_bwd_small_kernel; P is recomputed from the saved log-sum-exp, delta = rowsum(dO * O).
+constexpr int BW_WPITCH = 72;            // bf16 elements per staged weight / tile row (144 B: 16-byte aligned, rows 4 banks apart)
+constexpr int BW_TILE = 32 * BW_WPITCH;  // elements of a staged [32 tokens][64] tile
+constexpr int BW_SAMPLE = 4 * BW_TILE + 128;      // Q | K | V | dO tiles + 64 floats (delta, lse)
+constexpr int BW_THREADS = 512;          // eight waves stage; waves 0..3 compute (sample, half)
+constexpr int bw_apitch(int D) { return D + 8; }
+constexpr int bw_lds_bytes(int D) { return (D * BW_WPITCH + 64 * bw_apitch(D) + 2 * BW_SAMPLE) * 2; }
+
+template <int D>
+__global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HD = 64, NS = HD / 16, KT = D / 32, AP = bw_apitch(D), WP = BW_WPITCH, CPR = D / 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int npair = (p.Bb + 1) >> 1;
+    const int item = xcd_item(blockIdx.x, npair * p.H);
+    const int h = item / npair, pr = item % npair;                         // head-major: an XCD sees one or two heads' weight slices
+    bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                          // [D][WP], rows of a k-tile in k-slot order
+    bf16_t* sA = sW + D * WP;                                              // d(x_mid) rows of the pair: [64][AP]
+    bf16_t* sT = sA + 64 * AP;                                             // per sample: Q | K | V | dO tiles, then delta / lse
+
+    // ---- stage everything with coalesced 16-byte loads (row fragments gathered straight from memory touch 32 rows per load
+    //      instruction: measured, the texture-address path then costs more than the arithmetic of the whole kernel)
+#pragma unroll
+    for (int i = 0; i < D * 8 / BW_THREADS; ++i) {
+        const int c = tid + BW_THREADS * i, o = c >> 3, ch = c & 7;
+        const int ol5 = o & 31, s2 = ol5 >> 4, hh = (ol5 >> 3) & 1, j = ol5 & 7;
+        const int r = (o & ~31) + slot_key(s2, hh, j);
+        *reinterpret_cast<u32x4*>(sW + r * WP + 8 * ch) = *reinterpret_cast<const u32x4*>(p.w_hi + (long)o * D + 64 * h + 8 * ch);
+    }
+#pragma unroll
+    for (int i = 0; i < 64 * CPR / BW_THREADS; ++i) {
+        const int c = tid + BW_THREADS * i, row = c / CPR, ch = c % CPR;
+        const int bb = min(2 * pr + (row >> 5), p.Bb - 1), tt = min(row & 31, p.N - 1);
+        *reinterpret_cast<u32x4*>(sA + row * AP + 8 * ch) = *reinterpret_cast<const u32x4*>(p.dxm + ((long)bb * p.N + tt) * p.lddxm + 8 * ch);
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * 3 * 256 / BW_THREADS; ++i) {
+        const int c = tid + BW_THREADS * i, sm = c / 768, which = (c % 768) >> 8, r = (c & 255) >> 3, ch = c & 7;
+        const int bb = min(2 * pr + sm, p.Bb - 1), tt = min(r, p.N - 1);
+        *reinterpret_cast<u32x4*>(sT + sm * BW_SAMPLE + which * BW_TILE + r * WP + 8 * ch) =
+            *reinterpret_cast<const u32x4*>(p.qkv_hi + ((long)bb * p.N + tt) * (3 * D) + which * D + 64 * h + 8 * ch);
+    }
+    if (tid < 64) {
+        const int sm = tid >> 5, bb = min(2 * pr + sm, p.Bb - 1), tt = min(tid & 31, p.N - 1);
+        const long li = p.lse_packed ? ((long)(bb >> 1) * p.H + h) * (2 * p.N) + (bb & 1) * p.N + tt : ((long)bb * p.H + h) * p.N + tt;
+        reinterpret_cast<float*>(sT + sm * BW_SAMPLE + 4 * BW_TILE)[32 + (tid & 31)] = p.lse[li];
+    }
+    __syncthreads();
+
+    const int smp = (wave >> 1) & 1, half = wave & 1;
+    const bool worker = wave < 4;
+    const int b = min(2 * pr + smp, p.Bb - 1);
+    const bool active = worker && 2 * pr + smp < p.Bb;
+    const bool tok_ok = l31 < p.N;
+    const long tokrow = (long)b * p.N + min(l31, p.N - 1);
+    const bf16_t* ldsQ = sT + smp * BW_SAMPLE;
+    const bf16_t* ldsK = ldsQ + BW_TILE;
+    const bf16_t* ldsV = ldsK + BW_TILE;
+    bf16_t* ldsDO = sT + smp * BW_SAMPLE + 3 * BW_TILE;
+    float* ldsR = reinterpret_cast<float*>(ldsDO + BW_TILE);               // [0..31] delta, [32..63] lse
+
+    // ---- d(att)^T[feature 32 half + acc_row][token l31] = sum_o Wproj[o][64 h + feature] * d(x_mid)[token][o]
+    if (worker) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bf16_t* arow = sA + (smp * 32 + l31) * AP + h2 * 8;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            bf16x8 wf[2];
+            gather_frag_s2<HD, WP>(sW + kt * 32 * WP, h2, 32 * half + l31, wf);
+            U128 a0, a1;
+            a0.u = *reinterpret_cast<const u32x4*>(arow + 32 * kt);
+            a1.u = *reinterpret_cast<const u32x4*>(arow + 32 * kt + 16);
+            acc = MFMA32(wf[0], a0.v, acc);
+            acc = MFMA32(wf[1], a1.v, acc);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                                      // rows 8 c + 4 h2 + {0..3} of the accumulator: 4 consecutive features
+            u32x2 v;
+            v[0] = f2bf2(acc[4 * c], acc[4 * c + 1]); v[1] = f2bf2(acc[4 * c + 2], acc[4 * c + 3]);
+            *reinterpret_cast<u32x2*>(ldsDO + l31 * WP + 32 * half + 8 * c + 4 * h2) = v;
+        }
+    }
+    __syncthreads();                                                       // both halves of d(att) of both samples are in LDS
+#if defined(S3D_BWD_PROBE) && S3D_BWD_PROBE == 2        // timing probe: staging + GEMM only
+    if (ldsDO[tid & 31] == 12345.f) p.dqkv[0] = ldsDO[tid];
+    return;
+#endif
+
+    // ---- row fragments of this lane's token; scores and dP of both phases
+    bf16x8 qf[NS], kf[NS], vf[NS], dof[NS];
+    f32x16 sacc, dpacc;
+    float lse_q = 0.f;
+    if (worker) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int off = l31 * WP + 16 * s + 8 * h2;
+            U128 t;
+            t.u = *reinterpret_cast<const u32x4*>(ldsQ + off); qf[s] = t.v;
+            t.u = *reinterpret_cast<const u32x4*>(ldsK + off); kf[s] = t.v;
+            t.u = *reinterpret_cast<const u32x4*>(ldsV + off); vf[s] = t.v;
+            t.u = *reinterpret_cast<const u32x4*>(ldsDO + off); dof[s] = t.v;
+        }
+        lse_q = ldsR[32 + l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+        if (half == 0) {        // phase A: lane = query.  S^T = K . Q^T, dP^T = V . dO^T
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { sacc = MFMA32(kf[s], qf[s], sacc); dpacc = MFMA32(vf[s], dof[s], dpacc); }
+        } else {                // phase B: lane = key.    S = Q . K^T,     dP = dO . V^T
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { sacc = MFMA32(qf[s], kf[s], sacc); dpacc = MFMA32(dof[s], vf[s], dpacc); }
+        }
+    }
+    // delta[q] = sum_k P[q][k] dP[q][k]  (= rowsum(dO * O) in exact arithmetic; with the P this backward recomputes from the bf16 q, k it
+    // makes the rows of dS sum to zero exactly), by the phase-A wave, handed to the phase-B wave through LDS
+    float pq[16], delta = 0.f;
+    if (worker && half == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pq[r] = acc_row(r, h2) < p.N ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+            delta += pq[r] * dpacc[r];
+        }
+        delta = half_sum(delta);
+        if (h2 == 0) ldsR[l31] = delta;
+    }
+    __syncthreads();
+    if (!worker) return;
+
+    const long orow = tokrow * (3 * D) + h * HD;
+    if (half == 0) {
+        // ---- phase A: dQ^T = K^T . dS^T
+        U128 dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j;
+                dsf[s2].h[j] = f2bf(pq[r] * (dpacc[r] - delta) * p.scale);
+            }
+        f32x16 dq[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+        bf16x8 k0f[2], k1f[2];
+        gather_frag_2x2<HD, WP>(ldsK, l31, ldsK, 32 + l31, h2, k0f, k1f);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            dq[0] = MFMA32(k0f[s2], dsf[s2].v, dq[0]);
+            dq[1] = MFMA32(k1f[s2], dsf[s2].v, dq[1]);
+        }
+        if (active && tok_ok) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x2 v;
+                    v[0] = f2bf2(dq[d][4 * c], dq[d][4 * c + 1]); v[1] = f2bf2(dq[d][4 * c + 2], dq[d][4 * c + 3]);
+                    *reinterpret_cast<u32x2*>(p.dqkv + orow + d * 32 + 8 * c + 4 * h2) = v;
+                }
+        }
+    } else {
+        // ---- phase B: dV^T = dO^T . P, dK^T = Q^T . dS
+        U128 pf[2], dsf[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = 8 * s2 + j, q = acc_row(r, h2);
+                const bool ok = tok_ok && q < p.N;
+                const int qc = min(q, p.N - 1);
+                const float pr_ = ok ? fast_exp(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
+                pf[s2].h[j] = f2bf(pr_);
+                dsf[s2].h[j] = f2bf(pr_ * (dpacc[r] - ldsR[qc]) * p.scale);
+            }
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            f32x16 dk, dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+            bf16x8 fo[2], fq[2];
+            gather_frag_2x2<HD, WP>(ldsDO, d * 32 + l31, ldsQ, d * 32 + l31, h2, fo, fq);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                dv = MFMA32(fo[s2], pf[s2].v, dv);
+                dk = MFMA32(fq[s2], dsf[s2].v, dk);
+            }
+            if (active && tok_ok) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    u32x2 a, v;
+                    a[0] = f2bf2(dk[4 * c], dk[4 * c + 1]); a[1] = f2bf2(dk[4 * c + 2], dk[4 * c + 3]);
+                    v[0] = f2bf2(dv[4 * c], dv[4 * c + 1]); v[1] = f2bf2(dv[4 * c + 2], dv[4 * c + 3]);
+                    const long off = orow + d * 32 + 8 * c + 4 * h2;
+                    *reinterpret_cast<u32x2*>(p.dqkv + off + D) = a;
+                    *reinterpret_cast<u32x2*>(p.dqkv + off + 2 * D) = v;
+                }
+            }
+        }
+    }
+}
+
 template <typename K>
 int set_lds(K kern, int bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : 1;
@@ -449,6 +663,32 @@ int launch_mlp1(const FusedMlpArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+namespace {
+template <int D>
+int launch_attn_bwd(const FusedAttnBwdArgs& a, hipStream_t s) {
+    constexpr int LDS = bw_lds_bytes(D);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static const int once = set_lds(blk_attn_bwd_kernel<D>, LDS);
+    (void)once;
+    const int grid = ((a.Bb + 1) / 2) * a.H;
+    constexpr long long KEY = 900000000000LL + D;                          // bench.py: 9 = fused proj dgrad + attention backward
+    if (s3d_prof_skipped(KEY)) return 0;
+    const double M = (double)a.Bb * a.N;
+    s3d_prof_begin(KEY, 2.0 * M * D * D + 10.0 * a.Bb * a.N * a.N * D, s);          // proj dgrad + (s, dp, dq, dk, dv) of every head
+    hipLaunchKernelGGL((blk_attn_bwd_kernel<D>), dim3(grid), dim3(BW_THREADS), LDS, s, a);
+    s3d_prof_end(s);
+    S3D_CHECK_LAUNCH_V("blk_attn_bwd", D);
+    return 0;
+}
+}  // namespace
+
+bool s3d_fused_attn_bwd_ok(int Bb, int N, int D, int H) { return s3d_fused_attn_ok(Bb, N, D, H); }
+int s3d_launch_fused_attn_bwd(const FusedAttnBwdArgs& a, int D, hipStream_t s) {
+    S3D_REQUIRE(s3d_fused_attn_bwd_ok(a.Bb, a.N, D, a.H), "fused attention backward: unsupported shape Bb=%d N=%d D=%d H=%d", a.Bb, a.N, D, a.H);
+    S3D_REQUIRE(a.lddxm % 8 == 0, "fused attention backward: d(x_mid) row pitch must be a multiple of 8");
+    return D == 192 ? launch_attn_bwd<192>(a, s) : launch_attn_bwd<384>(a, s);
+}
 
 bool s3d_fused_attn_ok(int Bb, int N, int D, int H) {
     // small-batch shapes only, like the MLP half: with 1e4 - 1e5 short sequences (group_embed pass 1 on a deit_tiny / deit_small backbone)

@@ -26,7 +26,8 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split);
 
 // dgrad (k-major B, epilogue epi_a) and the wgrad that consumes the same dy, fused into one launch (see gemm.hip)
 struct AdamFillQueue;        // adam_fill.h: optimizer shares riding on the launch as filler workgroups (LDS-DMA pair kernel only)
-int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad, hipStream_t stream, AdamFillQueue* fill = nullptr);
+int s3d_launch_gemm_pair(int epi_a, const GemmArgs& dgrad, const GemmArgs& wgrad, hipStream_t stream, AdamFillQueue* fill = nullptr,
+                         const GemmArgs* wgrad2 = nullptr);
 
 // bench-only timing of every GEMM launch with HIP events on the launch stream (see gemm.hip)
 void s3d_gemm_prof_enable(bool on);

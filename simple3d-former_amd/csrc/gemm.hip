@@ -1337,18 +1337,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dmat_kernel(const GemmArgs 
 // dgrad (NN) + wgrad (TN) of one layer in one launch on the DMA / transpose-read pipeline (64x64 tiles), see gemm_pair_kernel
 template <int EPIA, int NS, bool KTAIL = false>
 __global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, const GemmArgs pb, int nA, int ntxA, int ntyA,
-                                                             int ntxB, int ntyB, const AdamFill fill) {
+                                                             int ntxB, int ntyB, const AdamFill fill, const GemmArgs pc, int nAB, int ntxC,
+                                                             int ntyC) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int bid = blockIdx.x;
-    {   // workgroups behind the two problems run a share of the optimizer update (adam_fill.h)
+    {   // workgroups behind the problems run a share of the optimizer update (adam_fill.h)
         const int nmain = (int)gridDim.x - fill.blocks;
         if (bid >= nmain) { adam_fill_run(fill, bid - nmain); return; }
     }
     if (bid < nA) {
         gemm_dmat_body<false, true, EPIA, NS, 64, 64, KTAIL>(pa, smem, bid, ntxA, ntyA, 0);
-    } else {
+    } else if (bid < nAB) {
         const int b = bid - nA, tiles = ntxB * ntyB;
         gemm_dmat_body<true, true, EPI_ATOMIC, NS, 64, 64, KTAIL>(pb, smem, b % tiles, ntxB, ntyB, b / tiles);
+    } else {        // a SECOND wgrad riding on the launch (its inputs are ready and no launch of its own would fill the chip either)
+        const int b = bid - nAB, tiles = ntxC * ntyC;
+        gemm_dmat_body<true, true, EPI_ATOMIC, NS, 64, 64, KTAIL>(pc, smem, b % tiles, ntxC, ntyC, b / tiles);
     }
 }
 
@@ -1701,7 +1705,7 @@ int s3d_gemm_pick_tile(int M, int N, int splitk, bool split) {
 
 // paired: the wgrad shares its launch with a dgrad that already supplies workgroups, so it needs fewer k-slices (fewer
 // fp32 atomics): full cfg-2 step 2.40 ms with the stand-alone target of 512 workgroups vs 2.33 ms with 256 (round 1).
-static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false) {
+static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired = false, long target_wgs = 0) {
     static const int forced_sk = env_int("S3D_GEMM_SPLITK");
     if (forced_sk > 0) splitk = forced_sk;
     if (s3d_deterministic()) splitk = 1;       // one workgroup per output tile: a single fp32 add per element, no ordering freedom
@@ -1720,7 +1724,7 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
         static const int target_env = env_int("S3D_GEMM_WGRAD_TARGET"), cap_env = env_int("S3D_GEMM_SPLITK_MAX");
         // paired: 145 - 216 workgroups give cfg-2's wgrads 2 / 2 / 2 / 6 k-slices (fc1, fc2, qkv, proj) instead of 2 / 2 / 3 / 8 at 256:
         // fewer fp32 atomics per element -- cfg-2 1.718 -> 1.698 ms, cfg-5 9.71 -> 9.63 ms (round 3; 128 puts fc1 / fc2 on ONE slice: 1.75)
-        const long target = target_env > 0 ? target_env : (paired ? 192 : 512);
+        const long target = target_wgs > 0 ? target_wgs : target_env > 0 ? target_env : (paired ? 192 : 512);
         const long tiles64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
         splitk = (int)((target + tiles64 - 1) / tiles64);
         const int cap = cap_env > 0 ? cap_env : 0;
@@ -1737,9 +1741,10 @@ static void wgrad_split(const GemmArgs& a, int& splitk, int& kchunk, bool paired
 }
 
 template <int EPIA, bool KTAIL = false>
-int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream, AdamFillQueue* fillq) {
+int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream_t stream, AdamFillQueue* fillq, const GemmArgs* c = nullptr,
+                     int splitk_c = 0) {
     if constexpr (!KTAIL) {
-        if (((a.K | b.K) & 63) != 0) return launch_pair_dmat<EPIA, true>(a, b, splitk, stream, fillq);   // partial last k-tile
+        if (((a.K | b.K | (c ? c->K : 0)) & 63) != 0) return launch_pair_dmat<EPIA, true>(a, b, splitk, stream, fillq, c, splitk_c);   // partial last k-tile
     }
     // three 16 KB stages (A 64x64 + B 64x64 bf16): 2.04 ms per cfg-2 step; two stages 2.15 ms, four 2.07 ms
     constexpr int NS = 3;
@@ -1752,24 +1757,26 @@ int launch_pair_dmat(const GemmArgs& a, const GemmArgs& b, int splitk, hipStream
     }
     const int ntxA = (a.N + 63) / 64, ntyA = (a.M + 63) / 64, ntxB = (b.N + 63) / 64, ntyB = (b.M + 63) / 64;
     const int nA = ntxA * ntyA, nB = ntxB * ntyB * splitk;
+    const int ntxC = c ? (c->N + 63) / 64 : 0, ntyC = c ? (c->M + 63) / 64 : 0, nC = ntxC * ntyC * splitk_c;
+    const GemmArgs& cc = c ? *c : b;
     constexpr long long KEY = 600000000000LL + 64 * 100000000LL + 64 * 100000LL + EPIA;     // 6 | 064 | 064 | 000 | EPI dgrad
     if (g_skip_key == KEY) return 0;          // (difference timing: the filler share stays in the queue and is drained by the caller)
     AdamFill fill = adam_fill_none();
     if (fillq) fill = fillq->take(256);
-    const dim3 grid(nA + nB + fill.blocks);
+    const dim3 grid(nA + nB + nC + fill.blocks);
     if (g_prof_on) {
         ProfSlot sl;
         sl.key = KEY;
-        sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K;
+        sl.flops = 2.0 * a.M * a.N * a.K + 2.0 * b.M * b.N * b.K + (c ? 2.0 * c->M * c->N * c->K : 0.0);
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill, cc, nA + nB, ntxC, ntyC);
         (void)hipEventRecord(sl.e1, stream);
         g_prof.push_back(sl);
     } else {
-        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill);
+        hipLaunchKernelGGL(kern, grid, dim3(256), LDS, stream, a, b, nA, ntxA, ntyA, ntxB, ntyB, fill, cc, nA + nB, ntxC, ntyC);
     }
-    S3D_CHECK_LAUNCH_V("gemm_pair_dmat", KEY * 10 + (KTAIL ? 1 : 0));
+    S3D_CHECK_LAUNCH_V("gemm_pair_dmat", KEY * 100 + (c ? 10 : 0) + (KTAIL ? 1 : 0));
     return 0;
 }
 
@@ -1782,11 +1789,26 @@ static int launch_pair_tiles(int ta_, int tb_, const GemmArgs& a, const GemmArgs
 }
 
 // dgrad (NN, epilogue epi_a) + wgrad (TN atomic) in one launch; falls back to two launches for shapes that want 128x128 tiles
-int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream, AdamFillQueue* fillq) {
+// c_in (optional): a second wgrad (TN, split-K atomics) that rides on the same launch -- e.g. attn.proj's wgrad on the qkv pair once its
+// dgrad has moved into the fused attention backward.  Taken by the LDS-DMA pair kernel; every other path launches it on its own.
+int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream, AdamFillQueue* fillq, const GemmArgs* c_in) {
     static const int no_pair = env_int("S3D_GEMM_NOPAIR");
     GemmArgs a = a_in, b = b_in;
     int splitk = 0, kchunk = 0;
     wgrad_split(b, splitk, kchunk, true);
+    GemmArgs c;
+    int splitk_c = 0, kchunk_c = 0;
+    bool c_ok = false;
+    if (c_in) {
+        c = *c_in;
+        wgrad_split(c, splitk_c, kchunk_c, true, 96);         // the launch already holds two problems: fewer k-slices = fewer atomics
+        c.kchunk = kchunk_c;
+        c_ok = (c.M % 8 == 0) && (c.N % 8 == 0) && (c.lda % 8 == 0) && (c.ldb % 8 == 0) && (c.K & 7) == 0 && (kchunk_c & 63) == 0;
+    }
+    struct Tail {          // the extra wgrad as a launch of its own on every path that cannot carry it
+        const GemmArgs* c; bool carried; hipStream_t s;
+        int finish(int rc) const { return (rc || !c || carried) ? rc : s3d_launch_gemm(true, true, false, EPI_ATOMIC, *c, 0, s); }
+    };
     static const int forced_a = env_int("S3D_GEMM_DGRAD_TILE"), forced_b = env_int("S3D_GEMM_WGRAD_TILE");
     const int tile_a = forced_a >= 0 ? forced_a : s3d_gemm_pick_tile(a.M, a.N, 1, false);
     const int tile_b = forced_b >= 0 ? forced_b : s3d_gemm_pick_tile(b.M, b.N, splitk, false);
@@ -1794,6 +1816,7 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
                     (b.lda % 8 == 0) && (b.ldb % 8 == 0);
     if (no_pair > 0 || tile_a >= 2 || tile_b >= 2 || !ok) {
         if (int rc = s3d_launch_gemm(true, true, false, EPI_ATOMIC, b_in, 0, stream)) return rc;
+        if (c_in) if (int rc = s3d_launch_gemm(true, true, false, EPI_ATOMIC, *c_in, 0, stream)) return rc;
         return s3d_launch_gemm(false, true, false, epi_a, a_in, 1, stream);
     }
     a.kchunk = (a.K + 63) / 64 * 64;
@@ -1801,12 +1824,13 @@ int s3d_launch_gemm_pair(int epi_a, const GemmArgs& a_in, const GemmArgs& b_in, 
     static const int pair_dmat = env_int("S3D_GEMM_PAIR_DMAT");          // S3D_GEMM_PAIR_DMAT=0: register-staged pair kernel
     if (pair_dmat != 0 && tile_a == 1 && tile_b == 1 && (a.K & 7) == 0 && (b.K & 7) == 0 && (kchunk & 63) == 0) {
         switch (epi_a) {
-            case EPI_F32: return launch_pair_dmat<EPI_F32>(a, b, splitk, stream, fillq);
-            case EPI_DGELU: return launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream, fillq);
-            case EPI_BF16_BIAS: return launch_pair_dmat<EPI_BF16_BIAS>(a, b, splitk, stream, fillq);
+            case EPI_F32: return Tail{c_in, c_ok, stream}.finish(launch_pair_dmat<EPI_F32>(a, b, splitk, stream, fillq, c_ok ? &c : nullptr, splitk_c));
+            case EPI_DGELU: return Tail{c_in, c_ok, stream}.finish(launch_pair_dmat<EPI_DGELU>(a, b, splitk, stream, fillq, c_ok ? &c : nullptr, splitk_c));
+            case EPI_BF16_BIAS: return Tail{c_in, c_ok, stream}.finish(launch_pair_dmat<EPI_BF16_BIAS>(a, b, splitk, stream, fillq, c_ok ? &c : nullptr, splitk_c));
             default: break;
         }
     }
+    if (c_in) if (int rc = s3d_launch_gemm(true, true, false, EPI_ATOMIC, *c_in, 0, stream)) return rc;
     switch (epi_a) {
         case EPI_F32: return launch_pair_tiles<EPI_F32>(tile_a, tile_b, a, b, splitk, stream);
         case EPI_DGELU: return launch_pair_tiles<EPI_DGELU>(tile_a, tile_b, a, b, splitk, stream);

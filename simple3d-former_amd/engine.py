@@ -180,7 +180,7 @@ class _BlockWorkspace:
         self.ln_tickets = torch.zeros((M + 31) // 32 + 8, dtype=torch.int32, device=device)
         self.shape = L.S3dBlockShape(Bb=Bb, N=N, D=D, H=H, hidden=hidden, eps=LN_EPS, split=1 if split else 0,
                                      ln_tickets=self.ln_tickets.data_ptr() if ln_fuse else None,
-                                     cls_only_block=depth if self.cls_only else 0, fuse=0 if fuse else -1)
+                                     cls_only_block=depth if self.cls_only else 0, fuse=(0 if FUSED_BWD else 1) if fuse else -1)
 
 
 # LayerNorm forward inside the producing GEMM launch (gemm.hip ln_band_tail: the last-arriving tile of a row band normalises it).
@@ -191,6 +191,9 @@ LN_FUSE = os.environ.get('S3D_LN_FUSE', '0') == '1'
 # norm1 + qkv + attention and norm2 + fc1 + GELU as one launch each (csrc/fused_block.hip; S3dBlockShape::fuse) wherever the shape
 # qualifies (small token counts: cfg-1 / cfg-2).  S3D_FUSED_BLOCKS=0: the seven-launch block forward everywhere (A/B measurements).
 FUSED_BLOCKS = os.environ.get('S3D_FUSED_BLOCKS', '1') != '0'
+# ... and in the backward attn.proj's dgrad inside the attention-backward launch, its wgrad on the qkv pair launch (blk_attn_bwd_kernel;
+# S3dBlockShape::fuse = 0).  S3D_FUSED_BWD=0: fused forward only (fuse = 1), for A/B measurements.
+FUSED_BWD = os.environ.get('S3D_FUSED_BWD', '1') != '0'
 # The last block's output is consumed at the class-token rows only (norm(x)[:, 0]): its row-local tail (proj, norm2, mlp) and their
 # backward run on those rows alone (S3dBlockShape::cls_only_block).  S3D_CLS_ONLY=0: dense, as the reference computes it.
 CLS_ONLY = os.environ.get('S3D_CLS_ONLY', '1') != '0'

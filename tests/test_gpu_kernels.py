@@ -172,6 +172,28 @@ def test_gemm_pair_dgrad_and_wgrad_tight(rows, O, I, epi, ld_scale):
             assert bool(torch.isnan(rest.float()).all())
 
 
+def test_gemm_pair_with_a_second_wgrad_riding_on_the_launch():
+    """s3d_gemm_pair3: the qkv pair launch of the fused backward carries attn.proj's wgrad as a third problem (cfg-2 shapes: 1664 rows) --
+    all three results against fp64 products of the same bf16-rounded operands."""
+    g = torch.Generator().manual_seed(77)
+    rows, D = 1664, 384
+    dqkv = torch.randn(rows, 3 * D, generator=g).to(DEV).to(torch.bfloat16)
+    xn1 = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
+    wqkv = (torch.randn(3 * D, D, generator=g) * 0.05).to(DEV).to(torch.bfloat16)
+    dxm = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
+    att = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
+    dxn = torch.full((rows, D), float('nan'), dtype=torch.float32, device=DEV)
+    dWq = torch.zeros(3 * D, D, dtype=torch.float32, device=DEV); dbq = torch.zeros(3 * D, dtype=torch.float32, device=DEV)
+    dWp = torch.zeros(D, D, dtype=torch.float32, device=DEV); dbp = torch.zeros(D, dtype=torch.float32, device=DEV)
+    dg = L.fill(L.S3dGemmArgs(), A_hi=dqkv, lda=3 * D, B_hi=wqkv, ldb=D, M=rows, N=D, K=3 * D, C=dxn, ldc=D, alpha=1.0)
+    wg = L.fill(L.S3dGemmArgs(), A_hi=dqkv, lda=3 * D, B_hi=xn1, ldb=D, M=3 * D, N=D, K=rows, C=dWq, ldc=D, bias_grad=dbq, alpha=1.0)
+    wg2 = L.fill(L.S3dGemmArgs(), A_hi=dxm, lda=D, B_hi=att, ldb=D, M=D, N=D, K=rows, C=dWp, ldc=D, bias_grad=dbp, alpha=1.0)
+    L.check(L.lib().s3d_gemm_pair3(ops.EPI['F32'], ctypes.byref(dg), ctypes.byref(wg), ctypes.byref(wg2), L.current_stream()), 'gemm_pair3')
+    assert rel_err(dxn, dqkv.double() @ wqkv.double()) < 1e-5
+    assert rel_err(dWq, dqkv.double().t() @ xn1.double()) < 2e-5 and rel_err(dbq, dqkv.double().sum(0)) < 2e-5
+    assert rel_err(dWp, dxm.double().t() @ att.double()) < 2e-5 and rel_err(dbp, dxm.double().sum(0)) < 2e-5
+
+
 @pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40), (66000, 192, 192), (33000, 192, 96)])   # k = 40: register-staged kernel
 def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
     """S3dGemmArgs::col_sums: the F32 epilogue of a point-path convolution also accumulates sum(y) and sum(y^2) per output channel
@@ -771,5 +793,66 @@ def test_block_stack_on_a_carved_workspace_equals_the_engine_layout():
         (y0, d0, g0), (y1, d1, g1) = results
         assert torch.equal(y0, y1) and torch.isfinite(y1).all()                    # class rows of the stack's output
         assert torch.equal(d0, d1) and torch.equal(g0, g1) and float(g1.abs().sum()) > 0
+    finally:
+        lib.s3d_set_deterministic(was)
+
+
+@pytest.mark.parametrize('D,H,N,Bb', [(384, 6, 26, 64), (384, 6, 26, 5), (192, 3, 10, 4), (192, 3, 32, 3), (384, 6, 1, 7)])
+def test_fused_attention_backward_equals_the_unfused_launches(D, H, N, Bb):
+    """S3dBlockShape::fuse = 0 (attn.proj dgrad inside the attention-backward launch -- blk_attn_bwd_kernel -- and attn.proj's wgrad as a
+    third problem of the qkv pair launch) against fuse = 1 (proj dgrad || wgrad pair, attention backward, qkv pair) on the same saved
+    activations: d(x_in) and every parameter gradient.  Same arithmetic (bf16 operands, fp32 accumulation, the bf16 rounding of d(att)
+    at the same place), different summation order: rms difference below 2e-3 of the tensor's rms (a dropped tile / head / k-slice would
+    be ~1e-1); 5e-3 where the softmax statistic enters: the fused kernel takes delta = sum_k P dP from the P it recomputes, the unfused one
+    rowsum(dO * O) from the saved output -- equal in exact arithmetic, bf16-rounding apart here (with N = 1 the fused dS is exactly 0)."""
+    from simple3d_former_amd.engine import ParamArena, _BlockWorkspace, _BlockScratch
+    g = torch.Generator().manual_seed(21)
+    Hd, M = 4 * D, Bb * N
+    p = 'blocks.0.'
+    shapes = {p + 'norm1.weight': (D,), p + 'norm1.bias': (D,), p + 'attn.qkv.weight': (3 * D, D), p + 'attn.qkv.bias': (3 * D,),
+              p + 'attn.proj.weight': (D, D), p + 'attn.proj.bias': (D,), p + 'norm2.weight': (D,), p + 'norm2.bias': (D,),
+              p + 'mlp.fc1.weight': (Hd, D), p + 'mlp.fc1.bias': (Hd,), p + 'mlp.fc2.weight': (D, Hd), p + 'mlp.fc2.bias': (D,)}
+    sd = {k: (1 + 0.1 * torch.randn(shp, generator=g)) if ('norm' in k and k.endswith('weight')) else torch.randn(shp, generator=g) * 0.05
+          for k, shp in shapes.items()}
+    x = torch.randn(M, D, generator=g)
+    dy = torch.randn(M, D, generator=g) * 0.1
+    lib = L.lib()
+    was = lib.s3d_get_deterministic()
+    lib.s3d_set_deterministic(1)
+    try:
+        res = []
+        for fuse in (1, 0):
+            arena = ParamArena(shapes, torch.device(DEV)); arena.load(sd); arena.refresh_planes()
+            bp = L.fill(L.S3dBlockParams(), ln1_w=arena.param(p + 'norm1.weight'), ln1_b=arena.param(p + 'norm1.bias'),
+                        ln2_w=arena.param(p + 'norm2.weight'), ln2_b=arena.param(p + 'norm2.bias'), qkv_b=arena.param(p + 'attn.qkv.bias'),
+                        proj_b=arena.param(p + 'attn.proj.bias'), fc1_b=arena.param(p + 'mlp.fc1.bias'), fc2_b=arena.param(p + 'mlp.fc2.bias'),
+                        qkv_w_hi=arena.hi_of(p + 'attn.qkv.weight'), qkv_w_lo=arena.lo_of(p + 'attn.qkv.weight'),
+                        proj_w_hi=arena.hi_of(p + 'attn.proj.weight'), proj_w_lo=arena.lo_of(p + 'attn.proj.weight'),
+                        fc1_w_hi=arena.hi_of(p + 'mlp.fc1.weight'), fc1_w_lo=arena.lo_of(p + 'mlp.fc1.weight'),
+                        fc2_w_hi=arena.hi_of(p + 'mlp.fc2.weight'), fc2_w_lo=arena.lo_of(p + 'mlp.fc2.weight'))
+            bg = L.fill(L.S3dBlockGrads(), ln1_w=arena.grad(p + 'norm1.weight'), ln1_b=arena.grad(p + 'norm1.bias'),
+                        ln2_w=arena.grad(p + 'norm2.weight'), ln2_b=arena.grad(p + 'norm2.bias'), qkv_w=arena.grad(p + 'attn.qkv.weight'),
+                        qkv_b=arena.grad(p + 'attn.qkv.bias'), proj_w=arena.grad(p + 'attn.proj.weight'), proj_b=arena.grad(p + 'attn.proj.bias'),
+                        fc1_w=arena.grad(p + 'mlp.fc1.weight'), fc1_b=arena.grad(p + 'mlp.fc1.bias'), fc2_w=arena.grad(p + 'mlp.fc2.weight'),
+                        fc2_b=arena.grad(p + 'mlp.fc2.bias'))
+            ws = _BlockWorkspace(1, Bb, N, D, H, Hd, DEV, True)
+            ws.shape.fuse = fuse
+            sc = _BlockScratch(M, D, H, Hd, Bb * H * N, DEV)
+            sc.dqkv.fill_(float('nan'))                                  # every d(q | k | v) entry the qkv GEMMs read must have been written
+            ws.x[0].copy_(x.to(DEV))
+            L.check(lib.s3d_block_fwd(ctypes.byref(ws.shape), ctypes.byref(bp), ctypes.byref(ws.acts[0]), L.current_stream()), 'block_fwd')
+            sc.dx_a.copy_(dy.to(DEV)); sc.dx_a_bf.copy_(dy.to(DEV).to(torch.bfloat16))
+            L.check(lib.s3d_block_bwd(ctypes.byref(ws.shape), ctypes.byref(bp), ctypes.byref(bg), ctypes.byref(ws.acts[0]), ctypes.byref(sc.c),
+                                      L.current_stream()), 'block_bwd')
+            torch.cuda.synchronize()
+            res.append((sc.dx_a.clone(), sc.dqkv.float().clone(), {k: arena.grad(k).clone() for k in shapes}))
+        (dx0, dq0, g0), (dx1, dq1, g1) = res
+        assert torch.isfinite(dq1).all() and torch.isfinite(dx1).all()
+        assert rms_err(dq1, dq0) < 5e-3, f'd(qkv): {rms_err(dq1, dq0):.3e}'
+        assert rms_err(dx1, dx0) < 5e-3, f'd(x_in): {rms_err(dx1, dx0):.3e}'
+        for k in shapes:
+            e = rms_err(g1[k], g0[k])
+            assert e < (5e-3 if ('qkv' in k or 'norm1' in k) else 2e-3), f'{k}: {e:.3e}'
+        assert rms_err(g1[p + 'attn.proj.weight'], g0[p + 'attn.proj.weight']) < 2e-5       # the same wgrad, riding on another launch
     finally:
         lib.s3d_set_deterministic(was)
