@@ -45,7 +45,10 @@ constexpr int FB_THREADS = 512;          // 8 waves: 2 (rows) x 4 (weight rows)
 constexpr int FB_ROWS = 64;              // activation rows per workgroup
 constexpr int FB_WROWS = 192;            // weight rows (output columns) per workgroup
 constexpr int FB_BK = 32;                // k per weight stage
-constexpr int FB_NS = 4;                 // weight stages in the ring
+#ifndef S3D_FB_NS
+#define S3D_FB_NS 4
+#endif
+constexpr int FB_NS = S3D_FB_NS;         // weight stages in the ring (make EXP=1 EXTRA=-DS3D_FB_NS=5: measured, section 6)
 constexpr int FB_PLANE = FB_WROWS * FB_BK * 2;       // 12 288 B: one plane of a stage, 64-byte rows
 constexpr int FB_STAGE = 2 * FB_PLANE;               // hi + lo
 constexpr int FB_APLANE = FB_ROWS * 128;             // 8 192 B: one plane of an A slab ([64 rows][64 k], 128-byte rows)
