@@ -57,6 +57,18 @@ constexpr int FB_PPW = FB_STAGE / 1024 / (FB_THREADS / 64);   // DMA pieces per 
 
 constexpr int fb_lds_bytes(int D) { return FB_NS * FB_STAGE + 2 * FB_ABUF + 2 * D * 4; }
 
+// in-kernel timeline (make TL=1 only; tools/fused_timeline_probe.py): thread 0 of every workgroup stamps s_memtime at the phase
+// boundaries, s_memrealtime (100 MHz, chip-wide) at entry / exit.  Rows [0, 256) = blk_attn, [256, 512) = blk_mlp1, [512, 768) = blk_attn_bwd.
+#ifdef S3D_TIMELINE
+__device__ unsigned long long* g_fb_tl = nullptr;      // [768][FB_TL_SLOTS]
+constexpr int FB_TL_SLOTS = 32;
+#define FB_TL(w, i) do { if (g_fb_tl && threadIdx.x == 0) g_fb_tl[(long)(w) * FB_TL_SLOTS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define FB_TL_REAL(w, i) do { if (g_fb_tl && threadIdx.x == 0) g_fb_tl[(long)(w) * FB_TL_SLOTS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FB_TL(w, i) do {} while (0)
+#define FB_TL_REAL(w, i) do {} while (0)
+#endif
+
 // sum over the 8 consecutive lanes that share a row: two quad butterflies + row_half_mirror (lane i <-> 7 - i within 8)
 __device__ __forceinline__ float oct_sum(float v) {
     int x = __float_as_int(v);
@@ -81,7 +93,7 @@ template <int D>
 __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* gamma, const float* beta, const float eps, const bf16_t* w_hi,
                                                const bf16_t* w_lo, const long wrow0, const long wrow1, const long wrow2, bf16_t* xn_hi,
                                                bf16_t* xn_lo, const int kp_store, unsigned char* smem, f32x4 (&acc)[2][3], float& mean,
-                                               float& rstd) {
+                                               float& rstd, const int tlw = 0) {
     constexpr int KP = D / 64, KT = D / FB_BK, NS = FB_NS;
     static_assert(D % 64 == 0 && KT >= NS - 1, "model dimension");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,7 +120,9 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
         for (int j = 0; j < FB_PPW; ++j) glds16(gp[j] + s * FB_BK, dst + j * 1024);
     };
 #pragma unroll
+    FB_TL(tlw, 2);
     for (int u = 0; u < NS - 1; ++u) issue(u);
+    FB_TL(tlw, 3);                                                         // ring prologue issued
 
     // ---- this thread's share of its row, gamma / beta -> LDS
     float xr[KP][8];
@@ -135,12 +149,14 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
             for (int i = 0; i < 8; ++i) { const float d = xr[kp][i] - mean; q += d * d; }
         rstd = rsqrtf(oct_sum(q) * inv_d + eps);
     }
+    FB_TL(tlw, 4);                                                         // rows arrived, statistics done
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                                       // gamma / beta are in LDS
+    FB_TL(tlw, 5);
 
 #pragma unroll
     for (int kp = 0; kp < KP; ++kp) {
@@ -173,6 +189,7 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
             if (s + NS - 1 <= KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * FB_PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                               // everyone's pieces + the A slab; stage s - 1 is free
+            FB_TL(tlw, 6 + s);                                             // k-step s may start (6 .. 17 at D = 384)
             if (s + NS - 1 < KT) issue(s + NS - 1);
             const unsigned char* sW = smem + (s % NS) * FB_STAGE;
             const unsigned char* sA = abuf + (kp & 1) * FB_ABUF;
@@ -206,6 +223,7 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
         }
     }
+    FB_TL(tlw, 20);                                                        // last MFMAs issued
 }
 
 // contiguous runs of items per XCD (the dispatcher places workgroup b on XCD b % 8): workgroups that stream the same weight slice
@@ -225,6 +243,7 @@ constexpr int QKV_TILE = 32 * QKV_PITCH * 2;                               // by
 template <int D>
 __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FB_TL_REAL(blockIdx.x, 0); FB_TL(blockIdx.x, 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int npair = (p.Bb + 1) >> 1;
     const int item = xcd_item(blockIdx.x, npair * p.H);
@@ -239,7 +258,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
     float mean, rstd;
     const long xo = row_ok ? grow * D + 64 * h + 8 * c8 : -1;              // this head's 64 columns of xn1
     ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, 64 * h, D + 64 * h, 2 * D + 64 * h,
-                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, h, smem, acc, mean, rstd);
+                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, h, smem, acc, mean, rstd, blockIdx.x);
     if (h == 0 && c8 == 0 && row_ok) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
 
     // ---- q | k | v (+ bias) -> LDS tiles [sample][q,k,v][hi,lo][32 tokens][QKV_PITCH] in the (now idle) weight ring
@@ -247,6 +266,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
     static_assert(12 * TILE <= FB_NS * FB_STAGE, "staged q / k / v tiles fit the weight ring");
     const int wm = wave >> 2, wn = wave & 3;
     __syncthreads();                                                       // every wave is done with the last stage
+    FB_TL(blockIdx.x, 21);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int n = wn * 48 + j * 16 + (lane >> 4) * 4;                  // 4 consecutive columns of q | k | v
@@ -276,6 +296,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.qkv_hi + ((long)bb * p.N + t) * (3 * D) + which * D + 64 * h + 8 * ch));
         }
     }
+    FB_TL(blockIdx.x, 22);                                                 // q | k | v staged and their stores issued
     // ---- attention: wave w < 2 owns sample w.  S^T = K Q^T on 32x32x16 MFMAs (every lane owns one query column), one key tile
     if (wave >= 2) return;
     const int bb = 2 * pr + wave;
@@ -347,6 +368,11 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
             p.lse[li] = mx + logf(l);
         }
     }
+#ifdef S3D_TIMELINE
+    FB_TL(blockIdx.x, 23);                                                 // attention done, stores issued
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FB_TL(blockIdx.x, 24); FB_TL_REAL(blockIdx.x, 25);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -358,6 +384,7 @@ constexpr int H_TILE = FB_ROWS * H_PITCH * 2;                              // by
 template <int D>
 __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    FB_TL_REAL(256 + blockIdx.x, 0); FB_TL(256 + blockIdx.x, 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int RB = p.band_rows;
     const int nband = (int)((p.M + RB - 1) / RB);
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
     const long xo = (row_ok && js < D / 64) ? grow * D + 64 * js + 8 * c8 : -1;   // slices 0 .. D / 64 - 1 store one 64-column slab of xn2 each
     const long w0 = (long)FB_WROWS * js;
     ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, w0, w0 + 64, w0 + 128,
-                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, js, smem, acc, mean, rstd);
+                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, js, smem, acc, mean, rstd, 256 + blockIdx.x);
     if (js == 0 && c8 == 0 && row_ok) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
 
     // ---- epilogue: pre = acc + b1 -> bf16; gelu(pre) -> split planes; staged through the idle weight ring for 16-byte row stores
@@ -381,6 +408,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
     static_assert(3 * TILE <= FB_NS * FB_STAGE, "staged outputs fit the weight ring");
     const int wm = wave >> 2, wn = wave & 3;
     __syncthreads();
+    FB_TL(256 + blockIdx.x, 21);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int n = wn * 48 + j * 16 + (lane >> 4) * 4;
@@ -401,6 +429,7 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
         }
     }
     __syncthreads();
+    FB_TL(256 + blockIdx.x, 22);                                           // GELU epilogue staged
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int e = tid + FB_THREADS * i;                                // 3 arrays x 64 rows x 24 chunks of 16 bytes
@@ -412,6 +441,11 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
             if (arr == 0) __builtin_nontemporal_store(v, dst); else *dst = v;      // hpre: read next by the backward
         }
     }
+#ifdef S3D_TIMELINE
+    FB_TL(256 + blockIdx.x, 23);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FB_TL(256 + blockIdx.x, 24); FB_TL_REAL(256 + blockIdx.x, 25);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -435,6 +469,7 @@ template <int D>
 __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int HD = 64, NS = HD / 16, KT = D / 32, AP = bw_apitch(D), WP = BW_WPITCH, CPR = D / 8;
+    FB_TL_REAL(512 + blockIdx.x, 0); FB_TL(512 + blockIdx.x, 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h2 = lane >> 5, l31 = lane & 31;
     const int npair = (p.Bb + 1) >> 1;
@@ -471,7 +506,9 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
         const long li = p.lse_packed ? ((long)(bb >> 1) * p.H + h) * (2 * p.N) + (bb & 1) * p.N + tt : ((long)bb * p.H + h) * p.N + tt;
         reinterpret_cast<float*>(sT + sm * BW_SAMPLE + 4 * BW_TILE)[32 + (tid & 31)] = p.lse[li];
     }
+    FB_TL(512 + blockIdx.x, 2);                                            // this thread's staged pieces are in LDS
     __syncthreads();
+    FB_TL(512 + blockIdx.x, 3);
 
     const int smp = (wave >> 1) & 1, half = wave & 1;
     const bool worker = wave < 4;
@@ -508,11 +545,9 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
             *reinterpret_cast<u32x2*>(ldsDO + l31 * WP + 32 * half + 8 * c + 4 * h2) = v;
         }
     }
+    FB_TL(512 + blockIdx.x, 4);                                            // proj dgrad done
     __syncthreads();                                                       // both halves of d(att) of both samples are in LDS
-#if defined(S3D_BWD_PROBE) && S3D_BWD_PROBE == 2        // timing probe: staging + GEMM only
-    if (ldsDO[tid & 31] == 12345.f) p.dqkv[0] = ldsDO[tid];
-    return;
-#endif
+    FB_TL(512 + blockIdx.x, 5);
 
     // ---- row fragments of this lane's token; scores and dP of both phases
     bf16x8 qf[NS], kf[NS], vf[NS], dof[NS];
@@ -552,6 +587,7 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
         if (h2 == 0) ldsR[l31] = delta;
     }
     __syncthreads();
+    FB_TL(512 + blockIdx.x, 6);                                            // delta handed over
     if (!worker) return;
 
     const long orow = tokrow * (3 * D) + h * HD;
@@ -626,7 +662,21 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
             }
         }
     }
+#ifdef S3D_TIMELINE
+    FB_TL(512 + blockIdx.x, 7);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    FB_TL(512 + blockIdx.x, 8); FB_TL_REAL(512 + blockIdx.x, 9);
+#endif
 }
+
+#ifdef S3D_TIMELINE
+}  // namespace
+extern "C" int s3d_debug_fused_timeline_set(void* buf) {
+    unsigned long long* b = reinterpret_cast<unsigned long long*>(buf);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_fb_tl), &b, sizeof(b)) == hipSuccess ? 0 : 1;
+}
+namespace {
+#endif
 
 template <typename K>
 int set_lds(K kern, int bytes) {
