@@ -41,19 +41,27 @@
 
 namespace {
 
-constexpr int FB_THREADS = 512;          // 8 waves: 2 (rows) x 4 (weight rows)
+constexpr int FB_THREADS = 512;          // 8 compute waves: 2 (rows) x 4 (weight rows)
+#ifndef S3D_FB_PROD
+#define S3D_FB_PROD 0
+#endif
+constexpr int FB_PROD = S3D_FB_PROD;     // weight-stream producer waves behind the compute waves (0: the compute waves issue the DMA themselves)
+constexpr int FB_LAUNCH = FB_THREADS + 64 * FB_PROD;
 constexpr int FB_ROWS = 64;              // activation rows per workgroup
 constexpr int FB_WROWS = 192;            // weight rows (output columns) per workgroup
-constexpr int FB_BK = 32;                // k per weight stage
+#ifndef S3D_FB_BK
+#define S3D_FB_BK 32
+#endif
+constexpr int FB_BK = S3D_FB_BK;         // k per weight stage: 32 (64-byte row segments) or 64 (128-byte ones: whole cache lines)
 #ifndef S3D_FB_NS
 #define S3D_FB_NS 4
 #endif
 constexpr int FB_NS = S3D_FB_NS;         // weight stages in the ring (make EXP=1 EXTRA=-DS3D_FB_NS=5: measured, section 6)
-constexpr int FB_PLANE = FB_WROWS * FB_BK * 2;       // 12 288 B: one plane of a stage, 64-byte rows
+constexpr int FB_ROWB = FB_BK * 2;                   // bytes per weight row and stage
+constexpr int FB_PLANE = FB_WROWS * FB_ROWB;         // 12 288 B: one plane of a stage (k = 32)
 constexpr int FB_STAGE = 2 * FB_PLANE;               // hi + lo
 constexpr int FB_APLANE = FB_ROWS * 128;             // 8 192 B: one plane of an A slab ([64 rows][64 k], 128-byte rows)
 constexpr int FB_ABUF = 2 * FB_APLANE;
-constexpr int FB_PPW = FB_STAGE / 1024 / (FB_THREADS / 64);   // DMA pieces per wave and stage = 3
 
 constexpr int fb_lds_bytes(int D) { return FB_NS * FB_STAGE + 2 * FB_ABUF + 2 * D * 4; }
 
@@ -90,7 +98,7 @@ __device__ __forceinline__ float oct_sum(float v) {
 // (plain scalars, not a parameter struct: a select between two struct members becomes a select between their ADDRESSES and drags
 // the struct into scratch memory -- the round-1 lesson of common.h, met again here)
 template <int D>
-__device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* gamma, const float* beta, const float eps, const bf16_t* w_hi,
+__device__ __forceinline__ bool ln_gemm_64x192(const float* xrow, const float* gamma, const float* beta, const float eps, const bf16_t* w_hi,
                                                const bf16_t* w_lo, const long wrow0, const long wrow1, const long wrow2, bf16_t* xn_hi,
                                                bf16_t* xn_lo, const int kp_store, unsigned char* smem, f32x4 (&acc)[2][3], float& mean,
                                                float& rstd, const int tlw = 0) {
@@ -103,26 +111,54 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
     float* gb = reinterpret_cast<float*>(abuf + 2 * FB_ABUF);              // gamma [D] | beta [D]
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
-    // ---- weight stream: this lane's source of each of its wave's pieces (k-step 0)
-    const bf16_t* gp[FB_PPW];
+    // ---- weight stream: this lane's source of each of its wave's pieces (k-step 0).  FB_PROD > 0: only the producer waves (wave >= 8)
+    //      stream; a wave that issues global_load_lds sits in the issue stage until the CU's memory pipeline has taken every piece
+    //      (measured: ~1.1 k cycles per k-step for the 24 pieces of a stage, tools/fused_timeline_probe.py), and compute waves that do
+    //      it themselves add that to every k-step.  Producer waves wait there instead while the compute waves read fragments and
+    //      feed the matrix pipe; they hand a landed stage over at the k-step barrier (only the issuing wave can count its vmcnt).
+    constexpr int NSTREAM = FB_PROD > 0 ? FB_PROD : FB_THREADS / 64;       // waves that issue the stream
+    constexpr int PPW = FB_STAGE / 1024 / NSTREAM;                         // DMA pieces per streaming wave and stage
+    static_assert((FB_STAGE / 1024) % NSTREAM == 0, "every streaming wave issues the same number of 1 KB pieces per stage");
+    const int sw = FB_PROD > 0 ? wave - FB_THREADS / 64 : wave;            // index among the streaming waves (negative: compute wave)
+    const bf16_t* gp[PPW];
 #pragma unroll
-    for (int j = 0; j < FB_PPW; ++j) {
-        const int piece = wave * FB_PPW + j;                               // [hi plane: 12 pieces of 16 rows][lo plane]
-        const int plane = piece / 12, rb = piece % 12;
-        const int r = rb * 16 + (lane >> 2), c = lane & 3;
+    for (int j = 0; j < PPW; ++j) {
+        constexpr int RPP = 1024 / FB_ROWB, CPRW = FB_ROWB / 16, PP = FB_WROWS / RPP;   // rows per 1 KB piece, chunks per row, pieces per plane
+        const int piece = max(sw, 0) * PPW + j;                            // [hi plane: PP pieces of RPP rows][lo plane]
+        const int plane = piece / PP, rb = piece % PP;
+        const int r = rb * RPP + lane / CPRW, c = lane % CPRW;
         const int rq = r >> 6;
         const long wrow = (rq == 0 ? wrow0 : rq == 1 ? wrow1 : wrow2) + (r & 63);
-        gp[j] = (plane ? w_lo : w_hi) + wrow * D + ((c ^ dma_swz32(r)) << 3);
+        gp[j] = (plane ? w_lo : w_hi) + wrow * D + ((c ^ (FB_BK == 64 ? dma_swz64(r) : dma_swz32(r))) << 3);
     }
     auto issue = [&](int s) {
-        const unsigned dst = lds0 + (unsigned)((s % NS) * FB_STAGE + wave * FB_PPW * 1024);
+        const unsigned dst = lds0 + (unsigned)((s % NS) * FB_STAGE + max(sw, 0) * PPW * 1024);
 #pragma unroll
-        for (int j = 0; j < FB_PPW; ++j) glds16(gp[j] + s * FB_BK, dst + j * 1024);
+        for (int j = 0; j < PPW; ++j) glds16(gp[j] + s * FB_BK, dst + j * 1024);
     };
+    if constexpr (FB_PROD > 0) {
+        if (sw >= 0) {                                                     // ---- producer wave: stream, hand over, leave
+            __syncthreads();                                               // (1) the compute waves' row loads are in the queue ahead of the stream
 #pragma unroll
-    FB_TL(tlw, 2);
-    for (int u = 0; u < NS - 1; ++u) issue(u);
-    FB_TL(tlw, 3);                                                         // ring prologue issued
+            for (int u = 0; u < NS - 1; ++u) issue(u);
+            __syncthreads();                                               // (2) gamma / beta
+#pragma unroll
+            for (int st = 0; st < KT; ++st) {
+                // stage st has landed once only this wave's pieces of the (at most NS - 2) younger stages are outstanding
+                if (st + NS - 2 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+                else if (NS > 3 && st + NS - 3 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS > 3 ? NS - 3 : 0) * PPW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();                                           // (3 + st) stage st handed over; the compute waves are done with st - 1
+                if (st + NS - 1 < KT) issue(st + NS - 1);
+            }
+            return true;                                                   // barriers after this count the surviving waves only
+        }
+    } else {
+        FB_TL(tlw, 2);
+#pragma unroll
+        for (int u = 0; u < NS - 1; ++u) issue(u);
+        FB_TL(tlw, 3);                                                     // ring prologue issued
+    }
 
     // ---- this thread's share of its row, gamma / beta -> LDS
     float xr[KP][8];
@@ -131,6 +167,12 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
         const f32x4 a = *reinterpret_cast<const f32x4*>(xrow + 64 * kp), b = *reinterpret_cast<const f32x4*>(xrow + 64 * kp + 4);
         xr[kp][0] = a[0]; xr[kp][1] = a[1]; xr[kp][2] = a[2]; xr[kp][3] = a[3];
         xr[kp][4] = b[0]; xr[kp][5] = b[1]; xr[kp][6] = b[2]; xr[kp][7] = b[3];
+    }
+    if constexpr (FB_PROD > 0) {
+        // the row loads must be IN the queue before the producers start: pin them in front of the barrier (plain loads could sink past it)
+        asm volatile("" ::: "memory");
+        __syncthreads();                                                   // (1)
+        FB_TL(tlw, 3);
     }
     for (int i = tid; i < 2 * D / 4; i += FB_THREADS)
         reinterpret_cast<f32x4*>(gb)[i] = *reinterpret_cast<const f32x4*>((i < D / 4 ? gamma : beta - D) + 4 * i);
@@ -181,16 +223,22 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
                 *reinterpret_cast<u32x4*>(xn_lo) = lo;
             }
         }
+        constexpr int SPS = 64 / FB_BK;                                    // stages per 64-wide A slab: 2 (k = 32) or 1 (k = 64)
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            const int s = 2 * kp + half;
-            // stage s has landed once at most the NS - 2 younger stages' pieces of this wave are outstanding (loads retire in order;
-            // stores in between only make the wait longer)
-            if (s + NS - 1 <= KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * FB_PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                               // everyone's pieces + the A slab; stage s - 1 is free
-            FB_TL(tlw, 6 + s);                                             // k-step s may start (6 .. 17 at D = 384)
-            if (s + NS - 1 < KT) issue(s + NS - 1);
+            const int s = SPS == 2 ? 2 * kp + half : kp;
+            if (SPS == 2 || half == 0) {
+                // stage s has landed once at most the NS - 2 younger stages' pieces of this wave are outstanding (loads retire in order;
+                // stores in between only make the wait longer)
+                if constexpr (FB_PROD == 0) {
+                    if (s + NS - 1 <= KT && NS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();                                           // everyone's pieces + the A slab; stage s - 1 is free
+                FB_TL(tlw, 6 + s);                                         // k-step s may start (6 .. 17 at D = 384)
+                if constexpr (FB_PROD == 0) { if (s + NS - 1 < KT) issue(s + NS - 1); }
+                if (s == 4) FB_TL(tlw, 26);                                // (timeline) ring refill of k-step 4 issued
+            }
             const unsigned char* sW = smem + (s % NS) * FB_STAGE;
             const unsigned char* sA = abuf + (kp & 1) * FB_ABUF;
             const int kcA = half * 4 + (lane >> 4);
@@ -205,10 +253,14 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int r = wn * 48 + j * 16 + (lane & 15);
-                const unsigned char* q = sW + r * 64 + (((lane >> 4) ^ dma_swz32(r)) << 4);
+                const unsigned char* q = FB_BK == 64 ? sW + r * 128 + ((kcA ^ dma_swz64(r)) << 4)
+                                                     : sW + r * 64 + (((lane >> 4) ^ dma_swz32(r)) << 4);
                 b_hi[j] = *reinterpret_cast<const bf16x8*>(q);
                 b_lo[j] = *reinterpret_cast<const bf16x8*>(q + FB_PLANE);
             }
+#ifdef S3D_TIMELINE
+            if (s == 4) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); FB_TL(tlw, 27); }      // fragments of k-step 4 arrived
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -221,9 +273,11 @@ __device__ __forceinline__ void ln_gemm_64x192(const float* xrow, const float* g
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+            if (s == 4) FB_TL(tlw, 28);                                    // (timeline) MFMAs of k-step 4 issued
         }
     }
     FB_TL(tlw, 20);                                                        // last MFMAs issued
+    return false;
 }
 
 // contiguous runs of items per XCD (the dispatcher places workgroup b on XCD b % 8): workgroups that stream the same weight slice
@@ -241,7 +295,7 @@ constexpr int QKV_PITCH = 72;            // bf16 elements per staged q / k / v r
 constexpr int QKV_TILE = 32 * QKV_PITCH * 2;                               // bytes per staged [32 tokens][64] plane
 
 template <int D>
-__global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArgs p) {
+__global__ __launch_bounds__(FB_LAUNCH) void blk_attn_kernel(const FusedAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FB_TL_REAL(blockIdx.x, 0); FB_TL(blockIdx.x, 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,8 +311,9 @@ __global__ __launch_bounds__(FB_THREADS) void blk_attn_kernel(const FusedAttnArg
     f32x4 acc[2][3];
     float mean, rstd;
     const long xo = row_ok ? grow * D + 64 * h + 8 * c8 : -1;              // this head's 64 columns of xn1
-    ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, 64 * h, D + 64 * h, 2 * D + 64 * h,
-                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, h, smem, acc, mean, rstd, blockIdx.x);
+    if (ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, 64 * h, D + 64 * h, 2 * D + 64 * h,
+                          xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, h, smem, acc, mean, rstd, blockIdx.x))
+        return;                                                            // weight-stream producer wave: done
     if (h == 0 && c8 == 0 && row_ok) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
 
     // ---- q | k | v (+ bias) -> LDS tiles [sample][q,k,v][hi,lo][32 tokens][QKV_PITCH] in the (now idle) weight ring
@@ -382,7 +437,7 @@ constexpr int H_PITCH = 200;             // bf16 elements per staged output row 
 constexpr int H_TILE = FB_ROWS * H_PITCH * 2;                              // bytes per staged [64][192] bf16 array
 
 template <int D>
-__global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs p) {
+__global__ __launch_bounds__(FB_LAUNCH) void blk_mlp1_kernel(const FusedMlpArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     FB_TL_REAL(256 + blockIdx.x, 0); FB_TL(256 + blockIdx.x, 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -399,8 +454,9 @@ __global__ __launch_bounds__(FB_THREADS) void blk_mlp1_kernel(const FusedMlpArgs
     float mean, rstd;
     const long xo = (row_ok && js < D / 64) ? grow * D + 64 * js + 8 * c8 : -1;   // slices 0 .. D / 64 - 1 store one 64-column slab of xn2 each
     const long w0 = (long)FB_WROWS * js;
-    ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, w0, w0 + 64, w0 + 128,
-                      xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, js, smem, acc, mean, rstd, 256 + blockIdx.x);
+    if (ln_gemm_64x192<D>(p.x + grow * D + 8 * c8, p.gamma, p.beta, p.eps, p.w_hi, p.w_lo, w0, w0 + 64, w0 + 128,
+                          xo >= 0 ? p.xn_hi + xo : nullptr, xo >= 0 ? p.xn_lo + xo : nullptr, js, smem, acc, mean, rstd, 256 + blockIdx.x))
+        return;                                                            // weight-stream producer wave: done
     if (js == 0 && c8 == 0 && row_ok) { p.mean[grow] = mean; p.rstd[grow] = rstd; }
 
     // ---- epilogue: pre = acc + b1 -> bf16; gelu(pre) -> split planes; staged through the idle weight ring for 16-byte row stores
@@ -694,7 +750,7 @@ int launch_attn(const FusedAttnArgs& a, hipStream_t s) {
     if (s3d_prof_skipped(KEY)) return 0;
     const double M = (double)a.Bb * a.N;
     s3d_prof_begin(KEY, 2.0 * M * 3 * D * D + 4.0 * a.Bb * a.N * a.N * D, s);       // qkv GEMM + (q k^T, p v) of every head
-    hipLaunchKernelGGL((blk_attn_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
+    hipLaunchKernelGGL((blk_attn_kernel<D>), dim3(grid), dim3(FB_LAUNCH), LDS, s, a);
     s3d_prof_end(s);
     S3D_CHECK_LAUNCH_V("blk_attn", D);
     return 0;
@@ -709,7 +765,7 @@ int launch_mlp1(const FusedMlpArgs& a, hipStream_t s) {
     constexpr long long KEY = 800000000000LL + D;                          // bench.py: 8 = fused norm2 + fc1 + GELU
     if (s3d_prof_skipped(KEY)) return 0;
     s3d_prof_begin(KEY, 2.0 * (double)a.M * a.hidden * D, s);
-    hipLaunchKernelGGL((blk_mlp1_kernel<D>), dim3(grid), dim3(FB_THREADS), LDS, s, a);
+    hipLaunchKernelGGL((blk_mlp1_kernel<D>), dim3(grid), dim3(FB_LAUNCH), LDS, s, a);
     s3d_prof_end(s);
     S3D_CHECK_LAUNCH_V("blk_mlp1", D);
     return 0;

@@ -23,10 +23,12 @@ from oracle import voxel_oracle as vo  # noqa: E402  (synthetic inputs only)
 SLOTS = 32
 PHASES = {
     'blk_attn': (0, 192, [(1, 2, 'entry -> addresses'), (2, 3, 'ring prologue issued'), (3, 4, 'rows arrived + LN statistics'), (4, 5, 'barrier (gamma / beta)'),
-                          (5, 6, 'slab 0 + stage 0 landed'), (6, 17, 'k-steps 0 .. 10'), (17, 20, 'last k-step'), (20, 21, 'drain barrier'),
+                          (5, 6, 'slab 0 + stage 0 landed'), (6, 17, 'k-steps 0 .. 10'), (10, 26, '  k-step 4: ring refill issued'), (26, 27, '  k-step 4: fragments read'), (27, 28, '  k-step 4: MFMAs issued'), (28, 11, '  k-step 4: wait + barrier of k-step 5'),
+                          (17, 20, 'last k-step'), (20, 21, 'drain barrier'),
                           (21, 22, 'q|k|v staged + stored'), (22, 23, 'attention (wave 0)'), (23, 24, 'stores acknowledged')]),
     'blk_mlp1': (256, 256, [(1, 2, 'entry -> addresses'), (2, 3, 'ring prologue issued'), (3, 4, 'rows arrived + LN statistics'), (4, 5, 'barrier (gamma / beta)'),
-                            (5, 6, 'slab 0 + stage 0 landed'), (6, 17, 'k-steps 0 .. 10'), (17, 20, 'last k-step'), (20, 21, 'drain barrier'),
+                            (5, 6, 'slab 0 + stage 0 landed'), (6, 17, 'k-steps 0 .. 10'), (10, 26, '  k-step 4: ring refill issued'), (26, 27, '  k-step 4: fragments read'), (27, 28, '  k-step 4: MFMAs issued'), (28, 11, '  k-step 4: wait + barrier of k-step 5'),
+                            (17, 20, 'last k-step'), (20, 21, 'drain barrier'),
                             (21, 22, 'bias + GELU + split -> LDS'), (22, 23, 'row stores issued'), (23, 24, 'stores acknowledged')]),
     'blk_attn_bwd': (512, 192, [(1, 2, 'staging loads -> LDS (this thread)'), (2, 3, 'barrier'), (3, 4, 'proj dgrad (12 k-tiles) + dO tile'), (4, 5, 'barrier'),
                                 (5, 6, 'S, dP, delta + barrier'), (6, 7, 'dQ (wave 0) + stores issued'), (7, 8, 'stores acknowledged')]),
@@ -73,7 +75,8 @@ def main():
             d = (rows[ok, b] - rows[ok, a]).astype(np.float64)
             if len(d) == 0:
                 continue
-            total += np.median(d)
+            if not label.startswith('  '):
+                total += np.median(d)
             print(f'   {label:38s} median {np.median(d):8.0f} cycles   p10 {np.percentile(d, 10):8.0f}   p90 {np.percentile(d, 90):8.0f}')
         print(f'   {"sum of medians":38s}        {total:8.0f} cycles')
 
