@@ -38,7 +38,7 @@ __device__ __forceinline__ bool seg_ok(const AttnArgs& p, int q, int k) {
     return (q >= p.seg) == (k >= p.seg);
 }
 
-template <int HD>
+template <int HD, int PITCH = HD>
 __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld, long row0_off, long st_ld, int t0,
                                            int N, int lane) {
     constexpr int CPR = HD / 8;                 // 16-byte chunks per row
@@ -47,7 +47,7 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
         const int c = min(lane + 64 * i, 32 * CPR - 1);
         const int r = c / CPR, cc = c % CPR;
         const int t = min(t0 + r, N - 1);
-        *reinterpret_cast<u32x4*>(lds + r * HD + cc * 8) =
+        *reinterpret_cast<u32x4*>(lds + r * PITCH + cc * 8) =
             *reinterpret_cast<const u32x4*>(g + row0_off + (long)t * st_ld + cc * 8);
     }
 }
@@ -55,13 +55,17 @@ __device__ __forceinline__ void stage_tile(bf16_t* lds, const bf16_t* g, long ld
 // ------------------------------------------------------------------------------------------- forward
 // DROP: attention-weight dropout compiled in (only the group encoder layer uses it; the timm blocks never do, and merely carrying
 // the masked path changed the register allocation of the 26-token kernel: 5.7 -> 8.3 us per launch)
+constexpr int fwd_pitch(int HD) { return HD + 8; }
+
 template <int HD, bool SPLIT, bool SEG = false, bool DROP = false>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
-    bf16_t* ldsV = reinterpret_cast<bf16_t*>(smem) + wave * (NPL * 32 * HD);
+    // tile rows are padded by 16 bytes: 16-byte row-fragment reads of 32 different rows and the transposed reads stay conflict-free
+    constexpr int PITCH = fwd_pitch(HD);
+    bf16_t* ldsV = reinterpret_cast<bf16_t*>(smem) + wave * (NPL * 32 * PITCH);
 
     const int QT = (p.N + 31) / 32;
     const long W = (long)p.Bb * p.H * QT;
@@ -77,14 +81,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     const bool qok = qrow < p.N;
     const int qrow_c = min(qrow, p.N - 1);
 
+    // Q and K row fragments pass through this wave's tile space (coalesced loads, then 16-byte LDS reads) instead of being gathered from
+    // memory with every lane on its own row (32 rows per load instruction: the slowest thing the texture-address path does, DESIGN.md
+    // section 6); the LDS operations of one wave stay in order, so the V tile can follow into the same space.
     bf16x8 qh[NS], ql[SPLIT ? NS : 1];
+    const int fo = l31 * PITCH + h2 * 8;
     {
-        const long off = base + (long)qrow_c * st_ld + h2 * 8;
+        stage_tile<HD, PITCH>(ldsV, p.qkv_hi, p.ld, base, st_ld, q0, p.N, lane);
+        if constexpr (SPLIT) stage_tile<HD, PITCH>(ldsV + 32 * PITCH, p.qkv_lo, p.ld, base, st_ld, q0, p.N, lane);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            qh[s] = ld_frag(p.qkv_hi + off + 16 * s);
-            if constexpr (SPLIT) ql[s] = ld_frag(p.qkv_lo + off + 16 * s);
+            U128 t;
+            t.u = *reinterpret_cast<const u32x4*>(ldsV + fo + 16 * s); qh[s] = t.v;
+            if constexpr (SPLIT) { t.u = *reinterpret_cast<const u32x4*>(ldsV + 32 * PITCH + fo + 16 * s); ql[s] = t.v; }
         }
+        __builtin_amdgcn_wave_barrier();
     }
     f32x16 o[NDB];
 #pragma unroll
@@ -97,24 +109,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     for (int kt = 0; kt < KT; ++kt) {
         const int k0 = kt * 32;
         __syncthreads();                                          // previous tile's LDS reads are done
-        stage_tile<HD>(ldsV, p.qkv_hi, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
-        if constexpr (SPLIT) stage_tile<HD>(ldsV + 32 * HD, p.qkv_lo, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
-
-        const int krow = min(k0 + l31, p.N - 1);
-        const long koff = base + p.D + (long)krow * st_ld + h2 * 8;
+        stage_tile<HD, PITCH>(ldsV, p.qkv_hi, p.ld, base + p.D, st_ld, k0, p.N, lane);                       // K first ...
+        if constexpr (SPLIT) stage_tile<HD, PITCH>(ldsV + 32 * PITCH, p.qkv_lo, p.ld, base + p.D, st_ld, k0, p.N, lane);
+        __builtin_amdgcn_wave_barrier();
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const bf16x8 kh = ld_frag(p.qkv_hi + koff + 16 * s);
+            U128 kh, kl;
+            kh.u = *reinterpret_cast<const u32x4*>(ldsV + fo + 16 * s);
             if constexpr (SPLIT) {
-                const bf16x8 kl = ld_frag(p.qkv_lo + koff + 16 * s);
-                sacc = MFMA32(kl, qh[s], sacc);
-                sacc = MFMA32(kh, ql[s], sacc);
+                kl.u = *reinterpret_cast<const u32x4*>(ldsV + 32 * PITCH + fo + 16 * s);
+                sacc = MFMA32(kl.v, qh[s], sacc);
+                sacc = MFMA32(kh.v, ql[s], sacc);
             }
-            sacc = MFMA32(kh, qh[s], sacc);
+            sacc = MFMA32(kh.v, qh[s], sacc);
         }
+        __builtin_amdgcn_wave_barrier();
+        stage_tile<HD, PITCH>(ldsV, p.qkv_hi, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);                   // ... then V into the same space
+        if constexpr (SPLIT) stage_tile<HD, PITCH>(ldsV + 32 * PITCH, p.qkv_lo, p.ld, base + 2 * p.D, st_ld, k0, p.N, lane);
         float sv[16], mloc = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -160,8 +174,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
             bf16x8 vh[2], vl[2];
-            if constexpr (SPLIT) gather_frag_2x2<HD>(ldsV, d * 32 + l31, ldsV + 32 * HD, d * 32 + l31, h2, vh, vl);
-            else gather_frag_s2<HD>(ldsV, h2, d * 32 + l31, vh);
+            if constexpr (SPLIT) gather_frag_2x2<HD, PITCH>(ldsV, d * 32 + l31, ldsV + 32 * PITCH, d * 32 + l31, h2, vh, vl);
+            else gather_frag_s2<HD, PITCH>(ldsV, h2, d * 32 + l31, vh);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 if constexpr (SPLIT) {
@@ -905,6 +919,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
 // microseconds of launch ramp and memory latency around a handful of MFMAs.  Here one wave does both for its (batch, head):
 // phase A = the dQ kernel's body (lane = query; also yields delta), phase B = the dK/dV kernel's body (lane = key), with
 // delta / lse handed over through LDS instead of a global round trip.
+constexpr int small_bwd_wave_lds(int HD) { return 3 * 32 * (HD + 8) * 2 + 256; }
+
 template <int HD, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, const AdamFill fill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -917,13 +933,16 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
     // gradients are accumulated two d-blocks at a time; three waves (49 KB of tiles each) share a CU
     constexpr int NDBC = NDB <= 3 ? NDB : 2;
     static_assert(NDB % NDBC == 0, "d-blocks split evenly");
-    constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;                    // K | Q | dO tiles (bf16) + delta / lse (fp32)
+    // tile rows are padded by 16 bytes: the row fragments below are 16-byte reads of 32 different rows (a pitch of HD * 2 bytes would
+    // put them all on the same banks), and the transposed reads of the gradient GEMMs stay conflict-free
+    constexpr int PITCH = HD + 8;
+    constexpr int WAVE_LDS = small_bwd_wave_lds(HD);                   // K | Q | dO tiles (bf16) + delta / lse (fp32)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
     bf16_t* ldsK = reinterpret_cast<bf16_t*>(smem + wave * WAVE_LDS);
-    bf16_t* ldsQ = ldsK + 32 * HD;
-    bf16_t* ldsDO = ldsQ + 32 * HD;
-    float* ldsR = reinterpret_cast<float*>(ldsDO + 32 * HD);           // [0..31] delta, [32..63] lse
+    bf16_t* ldsQ = ldsK + 32 * PITCH;
+    bf16_t* ldsDO = ldsQ + 32 * PITCH;
+    float* ldsR = reinterpret_cast<float*>(ldsDO + 32 * PITCH);        // [0..31] delta, [32..63] lse
 
     const long W = (long)p.Bb * p.H;
     long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -940,37 +959,37 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
     const long tokrow = (long)b * p.sb + (long)tok * p.st;
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;   // the seed lives on the device
 
-    stage_tile<HD>(ldsK, p.qkv_hi, p.ld, base + p.D, st_ld, 0, p.N, lane);
-    stage_tile<HD>(ldsQ, p.qkv_hi, p.ld, base, st_ld, 0, p.N, lane);
-    stage_tile<HD>(ldsDO, p.dout, p.lddo, dobase, st_lddo, 0, p.N, lane);
-
-    // row-fragments of this lane's token: Q, dO (phase A operands), K, V (phase B operands)
+    // row-fragments of this lane's token: Q, dO (phase A operands), K, V (phase B operands), all out of tiles staged with coalesced
+    // loads (a fragment gathered straight from memory -- every lane its own row, 32 rows per load instruction -- is what the
+    // texture-address path serves slowest: the six gathers per 16 features this kernel used to do cost more than its arithmetic,
+    // DESIGN.md section 6).  V is only ever needed as row fragments: it passes through the K tile's space first (the LDS operations of
+    // a wave stay in order).
     bf16x8 qf[NS], dof[NS], kf[NS], vf[NS];
-    float delta = 0.f;
+    const int lo = l31 * PITCH + h2 * 8;
+    stage_tile<HD, PITCH>(ldsK, p.qkv_hi, p.ld, base + 2 * p.D, st_ld, 0, p.N, lane);
+    stage_tile<HD, PITCH>(ldsQ, p.qkv_hi, p.ld, base, st_ld, 0, p.N, lane);
+    stage_tile<HD, PITCH>(ldsDO, p.dout, p.lddo, dobase, st_lddo, 0, p.N, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        U128 t;
+        t.u = *reinterpret_cast<const u32x4*>(ldsK + lo + 16 * s); vf[s] = t.v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    stage_tile<HD, PITCH>(ldsK, p.qkv_hi, p.ld, base + p.D, st_ld, 0, p.N, lane);
+    __builtin_amdgcn_wave_barrier();
     {
-        const long off = base + (long)tok * st_ld + h2 * 8;
-        const long doff = tokrow * p.lddo + h * HD + h2 * 8;
-        const long ooff = tokrow * p.ldo + h * HD + h2 * 8;
-        const float lo_on = p.out_lo ? 1.f : 0.f;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            qf[s] = ld_frag(p.qkv_hi + off + 16 * s);
-            kf[s] = ld_frag(p.qkv_hi + off + p.D + 16 * s);
-            vf[s] = ld_frag(p.qkv_hi + off + 2 * p.D + 16 * s);
-            dof[s] = ld_frag(p.dout + doff + 16 * s);
-            U128 a, ol, d;
-            a.v = ld_frag(p.out_hi + ooff + 16 * s);
-            ol.v = ld_frag((p.out_lo ? p.out_lo : p.out_hi) + ooff + 16 * s);
-            d.v = dof[s];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) delta += bf2f(d.h[j]) * (bf2f(a.h[j]) + lo_on * bf2f(ol.h[j]));
+            U128 t;
+            t.u = *reinterpret_cast<const u32x4*>(ldsQ + lo + 16 * s); qf[s] = t.v;
+            t.u = *reinterpret_cast<const u32x4*>(ldsK + lo + 16 * s); kf[s] = t.v;
+            t.u = *reinterpret_cast<const u32x4*>(ldsDO + lo + 16 * s); dof[s] = t.v;
         }
-        delta = half_sum(delta);
     }
     const float lse_q = p.lse[(long)bh * p.N + tok];
-    if (h2 == 0) { ldsR[l31] = delta; ldsR[32 + l31] = lse_q; }
-    if (active && tok_ok && h2 == 0 && p.delta) p.delta[(long)bh * p.N + l31] = delta;
-    __syncthreads();                                                   // tiles + delta / lse are staged
+    if (h2 == 0) ldsR[32 + l31] = lse_q;
+    __syncthreads();                                                   // tiles + lse are staged
 
     // ---- phase A: lane = query.  S^T = K . Q^T, dP^T = V . dO^T, dQ^T = K^T . dS^T
     {
@@ -982,17 +1001,28 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
             sacc = MFMA32(kf[s], qf[s], sacc);
             dpacc = MFMA32(vf[s], dof[s], dpacc);
         }
+        // delta[q] = sum_k P[q][k] dP[q][k] (= rowsum(dO * O) in exact arithmetic, with the dropout mask on both): no read of the
+        // forward's output, and the rows of dS sum to zero exactly for the P this backward recomputes
+        float pq[16], delta = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = acc_row(r, h2);
+            pq[r] = (key < p.N && seg_ok<SEG>(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
+            if (p.drop_thr)
+                dpacc[r] = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + min(key, p.N - 1), p.drop_thr) ? dpacc[r] * p.drop_scale : 0.f;
+            delta += pq[r] * dpacc[r];
+        }
+        delta = half_sum(delta);
+        if (h2 == 0) ldsR[l31] = delta;                                // read by this wave's phase B (LDS operations of a wave stay in order)
+        __builtin_amdgcn_wave_barrier();
+        if (active && tok_ok && h2 == 0 && p.delta) p.delta[(long)bh * p.N + l31] = delta;
         U128 dsf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int r = 8 * s2 + j, key = acc_row(r, h2);
-                const float pr = (key < p.N && seg_ok<SEG>(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
-                float dpn = dpacc[r];
-                if (p.drop_thr)
-                    dpn = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + key, p.drop_thr) ? dpn * p.drop_scale : 0.f;
-                dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
+                const int r = 8 * s2 + j;
+                dsf[s2].h[j] = f2bf(pq[r] * (dpacc[r] - delta) * p.scale);
             }
         const long orow = tokrow * p.lddq + h * HD;
 #pragma unroll
@@ -1005,8 +1035,8 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
 #pragma unroll
             for (int d = 0; d < NDBC; d += 2) {
                 bf16x8 k0f[2], k1f[2];
-                if (d + 1 < NDBC) gather_frag_2x2<HD>(ldsK, (d0 + d) * 32 + l31, ldsK, (d0 + d + 1) * 32 + l31, h2, k0f, k1f);
-                else gather_frag_s2<HD>(ldsK, h2, (d0 + d) * 32 + l31, k0f);
+                if (d + 1 < NDBC) gather_frag_2x2<HD, PITCH>(ldsK, (d0 + d) * 32 + l31, ldsK, (d0 + d + 1) * 32 + l31, h2, k0f, k1f);
+                else gather_frag_s2<HD, PITCH>(ldsK, h2, (d0 + d) * 32 + l31, k0f);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     dq[d] = MFMA32(k0f[s2], dsf[s2].v, dq[d]);
@@ -1061,7 +1091,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
                 bf16x8 fo[2], fq[2];
-                gather_frag_2x2<HD>(ldsDO, (d0 + d) * 32 + l31, ldsQ, (d0 + d) * 32 + l31, h2, fo, fq);
+                gather_frag_2x2<HD, PITCH>(ldsDO, (d0 + d) * 32 + l31, ldsQ, (d0 + d) * 32 + l31, h2, fo, fq);
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);
@@ -1172,22 +1202,22 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
     if (a.drop_thr) {                     // the masked variant (no segment packing: dropout sites are long-sequence / test shapes)
         S3D_REQUIRE(!a.seg, "attention_fwd: dropout with packed segments is not built");
         if (split) {
-            set_lds((attn_fwd_kernel<HD, true, false, true>), 4 * 2 * 32 * HD * 2);
-            hipLaunchKernelGGL((attn_fwd_kernel<HD, true, false, true>), grid, dim3(64 * wpb), wpb * 2 * 32 * HD * 2, s, a);
+            set_lds((attn_fwd_kernel<HD, true, false, true>), 4 * 2 * 32 * fwd_pitch(HD) * 2);
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, true, false, true>), grid, dim3(64 * wpb), wpb * 2 * 32 * fwd_pitch(HD) * 2, s, a);
         } else {
-            set_lds((attn_fwd_kernel<HD, false, false, true>), 4 * 32 * HD * 2);
-            hipLaunchKernelGGL((attn_fwd_kernel<HD, false, false, true>), grid, dim3(64 * wpb), wpb * 32 * HD * 2, s, a);
+            set_lds((attn_fwd_kernel<HD, false, false, true>), 4 * 32 * fwd_pitch(HD) * 2);
+            hipLaunchKernelGGL((attn_fwd_kernel<HD, false, false, true>), grid, dim3(64 * wpb), wpb * 32 * fwd_pitch(HD) * 2, s, a);
         }
     } else if (split) {
-        const int lds = wpb * 2 * 32 * HD * 2;
-        set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * HD * 2);
-        set_lds(attn_fwd_kernel<HD, true, true>, 4 * 2 * 32 * HD * 2);
+        const int lds = wpb * 2 * 32 * fwd_pitch(HD) * 2;
+        set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * fwd_pitch(HD) * 2);
+        set_lds(attn_fwd_kernel<HD, true, true>, 4 * 2 * 32 * fwd_pitch(HD) * 2);
         if (a.seg) hipLaunchKernelGGL((attn_fwd_kernel<HD, true, true>), grid, dim3(64 * wpb), lds, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<HD, true>), grid, dim3(64 * wpb), lds, s, a);
     } else {
-        const int lds = wpb * 32 * HD * 2;
-        set_lds(attn_fwd_kernel<HD, false>, 4 * 32 * HD * 2);
-        set_lds(attn_fwd_kernel<HD, false, true>, 4 * 32 * HD * 2);
+        const int lds = wpb * 32 * fwd_pitch(HD) * 2;
+        set_lds(attn_fwd_kernel<HD, false>, 4 * 32 * fwd_pitch(HD) * 2);
+        set_lds(attn_fwd_kernel<HD, false, true>, 4 * 32 * fwd_pitch(HD) * 2);
         if (a.seg) hipLaunchKernelGGL((attn_fwd_kernel<HD, false, true>), grid, dim3(64 * wpb), lds, s, a);
         else hipLaunchKernelGGL((attn_fwd_kernel<HD, false>), grid, dim3(64 * wpb), lds, s, a);
     }
@@ -1204,7 +1234,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
         static const bool no_small = s3d_tune_int("S3D_ATTN_NO_SMALL") >= 0;
         static const bool no_small_big = s3d_tune_int("S3D_ATTN_NO_SMALL_BIG") >= 0;       // hd > 96: back to the two-kernel path
         if (a.N <= 32 && !no_small && (HD <= 96 || !no_small_big)) {
-            constexpr int WAVE_LDS = 3 * 32 * HD * 2 + 256;
+            constexpr int WAVE_LDS = small_bwd_wave_lds(HD);
             constexpr int MAXW = (160 * 1024) / WAVE_LDS >= 4 ? 4 : (160 * 1024) / WAVE_LDS;      // 3 waves per workgroup at hd = 256
             const int w = wpb < MAXW ? wpb : MAXW;
             dim3 gs((unsigned)((W + w - 1) / w));
