@@ -1446,6 +1446,207 @@ static int nt_panel(int M, int N, int BM, int BN) {
     return (M >= 8192 && (N + BN - 1) / BN >= 6) ? 8 : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 split-bf16 forward tile for the long GEMMs of cfg-3 (>= 12 k token rows, k = 768 / 3072): eight waves (2 x 4), each owning
+// 128 x 64 outputs as 8 x 4 MFMA blocks (128 accumulator registers; 239 in all -- a wave of a 512-thread workgroup may use 256).
+// A third fewer operand bytes per flop than the 128x256 tile and twice the MFMAs per barrier.  Measured at 188 160 rows against the
+// sixteen-wave 128x256 kernel (us): qkv 1959 -> 1760, proj 812 -> 774, fc1 2733 -> 2470, fc2 2436 -> 2217; cfg-3 step 298.4 -> 289.8 ms
+// (same box).  In-kernel timeline (tools/run_fat_tl.sh): 4.5 k cycles per k = 32 step against 2.3 k for the last step, which issues
+// no DMA; with the MFMAs removed the launch still takes 70 % of its time, without the DMA 85 %, without the fragment reads 91 % --
+// no single ingredient bounds it, and the shader clock sits at 1.4 - 1.6 GHz while these launches run (power).
+//  * stage = [A_hi][A_lo][B_hi][B_lo], each 256 rows x 64 bytes (k = 32), two buffers = 128 KB; waves 2q, 2q+1 DMA plane q, so a
+//    wave's eight 1 KB pieces differ by a row offset only: one SGPR base + eight 32-bit lane offsets instead of eight pointers;
+//  * a wave's row blocks are interleaved (A block i = tile rows 32 i + 16 wm .., B block j = 64 j + 16 wn ..): the slot swizzle of
+//    a lane is then the same for every block (one LDS address + immediate offsets), and the epilogue can park the tile 32 rows at
+//    a time with every wave contributing -- the fp32 staging tile is 33 KB instead of 266 KB, and a chunk's accumulators are dead
+//    once parked;
+//  * the epilogue operands (residual rows / bias) of chunk c+1 are requested before chunk c is processed.
+__device__ __forceinline__ void glds16_s(unsigned long long sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_dst)
+                 : "memory");
+}
+
+// DBG (tuning build only, wrong results): the k-loop with one ingredient removed -- 1 no MFMAs, 2 no fragment reads, 3 no DMA
+template <int EPI, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm_nt_fat_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 256, BN = 256, BK = 32, NW = 8, NTHR = 512, WN = 4;
+    constexpr int PLANE = 256 * 64, STAGE = 4 * PLANE, PPW = 8;
+    constexpr int FM = 8, FN = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntx = gridDim.x, nty = gridDim.y;
+    {
+        const int ntile = ntx * nty;
+        const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm = tile_id / ntx, tn = tile_id % ntx;                         // panels of PM tile rows (see gemm_nt_dma_kernel)
+    if (const int PM = p.kchunk; PM > 1) {
+        const int per = PM * ntx, pnl = tile_id / per, w = tile_id - pnl * per;
+        const int rows = min(PM, nty - pnl * PM);
+        tm = pnl * PM + w % rows;
+        tn = w / rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int ntiles = p.K / BK;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+
+    // DMA: plane q = wave >> 1, tile rows (wave & 1) * 128 + 16 j + lane / 4, 16-byte chunk lane % 4 (source-side swizzle)
+    const int plane = wave >> 1;
+    const bool isB = plane >= 2;
+    unsigned long long sbase;
+    {
+        const bf16_t* base = plane == 0 ? p.A_hi : plane == 1 ? p.A_lo : plane == 2 ? p.B_hi : p.B_lo;
+        const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+        sbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)b) |
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(b >> 32)) << 32);
+    }
+    unsigned goff[PPW];                                                 // byte offsets (launcher: rows x ld x 2 < 2^32)
+    {
+        const long ld = isB ? p.ldb : p.lda;
+        const int r0 = (wave & 1) * 128 + (lane >> 2), c = lane & 3;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int r = r0 + 16 * j;
+            const int row = isB ? min(n0 + r, p.N - 1) : min(m0 + r, p.M - 1);
+            goff[j] = (unsigned)(((long)row * ld + ((c ^ dma_swz32(r)) << 3)) * 2);
+        }
+    }
+    auto issue = [&](int t) {
+        const unsigned dst = lds0 + (unsigned)((t & 1) * STAGE + wave * PPW * 1024);
+        const unsigned long long sb = sbase + (unsigned long long)t * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) glds16_s(sb, goff[j], dst + j * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addresses: row ra (+ 32 i) of A, row rb (+ 64 j) of B, chunk lane >> 4 at slot chunk ^ swz(row) -- swz(ra + 32 i) = swz(ra)
+    const int ra = wm * 16 + (lane & 15), rb = wn * 16 + (lane & 15), kc = lane >> 4;
+    const int offA = ra * 64 + ((kc ^ dma_swz32(ra)) << 4);
+    const int offB = 2 * PLANE + rb * 64 + ((kc ^ dma_swz32(rb)) << 4);
+
+    // Two buffers, two stages in flight: a stage's fragments are all read into registers first (24 x 16 bytes per lane), a second
+    // barrier releases the buffer, and the eight DMA pieces of stage t + 2 are issued one at a time BETWEEN the MFMA groups of stage t
+    // (a wave sits in the issue stage until the memory pipeline has taken its piece -- ~300 cycles with eight waves issuing; issued as
+    // one burst that is 2.4 k cycles per k-step in which the wave feeds no MFMA: in-kernel timeline, 4.7 k cycles per step against
+    // 2.3 k for the last step, which has nothing to issue).
+    TL_REAL(0); TL_HWID(1); TL_STAMP(2);
+    issue(0);
+    if (ntiles > 1) issue(1);
+    TL_STAMP(3);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");   // stage t landed (t + 1 may be in flight)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // ... for everyone
+        TL_STAMP(8 + t);
+        const unsigned char* sA = smem + (t & 1) * STAGE + offA;
+        const unsigned char* sB = smem + (t & 1) * STAGE + offB;
+        bf16x8 b_hi[FN], b_lo[FN], a_hi[FM], a_lo[FM];
+        if (DBG != 2 || t == 0) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            b_hi[j] = *reinterpret_cast<const bf16x8*>(sB + j * 4096);
+            b_lo[j] = *reinterpret_cast<const bf16x8*>(sB + PLANE + j * 4096);
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            a_hi[i] = *reinterpret_cast<const bf16x8*>(sA + i * 2048);
+            a_lo[i] = *reinterpret_cast<const bf16x8*>(sA + PLANE + i * 2048);
+        }
+        }
+        __syncthreads();                                               // everyone holds its fragments: buffer t & 1 is free
+        const bool pre = t + 2 < ntiles;
+        const unsigned dst = lds0 + (unsigned)((t & 1) * STAGE + wave * PPW * 1024);
+        const unsigned long long sb = sbase + (unsigned long long)(t + 2) * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 c = acc[i][j];
+                if constexpr (DBG == 1) {
+                    c[0] += __builtin_bit_cast(f32x4, b_hi[j])[0] + __builtin_bit_cast(f32x4, a_lo[i])[0] + __builtin_bit_cast(f32x4, b_lo[j])[0] + __builtin_bit_cast(f32x4, a_hi[i])[0];
+                    acc[i][j] = c;
+                    continue;
+                }
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_lo[i], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_lo[j], a_hi[i], c, 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], c, 0, 0, 0);
+            }
+            if (pre && DBG != 3) glds16_s(sb, goff[i], dst + i * 1024);
+            __builtin_amdgcn_sched_barrier(0);                         // keep the piece where it was placed
+        }
+    }
+    TL_STAMP(4);
+
+    // epilogue: 32 tile rows at a time through a [32][BN + 4] fp32 staging tile (rows 32 c + 16 wm + (lane & 15) of every wave)
+    using SE = StagedEpilogue<EPI, 32, BN, NTHR>;
+    constexpr int LDC = BN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+    SE se[2];
+    se[0].prefetch(p, m0, n0, tid);
+#pragma unroll
+    for (int c = 0; c < FM; ++c) {
+        __syncthreads();                                               // k-loop / previous chunk done with the staging tile
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+            *reinterpret_cast<f32x4*>(ct + (wm * 16 + (lane & 15)) * LDC + j * 64 + wn * 16 + (lane >> 4) * 4) = acc[c][j];
+        if (c + 1 < FM) se[(c + 1) & 1].prefetch(p, m0 + (c + 1) * 32, n0, tid);
+        __syncthreads();
+        se[c & 1].run(p, ct, m0 + c * 32, n0, tid);
+    }
+#ifdef S3D_TIMELINE
+    TL_STAMP(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL_STAMP(6); TL_REAL(7);
+#endif
+}
+
+template <int EPI>
+int launch_nt_fat(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    a.kchunk = nt_panel(a.M, a.N, 256, 256);
+    constexpr int LDS = 2 * 4 * 256 * 64;
+    auto kern = gemm_nt_fat_kernel<EPI>;
+#ifdef S3D_EXPERIMENTAL_TILES       // k-loop with one ingredient removed (wrong results): S3D_FAT_DBG = 1 no MFMAs, 2 no fragment reads, 3 no DMA
+    static const int dbg = env_int("S3D_FAT_DBG");
+    if (dbg == 1) kern = gemm_nt_fat_kernel<EPI, 1>;
+    if (dbg == 2) kern = gemm_nt_fat_kernel<EPI, 2>;
+    if (dbg == 3) kern = gemm_nt_fat_kernel<EPI, 3>;
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid(a.N / 256, (a.M + 255) / 256, 1);
+    constexpr long long KEY = 300000000000LL + 256 * 100000000LL + 256 * 100000LL + 100 + EPI;
+    if (g_skip_key == KEY) return 0;
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = KEY;
+        sl.flops = 2.0 * a.M * a.N * a.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+    }
+    S3D_CHECK_LAUNCH_V("gemm_nt_fat", KEY);
+    return 0;
+}
+
 // the forward DMA kernel on the small cfg-2 tiles (k = 64 stages)
 template <bool SPLIT, int EPI, int BM, int BN, int NS, int WM = 2, int WN = 2, int ILV = 0, int BK = 64>
 int launch_nt_dma_small(const GemmArgs& a_in, hipStream_t stream) {
@@ -1604,6 +1805,16 @@ int launch_nt_epi(int tile, const GemmArgs& a, hipStream_t s) {
         if (fat != 0 && dma != 0 && tile == 2 && a.M >= long_rows() && a.K >= fat_mink && (a.K & 31) == 0 && (a.N & 255) == 0 &&
             (long)((a.M + 127) / 128) * (a.N / 256) >= 512)
         {
+            // 256x256 tile, eight waves (gemm_nt_fat_kernel; byte offsets are 32-bit there) when its workgroups fill >= 85 % of the
+            // rounds they occupy on 256 CUs.  Measured against the 128x256 tile: 188 160 rows -10 / -5 / -10 / -9 % (qkv / proj / fc1 /
+            // fc2: 6615 .. 2205 tiles); 12 608 rows qkv -15 % (450 tiles = 0.88 of two rounds), the others +-2 %; 32 768 rows proj +14 %,
+            // fc2 +9 % (384 tiles = 0.75 of two rounds)
+            if constexpr (EPI == EPI_BF16_BIAS || EPI == EPI_GELU || EPI == EPI_RESID) {
+                const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), slots = (t256 + 255) / 256 * 256;
+                if (fat != 1 && fat != 2 && t256 * 100 >= slots * 85 && (long)a.M * a.lda * 2 < (1L << 32) &&
+                    (long)a.N * a.ldb * 2 < (1L << 32))
+                    return launch_nt_fat<EPI>(a, s);
+            }
             // sixteen waves on 64x32 sub-tiles (76 - 90 registers): 0.5 % ahead of eight waves on 64x64 (140 - 164) in the cfg-3 step
             if (fat == 1) return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 4, 0, 32>(a, s);
             return launch_nt_dma_small<SPLIT, EPI, 128, 256, 3, 2, 8, 0, 32>(a, s);

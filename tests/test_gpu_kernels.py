@@ -275,6 +275,34 @@ def test_gemm_epilogues_gelu_resid_token_dgelu(M, N, K):
     assert rms_err(o.float(), (dyh.double() @ w2h.double()) * (aux.double() > 0)) < 1e-2
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(14200, 2304, 768, 'BF16_BIAS'),      # 56 x 9 tiles of 256x256 (ragged last row tile)
+                                       (10700, 3072, 768, 'GELU'),           # 42 x 12
+                                       (21700, 768, 768, 'RESID'),           # 85 x 3: attn.proj
+                                       (21760, 768, 3072, 'RESID')])         # mlp.fc2 (96 k-steps)
+def test_gemm_fat_forward_tile(M, N, K, epi):
+    """gemm_nt_fat_kernel (256x256 split-bf16 tile, eight waves; what the pass-1 Linear layers of cfg-3 dispatch): every output against
+    the fp64 product of the SAME operand planes (hi + lo, minus the lo x lo term the three-MFMA product drops), every epilogue plane."""
+    g = torch.Generator().manual_seed(M + N)
+    ah, al = ops.split_bf16(torch.randn(M, K, generator=g).to(DEV))
+    bh, bl = ops.split_bf16((torch.randn(N, K, generator=g) * K ** -0.5).to(DEV))
+    bias = torch.randn(N, generator=g).to(DEV)
+    R = torch.randn(M, N, generator=g).to(DEV)
+    C = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+    oh = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV); ol = oh.clone(); aux = oh.clone()
+    ops.gemm(0, 0, 1, epi, A_hi=ah, A_lo=al, lda=K, B_hi=bh, B_lo=bl, ldb=K, M=M, N=N, K=K, bias=bias, R=R, ldr=N, C=C, ldc=N,
+             O_hi=oh, O_lo=ol, ldo=N, aux=aux, ldaux=N)
+    ref = (ah.double() + al.double()) @ (bh.double() + bl.double()).t() - al.double() @ bl.double().t() + bias.double()
+    if epi == 'RESID':
+        assert rel_err(C, ref + R.double()) < 1e-6
+        assert rel_err(oh.float() + ol.float(), C.double()) < 2e-5              # the optional split copy of the residual stream
+    elif epi == 'BF16_BIAS':
+        assert rel_err(oh.float() + ol.float(), ref) < 2e-5
+    else:
+        assert rel_err(oh.float() + ol.float(), F.gelu(ref)) < 2e-5
+        assert float((aux.double() - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8
+    del ref
+
+
 @pytest.mark.parametrize('rows,D', [(7, 192), (1664, 384), (333, 768), (40000, 192), (9, 256), (64, 1024), (5000, 512)])
 def test_layernorm_fwd_bwd(rows, D):
     g = torch.Generator().manual_seed(5)

@@ -27,7 +27,7 @@ def planes(r, c):
 
 
 def run(name, N, K, epi, tile, cold):
-    bm, bn = TILES[tile]
+    bm, bn = {'1': (128, 256), '2': (128, 256), '3': (256, 256)}.get(os.environ.get('S3D_GEMM_NT_FAT', ''), TILES[tile]) if tile == 2 and M >= 8192 else TILES[tile]
     nwg = ((M + bm - 1) // bm) * ((N + bn - 1) // bn)
     ah, al = planes(M, K); bh, bl = planes(N, K)
     bias = torch.randn(N, device=DEV)
@@ -84,6 +84,11 @@ def run(name, N, K, epi, tile, cold):
           f'(x{nk - 1})  last compute {f3(tail)}  epilogue issue {f3(epi_issue)}  store ack {f3(ack)}  total {f3(total)}')
     if nk > 1:
         print('    k-step medians:', ' '.join(f'{np.median(ksteps[:, i]):.0f}' for i in range(nk - 1)))
+    if t[:, 32].any():         # fat tile: inside k-step 4 -- landed barrier, fragments read, release barrier, MFMA block / DMA piece 0, 1, 7
+        names = ['frags read', 'release barrier', 'mfma blk0 issued', 'dma piece0 issued', 'mfma blk1 issued', 'dma piece1 issued', 'mfma blk7 issued', 'dma piece7 issued']
+        base = t[:, 8 + 4]
+        print('    inside k-step 4 (cycles after the landed barrier, p50):', '  '.join(f'{n} {np.median(t[:, 32 + i] - base):.0f}' for i, n in enumerate(names)),
+              f'  next landed barrier {np.median(t[:, 8 + 5] - base):.0f}')
     early = start < np.percentile(start, 30)
     late = start > np.percentile(start, 70)
     print(f'    early WGs (first 30%): total p50 {np.median(total[early]):.0f} cyc; late WGs (last 30%): total p50 {np.median(total[late]):.0f} cyc')
