@@ -68,6 +68,7 @@ if __name__ == '__main__':
     M = int(os.environ.get('M', '94080'))
     for name, N, K, epi in [('qkv', 2304, 768, 'BF16_BIAS'), ('proj', 768, 768, 'RESID'), ('fc1', 3072, 768, 'GELU'), ('fc2', 768, 3072, 'RESID')]:
         f = setup(M, N, K)
-        us = timeit(lambda: ops.gemm(0, 0, 1, epi, **f))
+        for _ in range(int(os.environ.get('LOOPS', '1'))):
+            us = timeit(lambda: ops.gemm(0, 0, 1, epi, **f))
         print(f'{name:5s} M={M} N={N:5d} K={K:5d}  {us:9.1f} us  {2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s(alg)', flush=True)
     print('worst err', w)
