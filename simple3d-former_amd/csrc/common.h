@@ -94,7 +94,22 @@ __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
     return copysignf(1.0f - erf_poly(ax, __expf(-ax * ax)), x);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752f)); }
+// gelu(x) = x Phi(x) = max(x, 0) - |x| h with h = erfc(|x| / sqrt 2) / 2 = 2^R(|x|): R = log2 of it, a degree-7 minimax fit on
+// |x| <= 4 sqrt 2 (weighted for the absolute error of h; beyond that h < 8e-9).  ONE transcendental (v_exp_f32 is base 2 already) + 7 FMAs
+// instead of exp + rcp + 8: the erf-GELU epilogues (cfg-3 fc1: 30 k of a 256 x 256 tile's 148 k cycles) are VALU-bound, and a
+// transcendental costs four issue slots.  Max abs error against fp64 erf-GELU over [-12, 12]: 3.8e-7 (the A&S 7.1.26 form: 4.6e-7).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float ax = fminf(fabsf(x), 5.656854249f);
+    float r = 8.469293712e-06f;
+    r = fmaf(r, ax, -5.389662502e-05f);
+    r = fmaf(r, ax, -4.212578507e-04f);
+    r = fmaf(r, ax, 7.389304524e-03f);
+    r = fmaf(r, ax, -5.269113505e-02f);
+    r = fmaf(r, ax, -4.591531407e-01f);
+    r = fmaf(r, ax, -1.151110944e+00f);
+    r = fmaf(r, ax, -9.999998964e-01f);
+    return fmaf(-fabsf(x), __builtin_amdgcn_exp2f(r), fmaxf(x, 0.f));
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float z = x * 0.70710678118654752f, az = fabsf(z);
     const float e = __expf(-az * az);                                    // = exp(-x^2 / 2): erf's exponential AND the normal density's
