@@ -178,6 +178,11 @@ typedef struct S3dAttnArgs {
      * (qkv_lo, dout_lo, out_lo required), evaluates the backward in fp32 and stores d(qkv) as the pair dqkv / dqkv_lo.  Slow reference
      * kernels, any N / head dim / layout; delta is still written. */
     const uint16_t* dout_lo; uint16_t* dqkv_lo;
+    /* optional 1-bit copy of the attention-weight dropout mask for LONG sequences (the cooperative kernels: N >= 192, head dim < 256;
+     * ignored otherwise): [Bb*H][ceil(N/32)][ceil(N/32)][32] words, word q of tile (query tile, key tile) = keep bits of the tile's 32
+     * keys for query row q.  s3d_attention_fwd writes it while it evaluates the hash, s3d_attention_bwd (given the SAME buffer, seed and
+     * shape) reads it instead of evaluating the hash twice more.  NULL: every kernel evaluates the hash. */
+    unsigned int* drop_mask;
 } S3dAttnArgs;
 int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
 int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);
@@ -450,6 +455,7 @@ typedef struct S3dEncActs {      /* M = G*Nb rows */
     uint16_t *xin_hi, *xin_lo, *qkv_hi, *qkv_lo, *att_hi, *att_lo, *x1_hi, *x1_lo;
     uint16_t *fpre, *f_hi, *f_lo;                  /* [M][Dff] */
     uint16_t* fpre_lo;                             /* optional: low plane of fpre (split-precision backward, see S3dBlockScratch::dx_a_lo) */
+    unsigned int* attn_mask;                       /* optional: S3dAttnArgs::drop_mask of the layer's attention, Nb*H * ceil(G/32)^2 * 32 words */
 } S3dEncActs;
 int s3d_encoder_layer_fwd(const S3dEncShape* shape, const S3dEncParams* params, const S3dEncActs* acts,
                           s3d_stream_t stream);

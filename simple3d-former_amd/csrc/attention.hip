@@ -17,6 +17,7 @@
 
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT, CPR = HD / 8;
     constexpr int PITCH = HD + 8;                                      // 16-byte pad: conflict-free ds_read_b128 of a column of rows
-    constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256;                // Q | dO tiles + lse / delta
+    constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256 + NWV * 128;    // Q | dO tiles + lse / delta + the waves' dropout-mask words
     constexpr int NCH = (32 * CPR + NTHR - 1) / NTHR;                        // 16-byte chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -490,7 +491,11 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
 
     u32x4 rq[NCH], rd[NCH];
     float rr = 0.f;
+    uint32_t rm = 0u;
+    // S3dAttnArgs::drop_mask: the 32 words (one per query row) of tile (query tile, THIS wave's key tile), staged with the query tile
+    const unsigned int* mwave = p.drop_mask ? p.drop_mask + ((long)bh * QT * KT + kt) * 32 + l31 : nullptr;
     auto gload = [&](int q0) {
+        if (mwave && h2 == 0) rm = mwave[(long)(q0 >> 5) * KT * 32];
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = min(tid + NTHR * i, 32 * CPR - 1);
@@ -517,6 +522,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             }
         }
         if (tid < 64) reinterpret_cast<float*>(dO + 32 * PITCH)[tid] = rr;
+        if (mwave && h2 == 0) reinterpret_cast<uint32_t*>(dO + 32 * PITCH)[64 + wave * 32 + l31] = rm;
     };
 
     gload(0);
@@ -547,26 +553,36 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             del4[g] = *reinterpret_cast<const f32x4*>(ldsR + 32 + 8 * g + 4 * h2);
         }
         U128 pf[2], dsf[2];
+        auto p_ds_tile = [&](auto from_mask) {                         // the mask from the stored bits (block-uniform choice) or from the hash
+            u32x4 mw4[4];                                              // the words of this lane's 16 query rows (four runs of four, like lse4)
+            if constexpr (decltype(from_mask)::value) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                float pv[2], dv2[2];
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int r = 8 * s2 + j + e, qr = acc_row(r, h2);
-                    const int q = q0 + qr;
-                    // columns of keys >= N are never stored, so only the ragged last QUERY tile needs a select (clamped rows would count twice)
-                    float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
-                    if (q0 + 32 > p.N) pr = (q < p.N) ? pr : 0.f;
-                    float dm = 1.f;     // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
-                    if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)q * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
-                    pv[e] = pr * dm;
-                    dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
-                }
-                pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
-                dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
+                for (int g = 0; g < 4; ++g) mw4[g] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ldsR) + 64 + wave * 32 + 8 * g + 4 * h2);
             }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    float pv[2], dv2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 8 * s2 + j + e, qr = acc_row(r, h2);
+                        const int q = q0 + qr;
+                        // columns of keys >= N are never stored, so only the ragged last QUERY tile needs a select (clamped rows would count twice)
+                        float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
+                        if (q0 + 32 > p.N) pr = (q < p.N) ? pr : 0.f;
+                        float dm = 1.f; // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
+                        if constexpr (decltype(from_mask)::value) dm = ((mw4[r >> 2][r & 3] >> l31) & 1u) ? p.drop_scale : 0.f;
+                        else if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)q * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
+                        pv[e] = pr * dm;
+                        dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
+                    }
+                    pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
+                    dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
+                }
+        };
+        if (mwave) p_ds_tile(std::true_type{});
+        else p_ds_tile(std::false_type{});
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
             const int col = (dblk0 + d) * 32 + l31;
@@ -736,9 +752,19 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
         l_i = l_i * alpha + lsum;
         m_i = mnew;
         if (DROP && p.drop_thr) {                                 // DROP = false: the masked path is compiled out (hd = 256 spilled with it)
+            uint32_t wb = 0u;                                     // keep bits of this lane's 16 keys, bit = acc_row(r, 0)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                sv[r] = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const bool keep = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr);
+                sv[r] = keep ? sv[r] * p.drop_scale : 0.f;
+                wb |= keep ? (1u << acc_row(r, 0)) : 0u;
+            }
+            // S3dAttnArgs::drop_mask: the query's word of tile (qt, kt) = the two half-waves' bits (keys 4 h2 + ..), for the backward kernels
+            if (p.drop_mask) {                                    // block-uniform
+                wb <<= 4 * h2;
+                const auto pr = __builtin_amdgcn_permlane32_swap(wb, wb, false, false);
+                if (active && h2 == 0) p.drop_mask[(((long)bh * QT + qt) * KT + kt) * 32 + l31] = pr[0] | pr[1];
+            }
         }
         // rescale the running output only when some row's maximum moved (wave-uniform test): after the first few key tiles of a long
         // sequence it almost never does, and alpha == 1 exactly for every row then (6 x 16 multiplies per tile at hd = 192)
@@ -847,6 +873,9 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
     const bf16_t* src[2] = {p.qkv_hi, p.qkv_hi};
     long rowoff[2] = {base + p.D, base + 2 * (long)p.D}, pitch[2] = {st_ld, st_ld};
     const int KT = (p.N + 31) / 32;
+    // S3dAttnArgs::drop_mask: this query's word of tile (qt, kt), fetched one key tile ahead
+    const unsigned int* mrow = p.drop_mask ? p.drop_mask + ((long)bh * QT + qt) * KT * 32 + l31 : nullptr;
+    uint32_t wnext = mrow ? mrow[0] : 0u;
     st.gload(src, rowoff, pitch, 0, p.N, tid);
     st.lstore(smem, tid);
     __syncthreads();
@@ -854,6 +883,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
         const int k0 = kt * 32;
         const bool more = kt + 1 < KT;
         if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
+        const uint32_t wcur = wnext >> (4 * h2);                       // bit acc_row(r, 0) = key acc_row(r, h2)
+        if (mrow && more) wnext = mrow[(long)(kt + 1) * 32];
         const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
         const bf16_t* ldsV = ldsK + TILE;
         const bool ragged = k0 + 32 > p.N;
@@ -868,22 +899,27 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
             dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsV + off), dof[s], dpacc);   // dP^T = V . dO^T
         }
         U128 dsf[2];
+        auto ds_tile = [&](auto from_mask) {                           // the mask from the stored bits (block-uniform choice) or from the hash
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                float dsv[2];
+                for (int j = 0; j < 8; j += 2) {
+                    float dsv[2];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int r = 8 * s2 + j + e;
-                    float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse2));            // exp(S * scale - lse), one fma + v_exp
-                    if (ragged) pr = (k0 + acc_row(r, h2)) < p.N ? pr : 0.f;                 // last key tile only (wave-uniform)
-                    float dpn = dpacc[r];
-                    if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
-                    dsv[e] = pr * (dpn - delta) * p.scale;
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 8 * s2 + j + e;
+                        float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse2));        // exp(S * scale - lse), one fma + v_exp
+                        if (ragged) pr = (k0 + acc_row(r, h2)) < p.N ? pr : 0.f;             // last key tile only (wave-uniform)
+                        float dpn = dpacc[r];
+                        if constexpr (decltype(from_mask)::value) dpn = ((wcur >> acc_row(r, 0)) & 1u) ? dpn * p.drop_scale : 0.f;
+                        else if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                        dsv[e] = pr * (dpn - delta) * p.scale;
+                    }
+                    dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
                 }
-                dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
-            }
+        };
+        if (mrow) ds_tile(std::true_type{});
+        else ds_tile(std::false_type{});
 #pragma unroll
         for (int d = 0; d < NDB; d += 2) {
             bf16x8 k0[2], k1[2];
@@ -1151,8 +1187,15 @@ static int coop_waves() {
     return w;
 }
 
+// S3dAttnArgs::drop_mask is honoured where BOTH passes run the cooperative kernels (the forward does not at hd = 256); everywhere else
+// every kernel evaluates the hash, whatever the caller passed
 template <int HD>
-int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
+static bool mask_ok(const AttnArgs& a) { return HD < 256 && a.drop_thr != 0 && a.drop_mask != nullptr && use_coop(a.N) && a.N > 32; }
+
+template <int HD>
+int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
+    AttnArgs a = a_in;
+    if (!mask_ok<HD>(a)) a.drop_mask = nullptr;
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     // (not at hd = 256: the cooperative forward needs 540 registers there -- 28 B of scratch per lane with, 152 B with the dropout
     // mask -- and its only user, the 197-token second pass of group_embed, is 0.1 % of the cfg-3 step on the per-wave kernel)
@@ -1194,7 +1237,7 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
                 hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 4, false>), g, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + (split ? 10 : 0) + (a.drop_thr ? 1 : 0));
+        S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + (split ? 10 : 0) + (a.drop_thr ? 1 : 0) + (a.drop_mask ? 2 : 0));
         return 0;
     }
     const int wpb = waves_per_block(W);
@@ -1226,7 +1269,9 @@ int fwd_hd(const AttnArgs& a, bool split, hipStream_t s) {
 }
 
 template <int HD, int DSPLIT>
-int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
+int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
+    AttnArgs a = a_in;
+    if (!mask_ok<HD>(a)) a.drop_mask = nullptr;
     const long W = (long)a.Bb * a.H * ((a.N + 31) / 32);
     const int wpb = waves_per_block(W);
     dim3 grid((unsigned)((W + wpb - 1) / wpb));
@@ -1264,7 +1309,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD);
+        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0));
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
@@ -1274,7 +1319,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
         S3D_CHECK_LAUNCH_V("attention_bwd_dq", HD * 10 + (a.seg ? 1 : 0));
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
-        const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256);
+        const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256 + (S3D_COOP8(HD) ? 8 : 4) * 128);
 #ifdef S3D_EXPERIMENTAL_TILES
         if (S3D_COOP8(HD)) {
             set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), lds);
@@ -1287,7 +1332,7 @@ int bwd_hd(const AttnArgs& a, hipStream_t s, AdamFillQueue* fillq) {
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 10 + DSPLIT);
+        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0));
     } else {
         // the per-wave kernel splits the d range in two from hd = 192 on (one half = 252 registers + 60 B of scratch there)
         constexpr int DS = HD >= 192 ? 2 : DSPLIT;

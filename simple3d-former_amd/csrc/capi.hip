@@ -390,6 +390,7 @@ int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, h
     at.ldo = D; at.lse = a.lse; at.Bb = sh.Nb; at.H = sh.H; at.N = sh.G; at.D = D; at.sb = 1; at.st = sh.Nb;
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     SET_DROP(at, 0);
+    at.drop_mask = a.attn_mask;
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
     g = gemm_zero();                                // s1 = x + drop(att @ Wo^T + bo)
     g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.out_w_hi; g.B_lo = p.out_w_lo; g.ldb = D;
@@ -471,6 +472,7 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
     at.dout = w.datt; at.lddo = D; at.dqkv = w.dqkv; at.lddq = 3 * D; at.delta = w.delta;
     if (sp) { at.dout_lo = w.datt_lo; at.dqkv_lo = w.dqkv_lo; }
     SET_DROP(at, 0);
+    at.drop_mask = sp ? nullptr : a.attn_mask;     // (the split-precision reference kernels evaluate the hash)
     S3D_TRY(s3d_launch_attention_bwd(at, s));
     S3D_TRY(wgrad_x(w.dqkv, w.dqkv_lo, 3 * D, a.xin_hi, a.xin_lo, D, gr.in_w, gr.in_b));
     g = gemm_zero();                                // dx = dqkv @ Win + ds1           -> dx_b (+bf16 copy)

@@ -430,6 +430,16 @@ class VoxelEngine:
         for ws in self._ws.values():
             if self.group:
                 ws.enc.shape.dropout_p = self.dropout_p
+                self._ensure_attn_mask(ws)
+
+    def _ensure_attn_mask(self, ws):
+        """S3dEncActs::attn_mask: one bit per attention weight of the seq-first encoder layer, written by the forward while it evaluates
+        the dropout hash and read by the two backward kernels (long sequences only: the cooperative kernels, G >= 192)."""
+        e = ws.enc
+        if self.dropout_p > 0 and ws.G >= 192 and getattr(e, 'attn_mask', None) is None and os.environ.get('S3D_NO_ATTN_MASK') != '1':   # (A/B knob)
+            t = (ws.G + 31) // 32
+            e.attn_mask = torch.zeros(self.ntok * self.enc_heads * t * t * 32 + 256, dtype=torch.int32, device=self.device)
+            e.acts.attn_mask = e.attn_mask.data_ptr()
 
     def advance_dropout_seed(self):
         """Fresh dropout masks for the next forward: one device-side increment (graph-replay safe).  Every path that trains calls
@@ -478,6 +488,7 @@ class VoxelEngine:
             e.shape = L.S3dEncShape(G=G, Nb=self.ntok, D=D, H=self.enc_heads, Dff=D, eps=1e-5, split=1 if self.split else 0,
                                     dropout_p=self.dropout_p, seed=self.dropout_seed.data_ptr())
             ws.enc = e
+            self._ensure_attn_mask(ws)
             ws.gstats = torch.empty(2, G, **f32)              # final-norm statistics of the pass-1 cls rows
             ws.gfeat = torch.empty(G, D, **f32)               # norm(x)[:, 0] of pass 1  -> tokens of pass 2
             ws.dgfeat = torch.empty(G, D, **f32)

@@ -80,24 +80,24 @@ def _drop_fields(drop):
     return dict(drop_seed=seed, drop_site=int(site), drop_thr=int(p * 4294967296.0), drop_scale=1.0 / (1.0 - p))
 
 
-def attention_fwd(qkv_hi, qkv_lo, Bb, H, N, D, sb, st, split=True, seg=0, drop=None):
+def attention_fwd(qkv_hi, qkv_lo, Bb, H, N, D, sb, st, split=True, seg=0, drop=None, drop_mask=None):
     rows = qkv_hi.shape[0]
     out_hi = torch.zeros(rows, D, dtype=torch.bfloat16, device=qkv_hi.device)
     out_lo = torch.zeros_like(out_hi)
     lse = torch.zeros(Bb * H * N, dtype=torch.float32, device=qkv_hi.device)
     a = L.fill(L.S3dAttnArgs(), qkv_hi=_dev(qkv_hi), qkv_lo=_dev(qkv_lo), ld=3 * D, out_hi=out_hi, out_lo=out_lo, ldo=D,
-               lse=lse, Bb=Bb, H=H, N=N, D=D, sb=sb, st=st, scale=float((D // H) ** -0.5), seg=seg, **_drop_fields(drop))
+               lse=lse, Bb=Bb, H=H, N=N, D=D, sb=sb, st=st, scale=float((D // H) ** -0.5), seg=seg, drop_mask=drop_mask, **_drop_fields(drop))
     L.check(L.lib().s3d_attention_fwd(ctypes.byref(a), 1 if split else 0, L.current_stream()), 'attention_fwd')
     return out_hi, out_lo, lse
 
 
-def attention_bwd(qkv_hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, seg=0, drop=None):
+def attention_bwd(qkv_hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, seg=0, drop=None, drop_mask=None):
     rows = qkv_hi.shape[0]
     dqkv = torch.zeros(rows, 3 * D, dtype=torch.bfloat16, device=qkv_hi.device)
     delta = torch.zeros(Bb * H * N, dtype=torch.float32, device=qkv_hi.device)
     a = L.fill(L.S3dAttnArgs(), qkv_hi=_dev(qkv_hi), ld=3 * D, out_hi=_dev(out_hi), out_lo=out_lo, ldo=D, lse=lse, Bb=Bb,
                H=H, N=N, D=D, sb=sb, st=st, scale=float((D // H) ** -0.5), dout=_dev(dout), lddo=D, dqkv=dqkv,
-               lddq=3 * D, delta=delta, seg=seg, **_drop_fields(drop))
+               lddq=3 * D, delta=delta, seg=seg, drop_mask=drop_mask, **_drop_fields(drop))
     L.check(L.lib().s3d_attention_bwd(ctypes.byref(a), L.current_stream()), 'attention_bwd')
     return dqkv
 

@@ -390,10 +390,12 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
         assert e < 2e-2, f'd{name} rms err {e:.3e}'
 
 
-@pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(3, 4, 300, 192, True),      # cooperative long-sequence kernels (>= 6 query tiles)
-                                                (2, 3, 197, 256, False), (4, 6, 26, 64, False), (3, 4, 100, 192, True),
-                                                (3, 3, 27, 256, False), (2, 4, 30, 192, True)])     # single-launch backward at hd = 192 / 256
-def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first):
+@pytest.mark.parametrize('Bb,H,N,hd,seq_first,stored', [(3, 4, 300, 192, True, False),      # cooperative long-sequence kernels (>= 6 query tiles)
+                                                       (3, 4, 300, 192, True, True),       # ... with the forward's 1-bit mask handed to the backward
+                                                       (2, 3, 333, 64, False, True), (2, 3, 197, 256, False, True),    # (hd = 256: mask ignored)
+                                                       (2, 3, 197, 256, False, False), (4, 6, 26, 64, False, False), (3, 4, 100, 192, True, False),
+                                                       (3, 3, 27, 256, False, False), (2, 4, 30, 192, True, False)])     # single-launch backward at hd = 192 / 256
+def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first, stored):
     """Dropout on the attention weights (site 0 of nn.TransformerEncoderLayer): P' = softmax(S) * keep / (1 - p) with the
     counter-based mask of oracle.voxel_oracle.hash_keep_mask over the [Bb*H, N, N] index space -- forward and backward of every
     kernel family (per-wave, single-launch small, cooperative) against autograd on exactly that mask."""
@@ -405,8 +407,22 @@ def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first):
     hi, lo = ops.split_bf16(qkv)
     seed = torch.tensor([seed_v], dtype=torch.int64, device=DEV)
     drop = (p, seed, site)
-    out_hi, out_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, sb, st, split=True, drop=drop)
-    keep = vo.hash_keep_mask((Bb, H, N, N), seed_v, site, p).to(DEV).double() / (1.0 - p)
+    T = (N + 31) // 32
+    mbuf = torch.full((Bb * H, T, T, 32), 0x5A5A5A5A, dtype=torch.int32, device=DEV) if stored else None   # S3dAttnArgs::drop_mask
+    out_hi, out_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, sb, st, split=True, drop=drop, drop_mask=mbuf)
+    keep01 = vo.hash_keep_mask((Bb, H, N, N), seed_v, site, p).to(DEV)
+    keep = keep01.double() / (1.0 - p)
+    if stored and hd < 256:            # the stored bits ARE the oracle's mask: word q of tile (qt, kt), bit = key within the tile
+        pad = torch.zeros(Bb * H, T * 32, T * 32, dtype=torch.int64, device=DEV)
+        pad[:, :N, :N] = keep01.reshape(Bb * H, N, N).long()
+        want = (pad.view(Bb * H, T, 32, T, 32) << torch.arange(32, device=DEV)).sum(-1).permute(0, 1, 3, 2)       # [bh][qt][kt][q]
+        got_w = mbuf.long() & 0xFFFFFFFF
+        valid_k = (torch.arange(T * 32, device=DEV) < N).view(T, 32).long()
+        kmask = (valid_k << torch.arange(32, device=DEV)).sum(-1)                                                  # bits of keys < N, per key tile
+        qvalid = (torch.arange(T * 32, device=DEV) < N).view(T, 1, 32)
+        assert bool((((got_w ^ want) & kmask.view(1, 1, T, 1)) * qvalid.long()).eq(0).all()), 'stored mask bits differ from the oracle mask'
+    elif stored:
+        assert bool((mbuf == 0x5A5A5A5A).all())        # hd = 256: the forward is not a cooperative kernel, the buffer is not touched
 
     def to_b(t):
         return t.view(N, Bb, -1).transpose(0, 1) if seq_first else t.view(Bb, N, -1)
@@ -421,7 +437,9 @@ def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first):
     e = rel_err(got, ref.detach())
     assert e < 1e-4, f'fwd rel err {e:.3e} (a wrong mask gives ~0.3)'
     dout = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
-    dqkv = ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop)
+    dqkv = ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop, drop_mask=mbuf)
+    if stored:                         # bit-identical to the backward that evaluates the hash
+        assert torch.equal(dqkv, ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop))
     xb = to_b(hi.double()).requires_grad_(True)
     ref_attn(xb).backward(to_b(dout.double()).reshape(Bb, N, H, hd).transpose(1, 2))
     gotd = to_b(dqkv.float())
