@@ -540,7 +540,9 @@ def main():
     global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE, PMC_TRAFFIC_FILE
     conf = CONFIGS[args.config]
     if args.config != 'cfg2':
-        PMC_TRAFFIC_FILE = f'profiles/r03_pmc_{args.config}_traffic.json'     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh
+        PMC_TRAFFIC_FILE = f'profiles/r04_pmc_{args.config}_traffic.json'     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh
+        if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)):
+            PMC_TRAFFIC_FILE = f'profiles/r03_pmc_{args.config}_traffic.json'
     CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
 
     import torch.distributed as dist
