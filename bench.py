@@ -89,6 +89,8 @@ def kernel_name(key):
         return f'gemm_pair_kernel<dgrad {b0}x64 NN {epi} || wgrad {b1}x64 TN atomic>'
     if kind == 6:
         return f'gemm_pair_dmat_kernel<dgrad {b0}x{b1} NN {epi} || wgrad {b0}x{b1} TN atomic; LDS-DMA + transpose reads>'
+    if kind == 3 and b0 == 256 and b1 == 256:
+        return f'gemm_nt_fat_kernel<256,256,NT,split3,{epi}> (eight waves)'
     if kind == 3:
         return f'gemm_nt_dma_kernel<{b0},{b1},NT,{"split3" if sp else "bf16"},{epi}>'
     if kind == 4:
@@ -107,6 +109,8 @@ def rocprof_name(key):
         return f'gemm_pair_kernel<{b0}, {epi}, {b1}>'
     if kind == 6:
         return f'gemm_pair_dmat_kernel<{epi}, 3>'
+    if kind == 3 and b0 == 256 and b1 == 256:
+        return f'gemm_nt_fat_kernel<{epi}, 0>'
     if kind == 3:
         return f'gemm_nt_dma_kernel<{tf(sp)}, {epi}, {3 if b1 == 256 else 2}, {32 if (sp and b0 == 128) else 64}, {b0}, {b1}>'     # 128x256: three-stage ring
     if kind == 4:

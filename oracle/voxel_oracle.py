@@ -124,12 +124,17 @@ def run_blocks(x, sd, depth, num_heads, bf16=False):
 
 
 # ----------------------------------------------------------------------------- group_embed
-def hash_keep_mask(shape, seed, site, p):
+def hash_keep_mask(shape, seed, site, p, pair_keys=None):
     """Counter-based dropout mask shared with the HIP kernels (common.h: drop_key / drop_mix32 / drop_keep): element i (row-major
     linear index) is kept iff mix32((lo(i) ^ (lo(key) * 0x9E3779B9)) + (mix32(hi(i) ^ hi(key)) ^ lo(key))) >= floor(p * 2^32), with
     key = seed * 0x9E3779B97F4A7C15 + site * 0xD1B54A32D192ED03 + 0x632BE59BD9B4E019 (mod 2^64) and mix32 two rounds of
-    xor-shift / multiply."""
+    xor-shift / multiply.
+    pair_keys (default: site == 0, the attention weights [.., query, key]): ONE hash per pair of adjacent keys (2j, 2j + 1) of a query
+    row -- the hash of the even key's element index -- and 16 bits of it per decision (low half: even key), compared with
+    floor(p * 2^32) >> 16 (common.h: drop_keep_attn / drop_half)."""
     import numpy as np
+    if pair_keys is None:
+        pair_keys = site == 0
     n = 1
     for d in shape:
         n *= int(d)
@@ -144,9 +149,17 @@ def hash_keep_mask(shape, seed, site, p):
 
     with np.errstate(over='ignore'):
         idx = np.arange(n, dtype=np.uint64)
+        odd = None
+        if pair_keys:
+            odd = (idx % np.uint64(int(shape[-1]))) & np.uint64(1)    # parity of the key index
+            idx = idx - odd                                            # the pair's even key
         lo, hi = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32), (idx >> np.uint64(32)).astype(np.uint32)
         h = mix32(hi ^ key_hi) ^ key_lo
         z = mix32((lo ^ (key_lo * np.uint32(0x9E3779B9))) + h)     # the key is NOT just an additive offset: no shifted-copy masks
+    if pair_keys:
+        half = np.where(odd == 1, z >> np.uint32(16), z & np.uint32(0xFFFF)).astype(np.uint64)
+        keep = half >= np.uint64(thr >> 16)
+        return torch.from_numpy(keep.reshape(tuple(shape)))
     keep = z.astype(np.uint64) >= np.uint64(thr)
     return torch.from_numpy(keep.reshape(tuple(shape)))
 

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
             const unsigned long long rowbase = ((unsigned long long)bh * p.N + min(qrow, p.N - 1)) * p.N;
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                sv[r] = drop_keep(key, rowbase + (k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
+                sv[r] = drop_keep_attn(key, rowbase, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? sv[r] * p.drop_scale : 0.f;
         }
         // rescale the running output only when some row's maximum moved (wave-uniform test): after the first few key tiles of a long
         // sequence it almost never does, and alpha == 1 exactly for every row then (6 x 16 multiplies per tile at hd = 192)
@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
                 float dpn = dpacc[r];
                 if (p.drop_thr)
-                    dpn = drop_keep(drop_key(p.drop_seed, p.drop_site),
-                                    ((unsigned long long)bh * p.N + qrow_c) * p.N + (k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                    dpn = drop_keep_attn(drop_key(p.drop_seed, p.drop_site), ((unsigned long long)bh * p.N + qrow_c) * p.N,
+                                         (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
                 dsf[s2].h[j] = f2bf(pr * (dpn - delta) * p.scale);
             }
         __syncthreads();
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - lse_r) : 0.f;
                 float dm = 1.f;
                 if (p.drop_thr)
-                    dm = drop_keep(drop_key(p.drop_seed, p.drop_site), ((unsigned long long)bh * p.N + qc) * p.N + krow_c, p.drop_thr)
+                    dm = drop_keep_attn(drop_key(p.drop_seed, p.drop_site), ((unsigned long long)bh * p.N + qc) * p.N, (uint32_t)krow_c, p.drop_thr)
                              ? p.drop_scale : 0.f;
                 pf[s2].h[j] = f2bf(pr * dm);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - del_r) * p.scale);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
     const float sc2 = p.scale * 1.4426950408889634f;                  // scores -> log2 units (lse is staged pre-scaled)
     const int krow_c = min(krow, p.N - 1);
     const unsigned long long dkey = p.drop_thr ? drop_key(p.drop_seed, p.drop_site) : 0ull;
-    const DropRow dcol = drop_row(dkey, (unsigned long long)bh * p.N * p.N + krow_c);        // mask index = column base + q * N
+    const DropRow dcol = drop_row(dkey, (unsigned long long)bh * p.N * p.N + (krow_c & ~1));  // hash index = (even key of the pair) + q * N
 
     bf16x8 kf[NS], vf[NS];
     {
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                         if (q0 + 32 > p.N) pr = (q < p.N) ? pr : 0.f;
                         float dm = 1.f; // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
                         if constexpr (decltype(from_mask)::value) dm = ((mw4[r >> 2][r & 3] >> l31) & 1u) ? p.drop_scale : 0.f;
-                        else if (p.drop_thr) dm = drop_keep_at(dcol, (uint32_t)q * (uint32_t)p.N, p.drop_thr) ? p.drop_scale : 0.f;
+                        else if (p.drop_thr) dm = drop_half(drop_hash_at(dcol, (uint32_t)q * (uint32_t)p.N), (uint32_t)krow_c & 1u, p.drop_thr) ? p.drop_scale : 0.f;
                         pv[e] = pr * dm;
                         dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
                     }
@@ -754,10 +754,12 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
         if (DROP && p.drop_thr) {                                 // DROP = false: the masked path is compiled out (hd = 256 spilled with it)
             uint32_t wb = 0u;                                     // keep bits of this lane's 16 keys, bit = acc_row(r, 0)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const bool keep = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr);
-                sv[r] = keep ? sv[r] * p.drop_scale : 0.f;
-                wb |= keep ? (1u << acc_row(r, 0)) : 0u;
+            for (int r = 0; r < 16; r += 2) {                        // keys acc_row(r, h2) (even) and + 1: one hash, 16 bits each
+                const uint32_t z = drop_hash_at(drow, (uint32_t)(k0 + acc_row(r, h2)));
+                const bool keep0 = drop_half(z, 0u, p.drop_thr), keep1 = drop_half(z, 1u, p.drop_thr);
+                sv[r] = keep0 ? sv[r] * p.drop_scale : 0.f;
+                sv[r + 1] = keep1 ? sv[r + 1] * p.drop_scale : 0.f;
+                wb |= (keep0 ? (1u << acc_row(r, 0)) : 0u) | (keep1 ? (1u << acc_row(r + 1, 0)) : 0u);
             }
             // S3dAttnArgs::drop_mask: the query's word of tile (qt, kt) = the two half-waves' bits (keys 4 h2 + ..), for the backward kernels
             if (p.drop_mask) {                                    // block-uniform
@@ -912,7 +914,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
                         if (ragged) pr = (k0 + acc_row(r, h2)) < p.N ? pr : 0.f;             // last key tile only (wave-uniform)
                         float dpn = dpacc[r];
                         if constexpr (decltype(from_mask)::value) dpn = ((wcur >> acc_row(r, 0)) & 1u) ? dpn * p.drop_scale : 0.f;
-                        else if (p.drop_thr) dpn = drop_keep_at(drow, (uint32_t)(k0 + acc_row(r, h2)), p.drop_thr) ? dpn * p.drop_scale : 0.f;
+                        else if (p.drop_thr) dpn = drop_half(drop_hash_at(drow, (uint32_t)(k0 + (acc_row(r, h2) & ~1))), (uint32_t)r & 1u, p.drop_thr) ? dpn * p.drop_scale : 0.f;
                         dsv[e] = pr * (dpn - delta) * p.scale;
                     }
                     dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
@@ -1045,7 +1047,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
             const int key = acc_row(r, h2);
             pq[r] = (key < p.N && seg_ok<SEG>(p, tok, key)) ? fast_exp(sacc[r] * p.scale - lse_q) : 0.f;
             if (p.drop_thr)
-                dpacc[r] = drop_keep(dkey, ((unsigned long long)bh * p.N + tok) * p.N + min(key, p.N - 1), p.drop_thr) ? dpacc[r] * p.drop_scale : 0.f;
+                dpacc[r] = drop_keep_attn(dkey, ((unsigned long long)bh * p.N + tok) * p.N, (uint32_t)min(key, p.N - 1), p.drop_thr) ? dpacc[r] * p.drop_scale : 0.f;
             delta += pq[r] * dpacc[r];
         }
         delta = half_sum(delta);
@@ -1114,7 +1116,7 @@ __global__ __launch_bounds__(256) void attn_bwd_small_kernel(const AttnArgs p, c
                 const int qc = min(q, p.N - 1);
                 const float pr = ok ? fast_exp(sacc[r] * p.scale - ldsR[32 + qc]) : 0.f;
                 float dm = 1.f;
-                if (p.drop_thr) dm = drop_keep(dkey, ((unsigned long long)bh * p.N + qc) * p.N + tok, p.drop_thr) ? p.drop_scale : 0.f;
+                if (p.drop_thr) dm = drop_keep_attn(dkey, ((unsigned long long)bh * p.N + qc) * p.N, (uint32_t)tok, p.drop_thr) ? p.drop_scale : 0.f;
                 pf[s2].h[j] = f2bf(pr * dm);
                 dsf[s2].h[j] = f2bf(pr * (dpacc[r] * dm - ldsR[qc]) * p.scale);
             }
@@ -1394,7 +1396,7 @@ __global__ __launch_bounds__(256) void attn_bwd_ref_kernel(const AttnArgs p) {
         }
         float pr = expf(sc * p.scale - p.lse[bh * p.N + i]);
         float dm = 1.f;
-        if (p.drop_thr) dm = drop_keep(dkey, ((unsigned long long)bh * p.N + i) * p.N + j, p.drop_thr) ? p.drop_scale : 0.f;
+        if (p.drop_thr) dm = drop_keep_attn(dkey, ((unsigned long long)bh * p.N + i) * p.N, (uint32_t)j, p.drop_thr) ? p.drop_scale : 0.f;
         const float ds = pr * (dp * dm - delta) * p.scale;
         if (KEY_SIDE) {
 #pragma unroll

@@ -137,10 +137,18 @@ __device__ __forceinline__ uint32_t drop_mix32(uint32_t x) {
 // masks of two seeds / sites / ranks are shifted copies of one 2^32-periodic sequence (mask_k'(i) == mask_k(i + delta)), and windows of
 // ~1.5e8 elements from different steps overlap with a probability of a few per cent.  Same instruction count (the xor replaces nothing
 // on the hoisted path: lo ^ klo is formed once per row in DropRow).
-__device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long long idx, unsigned thr) {
+__device__ __forceinline__ uint32_t drop_hash(unsigned long long key, unsigned long long idx) {
     const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
     const uint32_t hi = drop_mix32((uint32_t)(idx >> 32) ^ khi) ^ klo;   // changes every 2^32 elements
-    return drop_mix32(((uint32_t)idx ^ (klo * 0x9E3779B9u)) + hi) >= thr;   // lowbias32 avalanches consecutive integers by itself
+    return drop_mix32(((uint32_t)idx ^ (klo * 0x9E3779B9u)) + hi);       // lowbias32 avalanches consecutive integers by itself
+}
+__device__ __forceinline__ bool drop_keep(unsigned long long key, unsigned long long idx, unsigned thr) { return drop_hash(key, idx) >= thr; }
+// Attention weights (site 0 of the encoder layer, [b, h, query, key]): ONE hash per pair of adjacent keys (2j, 2j + 1) of a query row --
+// the hash of the even key's index -- and 16 bits of it per decision (low half: even key).  The long-sequence forward evaluates it
+// for 9.4e9 weights per step and holds a pair in the same lane; p is resolved to 2^-16 (0.1 -> 6553 / 65536).
+__device__ __forceinline__ bool drop_half(uint32_t z, uint32_t odd, unsigned thr) { return (odd ? (z >> 16) : (z & 0xffffu)) >= (thr >> 16); }
+__device__ __forceinline__ bool drop_keep_attn(unsigned long long key, unsigned long long rowbase, uint32_t k, unsigned thr) {
+    return drop_half(drop_hash(key, rowbase + (k & ~1u)), k & 1u, thr);
 }
 
 // The same mask for element (base + off), off < 2^32, with the 64-bit part hoisted: the long-sequence attention kernels evaluate the
@@ -150,10 +158,11 @@ __device__ __forceinline__ DropRow drop_row(unsigned long long key, unsigned lon
     const uint32_t hi = (uint32_t)(base >> 32), khi = (uint32_t)(key >> 32), klo = (uint32_t)key;
     return DropRow{(uint32_t)base, drop_mix32(hi ^ khi) ^ klo, drop_mix32((hi + 1u) ^ khi) ^ klo, klo * 0x9E3779B9u};
 }
-__device__ __forceinline__ bool drop_keep_at(const DropRow& r, uint32_t off, unsigned thr) {
+__device__ __forceinline__ uint32_t drop_hash_at(const DropRow& r, uint32_t off) {
     const uint32_t lo = r.lo + off;
-    return drop_mix32((lo ^ r.kx) + (lo < r.lo ? r.mix_b : r.mix_a)) >= thr;           // lo < r.lo: the add carried into the high word
+    return drop_mix32((lo ^ r.kx) + (lo < r.lo ? r.mix_b : r.mix_a));                  // lo < r.lo: the add carried into the high word
 }
+__device__ __forceinline__ bool drop_keep_at(const DropRow& r, uint32_t off, unsigned thr) { return drop_hash_at(r, off) >= thr; }
 
 // fp32 atomic add that lowers to global_atomic_add_f32 (built with -munsafe-fp-atomics)
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
