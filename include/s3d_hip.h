@@ -167,7 +167,8 @@ typedef struct S3dAttnArgs {
     const uint16_t* dout; long lddo;
     uint16_t* dqkv; long lddq;
     float* delta;
-    /* optional dropout on the attention weights, index ((b*H + h)*N + q)*N + key, see S3dGemmArgs */
+    /* optional dropout on the attention weights, index ((b*H + h)*N + q)*N + key (one hash per pair of adjacent keys, 16 bits each:
+     * csrc/common.h drop_keep_attn), see S3dGemmArgs */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
     /* block-diagonal attention: 0 = off; otherwise a query attends only to the keys of its own segment of `seg` consecutive
      * tokens (needs seg <= N <= 2*seg and N <= 32).  The launchers use it themselves to put TWO short sequences (N <= 16,
@@ -433,7 +434,8 @@ int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, con
  * (G = B*P*P groups, Nb = P+1 tokens per group) self-attention runs over the G axis for each of the Nb positions, i.e.
  * ACROSS the samples of the batch; ReLU feed-forward D -> Dff -> D; LayerNorm eps 1e-5.  Rows are r = g*Nb + t.
  * Dropout (p = 0.1, four sites: attention weights, after out_proj, after the ReLU, after linear2) uses a counter-based
- * hash mask keep = splitmix64(index, seed, site) >= p*2^32 (torch's RNG stream cannot be reproduced); dropout_p = 0 gives
+ * hash mask keep = mix32(index, seed, site) >= p*2^32 -- for the attention weights (site 0) one hash per pair of adjacent keys, 16 bits
+ * per decision; csrc/common.h drop_keep / drop_keep_attn == oracle.voxel_oracle.hash_keep_mask (torch's RNG stream cannot be reproduced); dropout_p = 0 gives
  * the eval-mode layer. */
 typedef struct S3dEncShape {
     int G, Nb, D, H, Dff;

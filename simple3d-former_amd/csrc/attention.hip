@@ -443,13 +443,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 // arithmetic), every operand of the MFMAs comes from LDS (row fragments by ds_read_b128 on a padded pitch, transposed fragments
 // by transpose reads), and there is one barrier per tile: a quarter of the staging traffic, no global fragment loads, and the
 // load latency hidden behind the previous tile.
-template <int HD, int DSPLIT, int NWV = 4>
+// MASK: the instantiation that reads S3dAttnArgs::drop_mask (kept apart: its extra state took the hd = 64 kernel of the point path from
+// 128 to 136 registers = three waves per SIMD instead of four, 59.6 -> 91.8 us)
+template <int HD, int DSPLIT, int NWV = 4, bool MASK = false>
 __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnArgs p) {
     constexpr int NTHR = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = ((HD + 31) / 32) / DSPLIT, CPR = HD / 8;
     constexpr int PITCH = HD + 8;                                      // 16-byte pad: conflict-free ds_read_b128 of a column of rows
-    constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256 + NWV * 128;    // Q | dO tiles + lse / delta + the waves' dropout-mask words
+    constexpr int BUF_BYTES = 2 * 32 * PITCH * 2 + 256 + (MASK ? NWV * 128 : 0);   // Q | dO tiles + lse / delta [+ the waves' dropout-mask words]
     constexpr int NCH = (32 * CPR + NTHR - 1) / NTHR;                        // 16-byte chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -491,11 +493,11 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
 
     u32x4 rq[NCH], rd[NCH];
     float rr = 0.f;
-    uint32_t rm = 0u;
+    [[maybe_unused]] uint32_t rm = 0u;
     // S3dAttnArgs::drop_mask: the 32 words (one per query row) of tile (query tile, THIS wave's key tile), staged with the query tile
-    const unsigned int* mwave = p.drop_mask ? p.drop_mask + ((long)bh * QT * KT + kt) * 32 + l31 : nullptr;
+    [[maybe_unused]] const unsigned int* mwave = MASK ? p.drop_mask + ((long)bh * QT * KT + kt) * 32 + l31 : nullptr;
     auto gload = [&](int q0) {
-        if (mwave && h2 == 0) rm = mwave[(long)(q0 >> 5) * KT * 32];
+        if constexpr (MASK) { if (h2 == 0) rm = mwave[(long)(q0 >> 5) * KT * 32]; }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = min(tid + NTHR * i, 32 * CPR - 1);
@@ -522,7 +524,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             }
         }
         if (tid < 64) reinterpret_cast<float*>(dO + 32 * PITCH)[tid] = rr;
-        if (mwave && h2 == 0) reinterpret_cast<uint32_t*>(dO + 32 * PITCH)[64 + wave * 32 + l31] = rm;
+        if constexpr (MASK) { if (h2 == 0) reinterpret_cast<uint32_t*>(dO + 32 * PITCH)[64 + wave * 32 + l31] = rm; }
     };
 
     gload(0);
@@ -553,12 +555,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             del4[g] = *reinterpret_cast<const f32x4*>(ldsR + 32 + 8 * g + 4 * h2);
         }
         U128 pf[2], dsf[2];
-        auto p_ds_tile = [&](auto from_mask) {                         // the mask from the stored bits (block-uniform choice) or from the hash
-            u32x4 mw4[4];                                              // the words of this lane's 16 query rows (four runs of four, like lse4)
-            if constexpr (decltype(from_mask)::value) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) mw4[g] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ldsR) + 64 + wave * 32 + 8 * g + 4 * h2);
-            }
+        if constexpr (!MASK) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -572,17 +569,35 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                         float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
                         if (q0 + 32 > p.N) pr = (q < p.N) ? pr : 0.f;
                         float dm = 1.f; // rows q >= N: pr = 0 kills both products, so the mask index needs no clamp (keeps q * N linear in r)
-                        if constexpr (decltype(from_mask)::value) dm = ((mw4[r >> 2][r & 3] >> l31) & 1u) ? p.drop_scale : 0.f;
-                        else if (p.drop_thr) dm = drop_half(drop_hash_at(dcol, (uint32_t)q * (uint32_t)p.N), (uint32_t)krow_c & 1u, p.drop_thr) ? p.drop_scale : 0.f;
+                        if (p.drop_thr) dm = drop_half(drop_hash_at(dcol, (uint32_t)q * (uint32_t)p.N), (uint32_t)krow_c & 1u, p.drop_thr) ? p.drop_scale : 0.f;
                         pv[e] = pr * dm;
                         dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
                     }
                     pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
                     dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
                 }
-        };
-        if (mwave) p_ds_tile(std::true_type{});
-        else p_ds_tile(std::false_type{});
+        } else {                                                       // the mask from the bits the forward stored
+            u32x4 mw4[4];                                              // the words of this lane's 16 query rows (four runs of four, like lse4)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) mw4[g] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint32_t*>(ldsR) + 64 + wave * 32 + 8 * g + 4 * h2);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    float pv[2], dv2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int r = 8 * s2 + j + e;
+                        float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
+                        if (q0 + 32 > p.N) pr = (q0 + acc_row(r, h2) < p.N) ? pr : 0.f;
+                        const float dm = ((mw4[r >> 2][r & 3] >> l31) & 1u) ? p.drop_scale : 0.f;
+                        pv[e] = pr * dm;
+                        dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
+                    }
+                    pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
+                    dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
+                }
+        }
 #pragma unroll
         for (int d = 0; d < NDB; ++d) {
             const int col = (dblk0 + d) * 32 + l31;
@@ -818,7 +833,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
     }
 }
 
-template <int HD, int NWV = 4>
+template <int HD, int NWV = 4, bool MASK = false>                   // MASK: see attn_bwd_dkv_coop_kernel
 __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
@@ -876,8 +891,9 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
     long rowoff[2] = {base + p.D, base + 2 * (long)p.D}, pitch[2] = {st_ld, st_ld};
     const int KT = (p.N + 31) / 32;
     // S3dAttnArgs::drop_mask: this query's word of tile (qt, kt), fetched one key tile ahead
-    const unsigned int* mrow = p.drop_mask ? p.drop_mask + ((long)bh * QT + qt) * KT * 32 + l31 : nullptr;
-    uint32_t wnext = mrow ? mrow[0] : 0u;
+    const unsigned int* mrow = MASK ? p.drop_mask + ((long)bh * QT + qt) * KT * 32 + l31 : nullptr;
+    uint32_t wnext = 0u;
+    if constexpr (MASK) wnext = mrow[0];
     st.gload(src, rowoff, pitch, 0, p.N, tid);
     st.lstore(smem, tid);
     __syncthreads();
@@ -886,7 +902,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
         const bool more = kt + 1 < KT;
         if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
         const uint32_t wcur = wnext >> (4 * h2);                       // bit acc_row(r, 0) = key acc_row(r, h2)
-        if (mrow && more) wnext = mrow[(long)(kt + 1) * 32];
+        if constexpr (MASK) { if (more) wnext = mrow[(long)(kt + 1) * 32]; }
         const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
         const bf16_t* ldsV = ldsK + TILE;
         const bool ragged = k0 + 32 > p.N;
@@ -920,8 +936,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
                     dsf[s2].w[j / 2] = f2bf2(dsv[0], dsv[1]);
                 }
         };
-        if (mrow) ds_tile(std::true_type{});
-        else ds_tile(std::false_type{});
+        ds_tile(std::integral_constant<bool, MASK>{});
 #pragma unroll
         for (int d = 0; d < NDB; d += 2) {
             bf16x8 k0[2], k1[2];
@@ -1307,9 +1322,17 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
         } else
 #endif
         {
-            set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
-            hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
+            if constexpr (HD < 256) {
+                if (a.drop_mask) {
+                    set_lds((attn_bwd_dq_coop_kernel<HD, 4, true>), lds);
+                    hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 4, true>), g, dim3(256), lds, s, a);
+                }
+            }
+            if (!a.drop_mask) {
+                set_lds(attn_bwd_dq_coop_kernel<HD>, lds);
+                hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
+            }
         }
         S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0));
     } else {
@@ -1321,7 +1344,7 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
         S3D_CHECK_LAUNCH_V("attention_bwd_dq", HD * 10 + (a.seg ? 1 : 0));
     }
     if (use_coop(a.N)) {          // long sequences: four key tiles share one query stream
-        const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256 + (S3D_COOP8(HD) ? 8 : 4) * 128);
+        const int lds = 2 * (2 * 32 * (HD + 8) * 2 + 256 + (a.drop_mask ? 4 * 128 : 0));
 #ifdef S3D_EXPERIMENTAL_TILES
         if (S3D_COOP8(HD)) {
             set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), lds);
@@ -1330,9 +1353,17 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
         } else
 #endif
         {
-            set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
-            hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+            if constexpr (HD < 256) {
+                if (a.drop_mask) {
+                    set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true>), lds);
+                    hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true>), g2, dim3(256), lds, s, a);
+                }
+            }
+            if (!a.drop_mask) {
+                set_lds(attn_bwd_dkv_coop_kernel<HD, DSPLIT>, lds);
+                hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
+            }
         }
         S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0));
     } else {
