@@ -93,6 +93,8 @@ def kernel_name(key):
         return f'gemm_nt_fat_kernel<256,256,NT,split3,{epi}> (eight waves)'
     if kind == 3:
         return f'gemm_nt_dma_kernel<{b0},{b1},NT,{"split3" if sp else "bf16"},{epi}>'
+    if kind == 4 and b0 == 256 and b1 == 256:
+        return f'gemm_nn_fat_kernel<256,256,{lay},bf16,{epi}> (eight waves)'
     if kind == 4:
         return f'gemm_dmat_kernel<{b0},{b1},{lay},bf16,{epi}>'
     return f'gemm_kernel<{b0},{b1},{lay},{"split3" if sp else "bf16"},{epi}>'
@@ -113,6 +115,8 @@ def rocprof_name(key):
         return f'gemm_nt_fat_kernel<{epi}, 0>'
     if kind == 3:
         return f'gemm_nt_dma_kernel<{tf(sp)}, {epi}, {3 if b1 == 256 else 2}, {32 if (sp and b0 == 128) else 64}, {b0}, {b1}>'     # 128x256: three-stage ring
+    if kind == 4 and b0 == 256 and b1 == 256:
+        return f'gemm_nn_fat_kernel<{epi}>'
     if kind == 4:
         return f'gemm_dmat_kernel<{tf(ta)}, {tf(tb)}, {epi}, {2 if b0 == 128 else 3}, {b0}, {b1}>'
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'

@@ -1356,6 +1356,127 @@ __global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 256x256 plain-bf16 dgrad tile (NN: A = dy [M][K] k-contiguous, B = W [K][N] k-major) for the long backward GEMMs of cfg-3, the
+// counterpart of gemm_nt_fat_kernel: eight waves (2 x 4) of 128 x 64 outputs, two 64 KB stages of k = 64 (A 256 rows x 128 bytes,
+// B 64 k-rows x 512 bytes read back transposed with ds_read_b64_tr_b16), the epilogue staged 32 rows at a time.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BM = 256, BN = 256, NTHR = 512, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = 64 * BN * 2, STAGE = A_BYTES + B_BYTES, PPW = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    int tile_id = blockIdx.y * gridDim.x + blockIdx.x;
+    const int ntx = gridDim.x;
+    {
+        const int ntile = ntx * gridDim.y;
+        const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    const int ntiles = p.K >> 6;                                       // K % 64 == 0 (launcher)
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+
+    // DMA pieces: waves 0 - 3 the A tile (8 rows x 8 slots per piece), waves 4 - 7 the B tile (2 k-rows x 32 slots per piece)
+    const bf16_t* gp[PPW];
+    const bool isB = wave >= 4;
+    const long gstep = isB ? 64 * p.ldb : 64;                          // elements per k-tile
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = (wave & 3) * PPW + j;
+        if (isB) {
+            const int r = q * 2 + (lane >> 5), c = lane & 31;
+            const int cg = c ^ kmajor_swz<BN>(r);
+            gp[j] = p.B_hi + (long)r * p.ldb + min(n0 + cg * 8, p.N - 8);
+        } else {
+            const int r = q * 8 + (lane >> 3), c = lane & 7;
+            gp[j] = p.A_hi + (long)min(m0 + r, p.M - 1) * p.lda + ((c ^ dma_swz64(r)) << 3);
+        }
+    }
+    auto issue = [&](int t) {
+        const unsigned dst = lds0 + (unsigned)((t & 1) * STAGE + wave * PPW * 1024);
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) glds16(gp[j] + (long)t * gstep, dst + j * 1024);
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(0);
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // stage t (the only one in flight) has landed for this wave
+        __syncthreads();                                               // ... for everyone; nobody reads stage t - 1 any more
+        if (t + 1 < ntiles) issue(t + 1);
+        const unsigned char* sA = smem + (t & 1) * STAGE;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a_hi[FM], b_hi[FN];
+            const int kq8 = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) a_hi[i] = read_frag_dma(sA, wm * TM + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+            frags_kmajor<BN, FN>(sB, wn * TN, kq8, lane, b_hi);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // epilogue: 32 tile rows at a time (the rows of wave row wm = c / 4, blocks 2 (c % 4) and + 1) through a [32][BN + 4] staging tile
+    using SE = StagedEpilogue<EPI, 32, BN, NTHR>;
+    constexpr int LDC = BN + 4;
+    float* ct = reinterpret_cast<float*>(smem);
+    SE se[2];
+    se[0].prefetch(p, m0, n0, tid);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        __syncthreads();                                               // k-loop / previous chunk done with the staging tile
+        if (wm == c / 4) {                                             // wave-uniform
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *reinterpret_cast<f32x4*>(ct + (h * 16 + (lane & 15)) * LDC + wn * TN + j * 16 + (lane >> 4) * 4) = acc[2 * (c % 4) + h][j];
+        }
+        if (c + 1 < 8) se[(c + 1) & 1].prefetch(p, m0 + (c + 1) * 32, n0, tid);
+        __syncthreads();
+        se[c & 1].run(p, ct, m0 + c * 32, n0, tid);
+    }
+}
+
+template <int EPI>
+int launch_nn_fat(const GemmArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * (256 * 128 + 64 * 256 * 2);
+    auto kern = gemm_nn_fat_kernel<EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid(a.N / 256, (a.M + 255) / 256, 1);
+    constexpr long long KEY = 400000000000LL + 256 * 100000000LL + 256 * 100000LL + 1000 + EPI;       // 4 | 256 | 256 | NN | EPI
+    if (g_skip_key == KEY) return 0;
+    if (g_prof_on) {
+        ProfSlot sl;
+        sl.key = KEY;
+        sl.flops = 2.0 * a.M * a.N * a.K;
+        (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
+        (void)hipEventRecord(sl.e0, stream);
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+        (void)hipEventRecord(sl.e1, stream);
+        g_prof.push_back(sl);
+    } else {
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+    }
+    S3D_CHECK_LAUNCH_V("gemm_nn_fat", KEY);
+    return 0;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool SPLIT, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2156,7 +2277,20 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
         }
         // long dgrads with a short reduction (k = output width <= 1024: cfg-3 proj, fc2): 256x128 tiles as for the wgrads above
         // (fc2 1479 -> 1327 us, proj 372 -> 358 us at 188 160 rows; neutral for k = 2304 / 3072)
-        static const int dfat = env_int("S3D_DGRAD_FAT");               // -1 (unset): as above; 0: never; 1: every long dgrad
+        static const int dfat = env_int("S3D_DGRAD_FAT");               // -1 (unset): the rules below; 0: never; 1: 256x128 for every long dgrad; 2: no 256x256
+        // 256x256 tiles (gemm_nn_fat_kernel) when they fill >= 85 % of the rounds they occupy on 256 CUs.  Measured at 188 160 rows against
+        // the 128x128 / 256x128 tiles (us): qkv 893 -> 811, fc1 1104 -> 993, fc2 (DGELU) 1576 -> 1479, proj 361 -> 304
+        if ((dfat < 0 || dfat == 4) && dmat != 0 && tile == 2 && (a.K & 63) == 0 && (a.N & 255) == 0 && a.M >= long_rows()) {
+            const long t256 = (long)((a.M + 255) / 256) * (a.N / 256), slots = (t256 + 255) / 256 * 256;
+            if (t256 * 100 >= slots * 85) {
+                switch (epi) {
+                    case EPI_F32: return launch_nn_fat<EPI_F32>(a, stream);
+                    case EPI_DGELU: return launch_nn_fat<EPI_DGELU>(a, stream);
+                    case EPI_BF16_BIAS: return launch_nn_fat<EPI_BF16_BIAS>(a, stream);
+                    default: break;
+                }
+            }
+        }
         if (dfat != 0 && dmat != 0 && tile == 2 && (a.K & 7) == 0 && (a.N & 7) == 0 && a.M >= long_rows() && a.N >= 256 && (dfat == 1 || dfat == 3 || (a.K >= 512 && a.K <= 1024))) {
             if (dfat == 3 && (a.N & 255) == 0) {                       // experiment: 128x256
                 switch (epi) {

@@ -306,6 +306,41 @@ def test_gemm_fat_forward_tile(M, N, K, epi):
     del ref
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(43500, 768, 2304, 'F32'),            # qkv dgrad (ragged last row tile)
+                                       (10700, 3072, 768, 'DGELU'),          # mlp.fc2 dgrad
+                                       (43520, 768, 768, 'BF16_BIAS')])      # attn.proj dgrad
+def test_gemm_fat_dgrad_tile(M, N, K, epi):
+    """gemm_nn_fat_kernel (256x256 plain-bf16 dgrad tile; the long backward Linear layers of cfg-3): against the fp64 product of the SAME
+    bf16 operands -- fp32 accumulation order for the F32 epilogue, one bf16 ulp for the bf16 outputs."""
+    from tests import _cov
+    g = torch.Generator().manual_seed(M + K)
+    dy = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(DEV).to(torch.bfloat16)         # nn.Linear weight [out = K][in = N]: k-major B
+    aux = torch.randn(M, N, generator=g).to(DEV).to(torch.bfloat16)
+    out32 = torch.full((M, N), float('nan'), dtype=torch.float32, device=DEV)
+    out16 = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+    kw = dict(A_hi=dy, lda=K, B_hi=w, ldb=N, M=M, N=N, K=K)
+    if epi == 'F32':
+        kw.update(C=out32, ldc=N)
+    else:
+        kw.update(O_hi=out16, ldo=N)
+        if epi == 'DGELU':
+            kw.update(aux=aux, ldaux=N)
+    L.lib().s3d_cov_enable(1)
+    ops.gemm(0, 1, 0, epi, **kw)
+    assert any(k.startswith('gemm_nn_fat:') for k in _cov.collect(L.lib())), 'the shape did not dispatch the 256x256 tile'
+    ref = dy.double() @ w.double()
+    if epi == 'F32':
+        assert rel_err(out32, ref) < 1e-5
+    else:
+        if epi == 'DGELU':
+            ref = ref * _gelu_grad(aux)
+        got = out16.double()
+        assert not torch.isnan(got).any()
+        ulp = ref.abs() * 2.0 ** -8 + 1e-6 * float(ref.abs().max())
+        assert bool(((got - ref).abs() <= ulp).all()), f'max {(got - ref).abs().max():.3e}'
+
+
 @pytest.mark.parametrize('rows,D', [(7, 192), (1664, 384), (333, 768), (40000, 192), (9, 256), (64, 1024), (5000, 512)])
 def test_layernorm_fwd_bwd(rows, D):
     g = torch.Generator().manual_seed(5)
