@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""256x256 dgrad tile (S3D_DGRAD_FAT=4, tuning build): outputs against fp64 on the same bf16 operands + timing at the cfg-3 shapes."""
+"""256x256 dgrad tile (default; S3D_DGRAD_FAT=2 in the tuning build = the 128x128 / 256x128 tiles): outputs against fp64 on the same bf16 operands + timing at the cfg-3 shapes."""
 import os
 import sys
 
