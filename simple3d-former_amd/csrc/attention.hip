@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                         const int r = 8 * s2 + j + e;
                         float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse4[r >> 2][r & 3]));
                         if (q0 + 32 > p.N) pr = (q0 + acc_row(r, h2) < p.N) ? pr : 0.f;
-                        const float dm = ((mw4[r >> 2][r & 3] >> l31) & 1u) ? p.drop_scale : 0.f;
+                        const float dm = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)mw4[r >> 2][r & 3], l31, 1) & __float_as_uint(p.drop_scale));
                         pv[e] = pr * dm;
                         dv2[e] = pr * (dpacc[r] * dm - del4[r >> 2][r & 3]) * p.scale;
                     }
@@ -772,8 +772,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
             for (int r = 0; r < 16; r += 2) {                        // keys acc_row(r, h2) (even) and + 1: one hash, 16 bits each
                 const uint32_t z = drop_hash_at(drow, (uint32_t)(k0 + acc_row(r, h2)));
                 const bool keep0 = drop_half(z, 0u, p.drop_thr), keep1 = drop_half(z, 1u, p.drop_thr);
-                sv[r] = keep0 ? sv[r] * p.drop_scale : 0.f;
-                sv[r + 1] = keep1 ? sv[r + 1] * p.drop_scale : 0.f;
+                sv[r] = keep0 ? sv[r] : 0.f;                          // (the 1 / (1 - p) scale is applied once, with 1 / l, at the end)
+                sv[r + 1] = keep1 ? sv[r + 1] : 0.f;
                 wb |= (keep0 ? (1u << acc_row(r, 0)) : 0u) | (keep1 ? (1u << acc_row(r + 1, 0)) : 0u);
             }
             // S3dAttnArgs::drop_mask: the query's word of tile (qt, kt) = the two half-waves' bits (keys 4 h2 + ..), for the backward kernels
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
         __syncthreads();
     }
     if (active && qok) {
-        const float inv = 1.0f / l_i;
+        const float inv = ((DROP && p.drop_thr) ? p.drop_scale : 1.0f) / l_i;
         const long orow = ((long)b * p.sb + (long)qrow * p.st) * p.ldo + h * HD;
 #pragma unroll
         for (int d = 0; d < NDB; ++d)
@@ -929,7 +929,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
                         float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc2, -lse2));        // exp(S * scale - lse), one fma + v_exp
                         if (ragged) pr = (k0 + acc_row(r, h2)) < p.N ? pr : 0.f;             // last key tile only (wave-uniform)
                         float dpn = dpacc[r];
-                        if constexpr (decltype(from_mask)::value) dpn = ((wcur >> acc_row(r, 0)) & 1u) ? dpn * p.drop_scale : 0.f;
+                        if constexpr (decltype(from_mask)::value)     // v_bfe_i32 (0 / ~0) & scale bits: three instructions instead of five
+                            dpn *= __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)wcur, acc_row(r, 0), 1) & __float_as_uint(p.drop_scale));
                         else if (p.drop_thr) dpn = drop_half(drop_hash_at(drow, (uint32_t)(k0 + (acc_row(r, h2) & ~1))), (uint32_t)r & 1u, p.drop_thr) ? dpn * p.drop_scale : 0.f;
                         dsv[e] = pr * (dpn - delta) * p.scale;
                     }

@@ -473,8 +473,10 @@ def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first, 
     assert e < 1e-4, f'fwd rel err {e:.3e} (a wrong mask gives ~0.3)'
     dout = torch.randn(rows, D, generator=g).to(DEV).to(torch.bfloat16)
     dqkv = ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop, drop_mask=mbuf)
-    if stored:                         # bit-identical to the backward that evaluates the hash
-        assert torch.equal(dqkv, ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop))
+    if stored:                         # the same gradient as the backward that evaluates the hash: the mask arithmetic differs only in where
+        ref_h = ops.attention_bwd(hi, out_hi, out_lo, lse, dout, Bb, H, N, D, sb, st, drop=drop).float()   # a product is fused into an fma
+        diff = (dqkv.float() - ref_h).abs()
+        assert float(diff.max()) <= 2.0 ** -7 * float(ref_h.abs().max()) and float((diff > 0).float().mean()) < 1e-2
     xb = to_b(hi.double()).requires_grad_(True)
     ref_attn(xb).backward(to_b(dout.double()).reshape(Bb, N, H, hd).transpose(1, 2))
     gotd = to_b(dqkv.float())
