@@ -1361,7 +1361,7 @@ __global__ __launch_bounds__(256) void gemm_pair_dmat_kernel(const GemmArgs pa, 
 // counterpart of gemm_nt_fat_kernel: eight waves (2 x 4) of 128 x 64 outputs, two 64 KB stages of k = 64 (A 256 rows x 128 bytes,
 // B 64 k-rows x 512 bytes read back transposed with ds_read_b64_tr_b16), the epilogue staged 32 rows at a time.
 template <int EPI>
-__global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p, const int PM) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 256, BN = 256, NTHR = 512, WN = 4, TM = 128, TN = 64, FM = 8, FN = 4;
     constexpr int A_BYTES = BM * 128, B_BYTES = 64 * BN * 2, STAGE = A_BYTES + B_BYTES, PPW = 8;
@@ -1374,7 +1374,15 @@ __global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p) {
         const int q = ntile >> 3, r = ntile & 7, xcd = tile_id & 7, idx = tile_id >> 3;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (tile_id / ntx) * BM, n0 = (tile_id % ntx) * BN;
+    int tm = tile_id / ntx, tn = tile_id % ntx;
+    if (PM > 1) {                                                      // panels of PM tile rows, walked m-first (see gemm_nt_dma_kernel): with 12
+        const int nty = gridDim.y;                                     // column tiles (fc2 dgrad) the row-major walk re-streams the 4.7 MB
+        const int per = PM * ntx, pnl = tile_id / per, w = tile_id - pnl * per;     // weight per row tile -- L2 hit rate 0.54 (PMC)
+        const int rows = min(PM, nty - pnl * PM);
+        tm = pnl * PM + w % rows;
+        tn = w / rows;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int ntiles = p.K >> 6;                                       // K % 64 == 0 (launcher)
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
 
@@ -1449,8 +1457,10 @@ __global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p) {
     }
 }
 
+static int nt_panel(int M, int N, int BM, int BN);       // (defined with the forward launchers below)
 template <int EPI>
 int launch_nn_fat(const GemmArgs& a, hipStream_t stream) {
+    const int pm = nt_panel(a.M, a.N, 256, 256);
     constexpr int LDS = 2 * (256 * 128 + 64 * 256 * 2);
     auto kern = gemm_nn_fat_kernel<EPI>;
     static bool attr_set = false;
@@ -1467,11 +1477,11 @@ int launch_nn_fat(const GemmArgs& a, hipStream_t stream) {
         sl.flops = 2.0 * a.M * a.N * a.K;
         (void)hipEventCreate(&sl.e0); (void)hipEventCreate(&sl.e1);
         (void)hipEventRecord(sl.e0, stream);
-        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a, pm);
         (void)hipEventRecord(sl.e1, stream);
         g_prof.push_back(sl);
     } else {
-        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a);
+        hipLaunchKernelGGL(kern, grid, dim3(512), LDS, stream, a, pm);
     }
     S3D_CHECK_LAUNCH_V("gemm_nn_fat", KEY);
     return 0;
