@@ -86,6 +86,45 @@ int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wg
 /* the same launch carrying a SECOND wgrad (any layer whose dy and x are ready: s3d_block_bwd puts attn.proj's wgrad on the qkv pair
  * launch once the proj dgrad has moved into the fused attention backward) */
 int s3d_gemm_pair3(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, const S3dGemmArgs* wgrad2, s3d_stream_t stream);
+/* Round 5 -- the same two halves as launches of their own, for callers that keep dy until several layers' wgrads can share one launch
+ * (s3d_blocks_bwd with S3dBlockScratch::wg_ring does):
+ *   s3d_gemm_dgrad_splitk: "dx = dy @ W" (A = dy [M][K] k-contiguous, B = W [K][N] k-major, fp32 C, alpha; no bias) on 64 x 64 tiles with
+ *   the k range cut into nslice slices of whole 64-tiles; slice s STORES its partial product at C + s * slice_stride (elements), and the
+ *   consumer adds the planes (s3d_layernorm_bwd: S3dLnBwdArgs::dy_parts / dy_part_stride).  No atomics: bitwise reproducible.
+ *   s3d_gemm_wgrad_group: for n <= 24 layers with the same row count K: dW_i[out][in] (+)= alpha * dy_i[K][out]^T x_i[K][in] and, when db is
+ *   set, db_i[out] (+)= alpha * colsum(dy_i); 128 x 128 output tiles over the full K, one workgroup per tile, plain read-modify-write
+ *   (accumulate = 1) or overwrite (accumulate = 0): no split-K, no atomics, bitwise reproducible.  out, in, ld_dy, ld_x multiples of 8.
+ *   s3d_gemm_dgrad_splitk_slices: the slices a request for `want` (1 .. 4) really gives for this K -- pass THAT count to both calls. */
+typedef struct S3dWgradItem {
+    const uint16_t* dy; long ld_dy; int out;
+    const uint16_t* x; long ld_x; int in;
+    float* dW; long ldw;
+    float* db;                        /* optional */
+} S3dWgradItem;
+/* Round 5 -- the LayerNorm backward as an EPILOGUE of the dgrad that produces its input (s3d_blocks_bwd with S3dBlockScratch::ln_aux does):
+ * the two per-row reductions of nn.LayerNorm's backward, s1 = mean_n(dy gamma) and s2 = mean_n(dy gamma xh), are linear in the gradient dz
+ * the dgrad multiplies (dy = dz @ W):  s1 = sum_k dz[k] u[k],  s2 = (1/D) sum_k dz[k] (pre[k] - c[k])  with the weights-only vectors
+ * u[k] = mean_n(W[k][n] gamma[n]), c[k] = b[k] + sum_n W[k][n] beta[n] (s3d_ln_aux) and the layer's own saved pre-activation `pre`.  The
+ * producer of dz accumulates both dots per row (rs1, rs2: fp32 atomics; s3d_gemm_dgrad_dgelu for mlp.fc2's dgrad, the fused attention
+ * backward for dqkv), and s3d_gemm_dgrad_lnbwd applies  dx = rstd (dy gamma - s1 - xh s2) + dres  element-wise to its own output tile
+ * (+ bf16 copy, + column partials of dgamma / dbeta: partial[row tile][2][D], >= ceil(M / 64) rows, or atomics).  Two launches fewer per block. */
+typedef struct S3dRowStats {
+    const float* u; const float* c;    /* producer: weights-only vectors of the Linear whose dgrad FOLLOWS, indexed by this launch's output column */
+    float* rs1; float* rs2;            /* [M]: accumulated by the producer (zero before it), read by the consumer (rs2 is divided by D there) */
+    float* zero_buf; int zero_n;       /* optional: zero_n floats the launch clears (a statistics buffer that is idle while it runs) */
+} S3dRowStats;
+typedef struct S3dLnAuxLayer {
+    const uint16_t* w_hi; const uint16_t* w_lo; const float* bias;     /* Linear weight [K][D] as split planes, bias [K] (may be NULL) */
+    const float* gamma; const float* beta;                             /* the LayerNorm in front of it */
+    float* u; float* c; int K;                                         /* out: [K] each */
+} S3dLnAuxLayer;
+int s3d_ln_aux(const S3dLnAuxLayer* layers, int n, int D, s3d_stream_t stream);       /* n <= 32 layers, one launch */
+struct S3dLnBwdArgs;
+int s3d_gemm_dgrad_dgelu(const S3dGemmArgs* args, const S3dRowStats* stats, s3d_stream_t stream);   /* O_hi = bf16(A @ B * gelu'(aux)); stats may be NULL */
+int s3d_gemm_dgrad_lnbwd(const S3dGemmArgs* args, const struct S3dLnBwdArgs* ln, const S3dRowStats* stats, s3d_stream_t stream);
+int s3d_gemm_dgrad_splitk_slices(int K, int want);
+int s3d_gemm_dgrad_splitk(const S3dGemmArgs* args, int nslice, long slice_stride, s3d_stream_t stream);
+int s3d_gemm_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, s3d_stream_t stream);
 /* 1 if s3d_gemm(0, 0, split, S3D_EPI_RESID, args, ...) with args->ln_tickets set would run the fused LayerNorm epilogue */
 int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
 /* 1 if a forward (0,0) F32-epilogue launch of this shape accumulates S3dGemmArgs::col_sums (128x128 tiles, N % 8 == 0); the caller
@@ -146,6 +185,9 @@ typedef struct S3dLnBwdArgs {
     /* optional dropout mask applied to the bf16 copy only (the branch gradient of a post-norm residual), see S3dGemmArgs */
     const unsigned long long* drop_seed; int drop_site; unsigned int drop_thr; float drop_scale;
     uint16_t* dx_bf_lo;            /* optional: low plane of dx_bf (dx ~= dx_bf + dx_bf_lo), same pitch -- split-precision backward mode */
+    /* dy arrives as dy_parts partial planes (the k-slices of s3d_gemm_dgrad_splitk): plane k at dy + k * dy_part_stride (elements), same
+     * pitch; they are added in plane order while they are loaded (at most 4).  0 or 1: dy is the whole gradient. */
+    int dy_parts; long dy_part_stride;
 } S3dLnBwdArgs;
 int s3d_layernorm_fwd(const S3dLnArgs* args, s3d_stream_t stream);
 int s3d_layernorm_bwd(const S3dLnBwdArgs* args, s3d_stream_t stream);
@@ -403,7 +445,21 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
      * the LAST block's data -- the library can only check that the pointers are set. */
     uint16_t *dx_a_lo, *dx_b_lo, *dh_lo, *dqkv_lo, *datt_lo, *dx_b_lo_cls, *datt_lo_cls;
     const S3dAdamFill* adam_fill;                 /* optional (host pointer): the optimizer update rides on the backward launches, see S3dAdamFill */
+    /* Round 5 -- dgrad chain + grouped wgrads (small token counts with the fused attention backward, plain-bf16 backward only).  wg_ring =
+     * wg_slots x s3d_block_wgrad_slot_bytes(shape) bytes: every block of a s3d_blocks_bwd call keeps its four dy tensors (d(x_out), d(x_mid),
+     * dh, dqkv as bf16) in a slot of its own instead of the shared dx_a_bf / dx_b_bf / dh / dqkv, its backward becomes dgrad-only launches,
+     * and the wgrads of up to wg_slots blocks run as ONE s3d_gemm_wgrad_group launch (read-modify-write into the gradient arena: no
+     * split-K, no atomics) before the last LayerNorm backward of the group / of the call.  NULL / 0: the paired launches of rounds 1 - 4.
+     * dgrad_splitk (1 .. 4; 0 = 1): k-slices of the fc1 / qkv dgrads on that path; dxn must then hold dgrad_splitk planes of [M][D]. */
+    uint16_t* wg_ring; int wg_slots; int dgrad_splitk;
+    /* ... and the LayerNorm backward kernels of that chain folded into the dgrads (see S3dRowStats): ln_aux = per block [u2 | c2 | u1 | c1] =
+     * 2 * (hidden + 3 D) floats (filled by s3d_blocks_bwd itself, one s3d_ln_aux launch per call), ln_rowstat = 4 * M floats, ZERO when the
+     * first backward runs (the chain's own launches clear what they have consumed).  Both NULL: stand-alone LayerNorm backward launches. */
+    float* ln_aux; float* ln_rowstat;
+    int wg_overwrite;                             /* 1: the grouped wgrads STORE dW / db instead of adding to them (the caller knows the gradient
+                                                   * arena is not accumulating across backward calls: no read of the old values) */
 } S3dBlockScratch;
+size_t s3d_block_wgrad_slot_bytes(const S3dBlockShape* shape);
 /* Workspace layout for callers that do not want to re-derive it (the shipped Python host allocates the same buffers one by one,
  * simple3d-former_amd/engine.py::_BlockWorkspace / _BlockScratch): ONE device allocation holds the saved activations of `depth`
  * consecutive blocks (acts[i].x_out aliases acts[i+1].x_in; low planes of xn1 / qkv / xn2 / hact shared by all blocks -- they only feed the
@@ -411,8 +467,9 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
  * shape->cls_only_block != 0, the class-row buffers.  s3d_block_workspace_bytes returns the size (0 on a bad shape); s3d_block_workspace_carve
  * fills acts[0 .. depth) and *scratch (may be NULL when with_backward == 0) with pointers into `base` (256-byte aligned pieces; host-side
  * arithmetic only, nothing is enqueued) and reports the sub-range [*zero_offset, *zero_offset + *zero_bytes) that the caller must clear
- * ONCE before the first backward (the class-row buffers: only their class rows are ever written).  Split-precision parity mode (the *_lo
- * gradient planes, hpre_lo) is not laid out here. */
+ * ONCE before the first backward (the class-row buffers: only their class rows are ever written; with_backward = 2: also the row statistics).  Split-precision parity mode (the *_lo
+ * gradient planes, hpre_lo) is not laid out here.  with_backward = 2: additionally the dy ring of the dgrad chain (S3dBlockScratch::wg_ring:
+ * min(depth, 3) slots, dgrad_splitk = 3 and a three-plane dxn) and the buffers of the fused LayerNorm backward (ln_aux, ln_rowstat). */
 size_t s3d_block_workspace_bytes(const S3dBlockShape* shape, int depth, int with_backward);
 int s3d_block_workspace_carve(const S3dBlockShape* shape, int depth, int with_backward, void* base, size_t bytes, S3dBlockActs* acts,
                               S3dBlockScratch* scratch, size_t* zero_offset, size_t* zero_bytes);

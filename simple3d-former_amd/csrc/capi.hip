@@ -10,6 +10,7 @@
 
 #include "adam_fill.h"
 #include "attention.h"
+#include "bwd_gemm.h"
 #include "fused_block.h"
 #include "gemm.h"
 #include "kernels.h"
@@ -209,16 +210,49 @@ int bwd_streams_join(hipStream_t s, BwdStreams* bs) {
 // LayerNorm column-sum partials of one s3d_blocks_bwd call (see S3dBlockScratch::ln_partial): slot k of the call's LayerNorms
 struct LnPartials {
     const float* part[64]; float* dg[64]; float* db[64];
+    int rows[64];                                  // partial rows this LayerNorm's launch really writes (<= ln_partial_blocks)
     int n = 0;
-    float* slot(const S3dBlockScratch& w, int D, float* dgamma, float* dbeta) {
+    float* slot(const S3dBlockScratch& w, int D, float* dgamma, float* dbeta, int nrows = 0) {
         float* ptr = w.ln_partial + (long)n * w.ln_partial_blocks * 2 * D;
-        part[n] = ptr; dg[n] = dgamma; db[n] = dbeta;
+        part[n] = ptr; dg[n] = dgamma; db[n] = dbeta; rows[n] = nrows > 0 ? nrows : w.ln_partial_blocks;
         ++n;
         return ptr;
     }
     int flush(const S3dBlockScratch& w, int D, hipStream_t s) {
-        const int rc = n ? s3d_launch_ln_grad_reduce(part, dg, db, n, w.ln_partial_blocks, D, s) : 0;
+        const int rc = n ? s3d_launch_ln_grad_reduce_rows(part, dg, db, rows, n, D, s) : 0;
         n = 0;
+        return rc;
+    }
+};
+
+// ---- round 5: dgrad chain + grouped wgrads (S3dBlockScratch::wg_ring) -----------------------------------------------------------
+// Every block of a s3d_blocks_bwd call keeps its four dy tensors in a ring slot; its backward is dgrad-only launches (the fc1 / qkv
+// dgrads as k-slices whose planes the LayerNorm backward adds), and the wgrads of up to `slots` blocks run as ONE grouped launch
+// right before the last LayerNorm backward of the group (bwd_gemm.hip).  That LayerNorm backward is the only launch that writes a
+// buffer a pending wgrad may still read (the next block's d(x_out) slot, or the caller's dx_a_bf at the end of the call).
+struct WgSlot { bf16_t *dxa, *dxb, *dh, *dqkv; };
+inline size_t wg_pad(size_t n) { return (n + 127) / 128 * 128; }
+inline size_t wg_slot_elems(size_t M, size_t D, size_t Hd) { return 2 * wg_pad(M * D) + wg_pad(M * Hd) + wg_pad(M * 3 * D); }
+struct WgradDefer {
+    bf16_t* ring = nullptr;
+    int slots = 0, splitk = 1, accumulate = 1;
+    size_t M = 0, D = 0, Hd = 0;
+    S3dWgradItem items[24];
+    int n = 0, pending_blocks = 0, next = 0;
+    const bf16_t* dxa_cur = nullptr;               // d(x_out) (bf16) of the block about to run: the caller's dx_a_bf, then ring slots
+    const float* aux = nullptr;                    // fused LayerNorm backward: the call's [u2 | c2 | u1 | c1] vectors, block by block in call order
+    int aux_index = 0;
+    WgSlot slot(int i) const {
+        bf16_t* b = ring + (size_t)i * wg_slot_elems(M, D, Hd);
+        return WgSlot{b, b + wg_pad(M * D), b + 2 * wg_pad(M * D), b + 2 * wg_pad(M * D) + wg_pad(M * Hd)};
+    }
+    void push(const bf16_t* dy, int out, const bf16_t* x, int in, float* dW, float* db) {
+        S3dWgradItem& q = items[n++];
+        q.dy = dy; q.ld_dy = out; q.out = out; q.x = x; q.ld_x = in; q.in = in; q.dW = dW; q.ldw = in; q.db = db;
+    }
+    int flush(hipStream_t s) {
+        const int rc = n ? s3d_launch_wgrad_group(items, n, (int)M, 1.0f, accumulate, s) : 0;
+        n = 0; pending_blocks = 0;
         return rc;
     }
 };
@@ -292,9 +326,14 @@ int block_bwd_split(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
 
 // fq: optimizer shares (adam_fill.h) that ride on this block's launches -- the GEMM parameters of the block whose backward has just retired.
 // Shares in sixteenths, roughly the launches' durations (16.8 / 12.9 / 6.0 / 7.5 / 7.9 / 12.9 / 6.0 us at cfg-2).
+int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
+                    const S3dBlockScratch& w, hipStream_t s, LnPartials* lp, WgradDefer& wd, bool last_of_call);
+
 int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
-              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false, AdamFillQueue* fq = nullptr) {
+              const S3dBlockScratch& w, hipStream_t s, LnPartials* lp = nullptr, bool cls_only = false, AdamFillQueue* fq = nullptr,
+              WgradDefer* wd = nullptr, bool last_of_call = true) {
     if (w.dx_a_lo != nullptr) return block_bwd_split(sh, p, gr, a, w, s, lp, cls_only);
+    if (wd != nullptr && !cls_only) return block_bwd_chain(sh, p, gr, a, w, s, lp, *wd, last_of_call);
     auto share = [&](int sixteenths) { if (fq) fq->share16 = sixteenths; return fq; };
     const long M = (long)sh.Bb * sh.N;
     const int D = sh.D, Hd = sh.hidden;
@@ -334,7 +373,7 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     const bool fuse_bwd = sh.fuse == 0 && !cls_only && bs == nullptr && s3d_fused_attn_bwd_ok(sh.Bb, sh.N, D, sh.H);
     const GemmArgs proj_wg = wgrad_args(dxb_bf, D, a.att_hi, D, M2, gr.proj_w, gr.proj_b, pd, pd);
     if (fuse_bwd) {
-        FusedAttnBwdArgs fb;
+        FusedAttnBwdArgs fb{};
         fb.dxm = dxb_bf; fb.lddxm = D; fb.w_hi = p.proj_w_hi; fb.qkv_hi = a.qkv_hi;
         fb.lse = a.lse; fb.dqkv = w.dqkv; fb.Bb = sh.Bb; fb.N = sh.N; fb.H = sh.H; fb.scale = at.scale;
         fb.lse_packed = s3d_attention_pairs_packed(at) ? 1 : 0;
@@ -356,6 +395,96 @@ int block_bwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGr
     lb.dx_bf = w.dx_a_bf; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
     if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
     S3D_TRY(s3d_launch_ln_bwd(lb, s, share(16)));        // whatever is left of the current range
+    return 0;
+}
+
+// The dense block on the dgrad chain (see WgradDefer): fc2 dgrad * gelu' -> fc1 dgrad (k-slices) -> norm2 -> fused proj dgrad + attention
+// backward -> qkv dgrad (k-slices) -> [grouped wgrads of the pending blocks] -> norm1.  Six launches on the critical path, none of them
+// carries a wgrad.
+int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockGrads& gr, const S3dBlockActs& a,
+                    const S3dBlockScratch& w, hipStream_t s, LnPartials* lp, WgradDefer& wd, bool last_of_call) {
+    const long M = (long)sh.Bb * sh.N;
+    const int D = sh.D, Hd = sh.hidden;
+    const WgSlot S = wd.slot(wd.next);
+    const bf16_t* dxa = wd.dxa_cur;
+    const long plane = M * D;
+    // fused: the two LayerNorm backward launches run as epilogues of the fc1 / qkv dgrads (bwd_gemm.hip, "Row statistics"): four launches
+    // per block.  aux = this block's [u2 | c2 | u1 | c1]; rowstat = [norm2: s1, s2 | norm1: s1, s2], each [M]
+    const bool fused = wd.aux != nullptr;
+    const float* aux = fused ? wd.aux + (size_t)wd.aux_index * 2 * (Hd + 3 * D) : nullptr;
+    float* rs = w.ln_rowstat;
+    const int nty = (int)((M + 63) / 64);
+    S3dRowStats st;
+    memset(&st, 0, sizeof(st));
+    GemmArgs g = gemm_zero();   // dh = (dx_out @ W2) * gelu'(hpre)   [+ norm2's row statistics; clears norm1's]
+    g.A_hi = dxa; g.lda = D; g.B_hi = p.fc2_w_hi; g.ldb = Hd; g.M = (int)M; g.N = Hd; g.K = D;
+    g.aux = a.hpre; g.ldaux = Hd; g.O_hi = S.dh; g.ldo = Hd;
+    if (fused) {
+        st.u = aux; st.c = aux + Hd; st.rs1 = rs; st.rs2 = rs + M; st.zero_buf = rs + 2 * M; st.zero_n = (int)(2 * M);
+        S3D_TRY(s3d_launch_dgrad_dgelu(g, &st, s));
+    } else {
+        S3D_TRY(s3d_launch_gemm(false, true, false, EPI_DGELU, g, 1, s));
+    }
+    wd.push(dxa, D, a.hact_hi, Hd, gr.fc2_w, gr.fc2_b);
+    g = gemm_zero();            // dxn2 = dh @ W1   [-> norm2 backward -> d(x_mid)]
+    g.A_hi = S.dh; g.lda = Hd; g.B_hi = p.fc1_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = Hd; g.C = w.dxn; g.ldc = D;
+    LnBwdArgs lb;
+    memset(&lb, 0, sizeof(lb));
+    lb.dy = w.dxn; lb.lddy = D;
+    lb.x = a.x_mid; lb.ldx = D; lb.mean = a.mean2; lb.rstd = a.rstd2; lb.gamma = p.ln2_w;
+    lb.dres = w.dx_a; lb.lddres = D; lb.dx = w.dx_b; lb.lddx = D; lb.dx_bf = S.dxb; lb.lddxbf = D;
+    lb.dgamma = gr.ln2_w; lb.dbeta = gr.ln2_b; lb.rows = M; lb.D = D;
+    if (fused) {
+        if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b, nty); lb.partial_blocks = w.ln_partial_blocks; }
+        st.u = st.c = nullptr; st.rs1 = rs; st.rs2 = rs + M; st.zero_buf = nullptr; st.zero_n = 0;
+        S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
+    } else {
+        const int sl1 = s3d_dgrad_splitk_slices(Hd, wd.splitk);
+        S3D_TRY(s3d_launch_dgrad_splitk(g, sl1, plane, s));
+        lb.dy_parts = sl1; lb.dy_part_stride = plane;
+        if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
+        S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    }
+    wd.push(S.dh, Hd, a.xn2_hi, D, gr.fc1_w, gr.fc1_b);
+    AttnArgs at;                // (only for the lse layout question)
+    memset(&at, 0, sizeof(at));
+    at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
+    FusedAttnBwdArgs fb{};      // datt = dx_mid @ Wproj per head slice, then dq / dk / dv   [+ norm1's row statistics]
+    fb.dxm = S.dxb; fb.lddxm = D; fb.w_hi = p.proj_w_hi; fb.qkv_hi = a.qkv_hi;
+    fb.lse = a.lse; fb.dqkv = S.dqkv; fb.Bb = sh.Bb; fb.N = sh.N; fb.H = sh.H; fb.scale = 1.0f / sqrtf((float)(D / sh.H));
+    fb.lse_packed = s3d_attention_pairs_packed(at) ? 1 : 0;
+    if (fused) { fb.st_u = aux + 2 * Hd; fb.st_c = aux + 2 * Hd + 3 * D; fb.st_s1 = rs + 2 * M; fb.st_s2 = rs + 3 * M; }
+    S3D_TRY(s3d_launch_fused_attn_bwd(fb, D, s));
+    wd.push(S.dxb, D, a.att_hi, D, gr.proj_w, gr.proj_b);
+    wd.push(S.dqkv, 3 * D, a.xn1_hi, D, gr.qkv_w, gr.qkv_b);
+    ++wd.pending_blocks;
+    // norm1's backward writes the NEXT block's d(x_out): the next ring slot, whose previous content a pending wgrad may still read when the
+    // ring wraps -- or the caller's dx_a_bf when the call ends, which the first block of the call read.  So the grouped wgrads of the
+    // pending blocks go first (fused: the qkv dgrad carries that LayerNorm backward, so they go in front of it; all their operands exist).
+    const bool full = wd.pending_blocks >= wd.slots;
+    const bool flush_now = full || last_of_call;
+    const int next = full ? 0 : wd.next + 1;
+    bf16_t* dxa_next = last_of_call ? w.dx_a_bf : wd.slot(next).dxa;
+    g = gemm_zero();            // dxn1 = dqkv @ Wqkv   [-> norm1 backward -> d(x_in)]
+    g.A_hi = S.dqkv; g.lda = 3 * D; g.B_hi = p.qkv_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = 3 * D; g.C = w.dxn; g.ldc = D;
+    lb.dy = w.dxn; lb.x = a.x_in; lb.mean = a.mean1; lb.rstd = a.rstd1; lb.gamma = p.ln1_w; lb.dres = w.dx_b; lb.dx = w.dx_a;
+    lb.dx_bf = dxa_next; lb.dgamma = gr.ln1_w; lb.dbeta = gr.ln1_b;
+    if (fused) {
+        if (flush_now) S3D_TRY(wd.flush(s));
+        if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b, nty);
+        st.rs1 = rs + 2 * M; st.rs2 = rs + 3 * M; st.zero_buf = rs; st.zero_n = (int)(2 * M);      // norm2's statistics are consumed: cleared here
+        S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
+    } else {
+        const int sl2 = s3d_dgrad_splitk_slices(3 * D, wd.splitk);
+        S3D_TRY(s3d_launch_dgrad_splitk(g, sl2, plane, s));
+        if (flush_now) S3D_TRY(wd.flush(s));
+        lb.dy_parts = sl2; lb.dy_part_stride = plane;
+        if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
+        S3D_TRY(s3d_launch_ln_bwd(lb, s));
+    }
+    wd.next = next;
+    wd.dxa_cur = dxa_next;
+    ++wd.aux_index;
     return 0;
 }
 
@@ -485,6 +614,16 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
 
 }  // namespace
 
+namespace {
+// the dgrad chain + grouped wgrads replace the paired launches where the fused attention backward runs (small token counts, dense
+// blocks, plain-bf16 backward) and the caller has provided the ring
+bool wgrad_chain_ok(const S3dBlockShape& sh, const S3dBlockScratch& w) {
+    if (w.wg_ring == nullptr || w.wg_slots < 1 || w.dx_a_lo != nullptr || bwd_streams_enabled()) return false;
+    if (sh.fuse != 0 || !s3d_fused_attn_bwd_ok(sh.Bb, sh.N, sh.D, sh.H)) return false;
+    return (sh.D & 7) == 0 && (sh.hidden & 7) == 0 && w.dgrad_splitk >= 0 && w.dgrad_splitk <= 4;
+}
+}  // namespace
+
 // ---- workspace layout of a block stack (mirrors engine.py::_BlockWorkspace / _BlockScratch; one allocation instead of ~25)
 namespace {
 struct Carver {
@@ -497,7 +636,8 @@ struct Carver {
 };
 // LayerNorm-backward partial rows per LayerNorm: engine.py::ln_partial_blocks
 int ws_ln_partial_blocks(long rows) { return rows <= 8192 ? 208 : 416; }
-size_t block_ws_layout(const S3dBlockShape& sh, int depth, bool bwd, void* base, S3dBlockActs* acts, S3dBlockScratch* sc, size_t* zoff, size_t* zbytes) {
+size_t block_ws_layout(const S3dBlockShape& sh, int depth, int bwd, void* base, S3dBlockActs* acts, S3dBlockScratch* sc, size_t* zoff, size_t* zbytes) {
+    const bool ring = (bwd & 2) != 0;            // with_backward = 2 / 3: + the dy ring of the dgrad chain (3 slots, 3 k-slices)
     const size_t M = (size_t)sh.Bb * sh.N, D = sh.D, Hd = sh.hidden, BHN = (size_t)sh.Bb * sh.H * sh.N;
     Carver c{static_cast<unsigned char*>(base)};
     std::vector<float*> x(depth + 1);
@@ -521,15 +661,21 @@ size_t block_ws_layout(const S3dBlockShape& sh, int depth, bool bwd, void* base,
     if (bwd) {
         S3dBlockScratch s;
         memset(&s, 0, sizeof(s));
-        s.dxn = c.take<float>(M * D); s.dx_a = c.take<float>(M * D); s.dx_b = c.take<float>(M * D);
+        s.dxn = c.take<float>(M * D * (ring ? 3 : 1)); s.dx_a = c.take<float>(M * D); s.dx_b = c.take<float>(M * D);
         s.dx_a_bf = c.take<uint16_t>(M * D); s.dx_b_bf = c.take<uint16_t>(M * D);
         s.dh = c.take<uint16_t>(M * Hd); s.dqkv = c.take<uint16_t>(M * 3 * D); s.datt = c.take<uint16_t>(M * D);
         s.delta = c.take<float>(BHN);
         s.ln_partial_blocks = ws_ln_partial_blocks((long)M);
         s.ln_partial = c.take<float>((size_t)2 * depth * s.ln_partial_blocks * 2 * D);
-        if (sh.cls_only_block) {
-            const size_t z0 = c.off;
-            s.dx_b_cls = c.take<float>(M * D); s.dx_b_bf_cls = c.take<uint16_t>(M * D); s.datt_cls = c.take<uint16_t>(M * D);
+        if (ring) {
+            s.wg_slots = depth < 3 ? depth : 3; s.dgrad_splitk = 3;
+            s.wg_ring = c.take<uint16_t>(wg_slot_elems(M, D, Hd) * (size_t)s.wg_slots);
+            s.ln_aux = c.take<float>((size_t)depth * 2 * (Hd + 3 * D));
+        }
+        const size_t z0 = c.off;                     // everything from here on is cleared once by the caller
+        if (ring) s.ln_rowstat = c.take<float>(4 * M);
+        if (sh.cls_only_block) { s.dx_b_cls = c.take<float>(M * D); s.dx_b_bf_cls = c.take<uint16_t>(M * D); s.datt_cls = c.take<uint16_t>(M * D); }
+        if (c.off > z0) {
             if (zoff) *zoff = z0;
             if (zbytes) *zbytes = c.off - z0;
         }
@@ -553,7 +699,7 @@ size_t s3d_sizeof(const char* n) {
     SZ(S3dGemmArgs); SZ(S3dLnArgs); SZ(S3dLnBwdArgs); SZ(S3dAttnArgs); SZ(S3dFoldArgs); SZ(S3dPosGradArgs);
     SZ(S3dHeadArgs); SZ(S3dCeArgs); SZ(S3dHeadLossArgs); SZ(S3dAdamState); SZ(S3dBlockShape); SZ(S3dBlockParams); SZ(S3dBlockGrads);
     SZ(S3dBlockActs); SZ(S3dBlockScratch); SZ(S3dEncShape); SZ(S3dEncParams); SZ(S3dEncGrads); SZ(S3dEncActs); SZ(S3dBnArgs);
-    SZ(S3dGroupProjArgs); SZ(S3dAdamFill);
+    SZ(S3dGroupProjArgs); SZ(S3dAdamFill); SZ(S3dWgradItem); SZ(S3dRowStats); SZ(S3dLnAuxLayer);
 #undef SZ
     return 0;
 }
@@ -589,6 +735,27 @@ int s3d_gemm_pair(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wg
     S3D_REQUIRE(dgrad->M > 0 && dgrad->N > 0 && dgrad->K > 0 && wgrad->M > 0 && wgrad->N > 0 && wgrad->K > 0, "s3d_gemm_pair: empty problem");
     S3D_REQUIRE(wgrad->C != nullptr, "s3d_gemm_pair: the wgrad half accumulates into C");
     return s3d_launch_gemm_pair(epi_dgrad, *dgrad, *wgrad, st(s));
+}
+int s3d_gemm_dgrad_splitk_slices(int K, int want) { return s3d_dgrad_splitk_slices(K, want); }
+int s3d_gemm_dgrad_splitk(const S3dGemmArgs* a, int nslice, long slice_stride, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_gemm_dgrad_splitk: null args");
+    return s3d_launch_dgrad_splitk(*a, nslice, slice_stride, st(s));
+}
+int s3d_gemm_dgrad_dgelu(const S3dGemmArgs* a, const S3dRowStats* stats, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr, "s3d_gemm_dgrad_dgelu: null args");
+    return s3d_launch_dgrad_dgelu(*a, stats, st(s));
+}
+int s3d_gemm_dgrad_lnbwd(const S3dGemmArgs* a, const S3dLnBwdArgs* ln, const S3dRowStats* stats, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr && ln != nullptr, "s3d_gemm_dgrad_lnbwd: null args");
+    return s3d_launch_dgrad_lnbwd(*a, *ln, stats, st(s));
+}
+int s3d_ln_aux(const S3dLnAuxLayer* layers, int n, int D, s3d_stream_t s) { return s3d_launch_ln_aux(layers, n, D, st(s)); }
+int s3d_gemm_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, s3d_stream_t s) {
+    return s3d_launch_wgrad_group(items, n, K, alpha, accumulate, st(s));
+}
+size_t s3d_block_wgrad_slot_bytes(const S3dBlockShape* sh) {
+    if (sh == nullptr || sh->Bb <= 0 || sh->N <= 0 || sh->D <= 0 || sh->hidden <= 0) { s3d_set_error("s3d_block_wgrad_slot_bytes: bad shape"); return 0; }
+    return wg_slot_elems((size_t)sh->Bb * sh->N, sh->D, sh->hidden) * sizeof(bf16_t);
 }
 int s3d_gemm_pair3(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* wgrad, const S3dGemmArgs* wgrad2, s3d_stream_t s) {
     S3D_REQUIRE(dgrad && wgrad && wgrad2, "s3d_gemm_pair3: null args");
@@ -785,16 +952,16 @@ int s3d_stream_wait_event(s3d_stream_t s, void* ev) {
 
 size_t s3d_block_workspace_bytes(const S3dBlockShape* sh, int depth, int with_backward) {
     if (!block_ws_shape_ok(sh, depth)) { s3d_set_error("s3d_block_workspace_bytes: bad shape / depth"); return 0; }
-    return block_ws_layout(*sh, depth, with_backward != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    return block_ws_layout(*sh, depth, with_backward, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 int s3d_block_workspace_carve(const S3dBlockShape* sh, int depth, int with_backward, void* base, size_t bytes, S3dBlockActs* acts,
                               S3dBlockScratch* scratch, size_t* zero_offset, size_t* zero_bytes) {
     S3D_REQUIRE(block_ws_shape_ok(sh, depth), "s3d_block_workspace_carve: bad shape / depth");
     S3D_REQUIRE(base != nullptr && acts != nullptr && (!with_backward || scratch != nullptr), "s3d_block_workspace_carve: base, acts (and scratch with with_backward) required");
     S3D_REQUIRE(((uintptr_t)base & 255) == 0, "s3d_block_workspace_carve: base must be 256-byte aligned");
-    const size_t need = block_ws_layout(*sh, depth, with_backward != 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const size_t need = block_ws_layout(*sh, depth, with_backward, nullptr, nullptr, nullptr, nullptr, nullptr);
     S3D_REQUIRE(bytes >= need, "s3d_block_workspace_carve: %zu bytes given, %zu needed", bytes, need);
-    block_ws_layout(*sh, depth, with_backward != 0, base, acts, scratch, zero_offset, zero_bytes);
+    block_ws_layout(*sh, depth, with_backward, base, acts, scratch, zero_offset, zero_bytes);
     return 0;
 }
 int s3d_block_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, s3d_stream_t s) {
@@ -845,10 +1012,36 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
         }
         return 0;
     };
+    WgradDefer wd;
+    const bool chain = wgrad_chain_ok(*sh, *w) && af == nullptr;
+    if (chain) {
+        wd.ring = w->wg_ring; wd.slots = w->wg_slots < 6 ? w->wg_slots : 6; wd.splitk = w->dgrad_splitk > 0 ? w->dgrad_splitk : 1;
+        wd.M = (size_t)sh->Bb * sh->N; wd.D = sh->D; wd.Hd = sh->hidden;
+        wd.dxa_cur = w->dx_a_bf;
+        wd.accumulate = w->wg_overwrite ? 0 : 1;
+        if (w->ln_aux != nullptr && w->ln_rowstat != nullptr && !s3d_deterministic()) {
+            // weights-only vectors of the row statistics for every dense block of this call, in call order (one launch)
+            S3dLnAuxLayer layers[32];
+            int nl = 0;
+            const size_t per = 2 * ((size_t)sh->hidden + 3 * (size_t)sh->D);
+            for (int i = first; i >= last && nl + 2 <= 32; --i) {
+                if (sh->cls_only_block == i + 1) continue;
+                float* base = w->ln_aux + (size_t)(nl / 2) * per;
+                layers[nl++] = S3dLnAuxLayer{p[i].fc1_w_hi, p[i].fc1_w_lo, p[i].fc1_b, p[i].ln2_w, p[i].ln2_b, base, base + sh->hidden, sh->hidden};
+                layers[nl++] = S3dLnAuxLayer{p[i].qkv_w_hi, p[i].qkv_w_lo, p[i].qkv_b, p[i].ln1_w, p[i].ln1_b, base + 2 * sh->hidden, base + 2 * sh->hidden + 3 * sh->D, 3 * sh->D};
+            }
+            int dense = 0;
+            for (int i = first; i >= last; --i) dense += sh->cls_only_block == i + 1 ? 0 : 1;
+            if (nl == 2 * dense && nl > 0) {                    // (more than 16 dense blocks in one call: stand-alone LayerNorm backward)
+                S3D_TRY(s3d_launch_ln_aux(layers, nl, sh->D, st(s)));
+                wd.aux = w->ln_aux;
+            }
+        }
+    }
     for (int i = first; i >= last; --i) {
         const bool cls_only = sh->cls_only_block == i + 1;
         if (cls_only) S3D_REQUIRE(w->dx_b_cls && w->dx_b_bf_cls && w->datt_cls, "s3d_blocks_bwd: cls_only_block needs the *_cls scratch buffers");
-        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, af ? &fq : nullptr));
+        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, af ? &fq : nullptr, chain ? &wd : nullptr, i == last));
         if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
         if (af) {
             S3D_TRY(drain());

@@ -34,6 +34,9 @@ struct FusedAttnBwdArgs {
     const float* lse;                     // as written by the forward (lse_packed: see FusedAttnArgs)
     bf16_t* dqkv;                         // out: d(q | k | v) [M][3D]
     int Bb, N, H; float scale; int lse_packed;
+    // optional (round 5, bwd_gemm.hip "Row statistics"): the LayerNorm-1 backward's per-row dots of dqkv, st_s1[row] += sum_k dqkv[row][k] u[k],
+    // st_s2[row] += sum_k dqkv[row][k] (qkv[row][k] - c[k]) over this head's 3 x 64 columns (fp32 atomics; u, c: [3D]).  nullptr: not computed.
+    const float* st_u; const float* st_c; float* st_s1; float* st_s2;
 };
 bool s3d_fused_attn_bwd_ok(int Bb, int N, int D, int H);
 int s3d_launch_fused_attn_bwd(const FusedAttnBwdArgs& a, int D, hipStream_t s);

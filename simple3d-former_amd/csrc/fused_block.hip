@@ -519,7 +519,18 @@ constexpr int BW_TILE = 32 * BW_WPITCH;  // elements of a staged [32 tokens][64]
 constexpr int BW_SAMPLE = 4 * BW_TILE + 128;      // Q | K | V | dO tiles + 64 floats (delta, lse)
 constexpr int BW_THREADS = 512;          // eight waves stage; waves 0..3 compute (sample, half)
 constexpr int bw_apitch(int D) { return D + 8; }
-constexpr int bw_lds_bytes(int D) { return (D * BW_WPITCH + 64 * bw_apitch(D) + 2 * BW_SAMPLE) * 2; }
+constexpr int BW_STAT = 2 * 3 * 64;      // floats: this head's slices of the row-statistics vectors u | c (q, k, v columns)
+constexpr int bw_lds_bytes(int D) { return (D * BW_WPITCH + 64 * bw_apitch(D) + 2 * BW_SAMPLE) * 2 + BW_STAT * 4; }
+
+// row statistics of four gradient values g (bf16 pairs as stored) against the saved pre-activation z (LDS, 4 bf16) and the u / c slices
+__device__ __forceinline__ void bw_row_stats(const u32x2 g, const bf16_t* z, const float* u, const float* c, float& s1, float& s2) {
+    const u32x2 zz = *reinterpret_cast<const u32x2*>(z);
+    const f32x4 u4 = *reinterpret_cast<const f32x4*>(u), c4 = *reinterpret_cast<const f32x4*>(c);
+    const float gv[4] = {__uint_as_float(g[0] << 16), __uint_as_float(g[0] & 0xffff0000u), __uint_as_float(g[1] << 16), __uint_as_float(g[1] & 0xffff0000u)};
+    const float zv[4] = {__uint_as_float(zz[0] << 16), __uint_as_float(zz[0] & 0xffff0000u), __uint_as_float(zz[1] << 16), __uint_as_float(zz[1] & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s1 = fmaf(gv[e], u4[e], s1); s2 = fmaf(gv[e], zv[e] - c4[e], s2); }
+}
 
 template <int D>
 __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAttnBwdArgs p) {
@@ -534,6 +545,8 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
     bf16_t* sW = reinterpret_cast<bf16_t*>(smem);                          // [D][WP], rows of a k-tile in k-slot order
     bf16_t* sA = sW + D * WP;                                              // d(x_mid) rows of the pair: [64][AP]
     bf16_t* sT = sA + 64 * AP;                                             // per sample: Q | K | V | dO tiles, then delta / lse
+    float* sU = reinterpret_cast<float*>(sT + 2 * BW_SAMPLE);              // [3][64] u, then [3][64] c of this head (row statistics)
+    const bool stats = p.st_s1 != nullptr;                                 // uniform
 
     // ---- stage everything with coalesced 16-byte loads (row fragments gathered straight from memory touch 32 rows per load
     //      instruction: measured, the texture-address path then costs more than the arithmetic of the whole kernel)
@@ -556,6 +569,10 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
         const int bb = min(2 * pr + sm, p.Bb - 1), tt = min(r, p.N - 1);
         *reinterpret_cast<u32x4*>(sT + sm * BW_SAMPLE + which * BW_TILE + r * WP + 8 * ch) =
             *reinterpret_cast<const u32x4*>(p.qkv_hi + ((long)bb * p.N + tt) * (3 * D) + which * D + 64 * h + 8 * ch);
+    }
+    if (stats && tid >= 128 && tid < 128 + BW_STAT) {
+        const int c = tid - 128, which = c / 192, part = (c % 192) >> 6, f = c & 63;
+        sU[c] = (which ? p.st_c : p.st_u)[part * D + 64 * h + f];
     }
     if (tid < 64) {
         const int sm = tid >> 5, bb = min(2 * pr + sm, p.Bb - 1), tt = min(tid & 31, p.N - 1);
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
             dq[0] = MFMA32(k0f[s2], dsf[s2].v, dq[0]);
             dq[1] = MFMA32(k1f[s2], dsf[s2].v, dq[1]);
         }
+        float st1 = 0.f, st2 = 0.f;
         if (active && tok_ok) {
 #pragma unroll
             for (int d = 0; d < 2; ++d)
@@ -676,11 +694,18 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
                 for (int c = 0; c < 4; ++c) {
                     u32x2 v;
                     v[0] = f2bf2(dq[d][4 * c], dq[d][4 * c + 1]); v[1] = f2bf2(dq[d][4 * c + 2], dq[d][4 * c + 3]);
-                    *reinterpret_cast<u32x2*>(p.dqkv + orow + d * 32 + 8 * c + 4 * h2) = v;
+                    const int f = d * 32 + 8 * c + 4 * h2;
+                    *reinterpret_cast<u32x2*>(p.dqkv + orow + f) = v;
+                    if (stats) bw_row_stats(v, ldsQ + l31 * WP + f, sU + f, sU + 192 + f, st1, st2);
                 }
+        }
+        if (stats) {
+            st1 = half_sum(st1); st2 = half_sum(st2);
+            if (active && tok_ok && h2 == 0) { atomic_add_f32(p.st_s1 + tokrow, st1); atomic_add_f32(p.st_s2 + tokrow, st2); }
         }
     } else {
         // ---- phase B: dV^T = dO^T . P, dK^T = Q^T . dS
+        float st1 = 0.f, st2 = 0.f;
         U128 pf[2], dsf[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -711,11 +736,20 @@ __global__ __launch_bounds__(BW_THREADS) void blk_attn_bwd_kernel(const FusedAtt
                     u32x2 a, v;
                     a[0] = f2bf2(dk[4 * c], dk[4 * c + 1]); a[1] = f2bf2(dk[4 * c + 2], dk[4 * c + 3]);
                     v[0] = f2bf2(dv[4 * c], dv[4 * c + 1]); v[1] = f2bf2(dv[4 * c + 2], dv[4 * c + 3]);
-                    const long off = orow + d * 32 + 8 * c + 4 * h2;
+                    const int f = d * 32 + 8 * c + 4 * h2;
+                    const long off = orow + f;
                     *reinterpret_cast<u32x2*>(p.dqkv + off + D) = a;
                     *reinterpret_cast<u32x2*>(p.dqkv + off + 2 * D) = v;
+                    if (stats) {
+                        bw_row_stats(a, ldsK + l31 * WP + f, sU + 64 + f, sU + 192 + 64 + f, st1, st2);
+                        bw_row_stats(v, ldsV + l31 * WP + f, sU + 128 + f, sU + 192 + 128 + f, st1, st2);
+                    }
                 }
             }
+        }
+        if (stats) {
+            st1 = half_sum(st1); st2 = half_sum(st2);
+            if (active && tok_ok && h2 == 0) { atomic_add_f32(p.st_s1 + tokrow, st1); atomic_add_f32(p.st_s2 + tokrow, st2); }
         }
     }
 #ifdef S3D_TIMELINE

@@ -8,6 +8,8 @@ typedef S3dLnBwdArgs LnBwdArgs;
 int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s);
 int s3d_launch_ln_grad_reduce(const float* const* partial, float* const* dgamma, float* const* dbeta, int n_ln, int nblk, int D,
                               hipStream_t s);
+int s3d_launch_ln_grad_reduce_rows(const float* const* partial, float* const* dgamma, float* const* dbeta, const int* rows, int n_ln, int D,
+                                   hipStream_t s);
 struct AdamFillQueue;        // adam_fill.h: optimizer shares that ride on this launch as filler workgroups (nullptr: none)
 int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s, AdamFillQueue* fill = nullptr);
 

@@ -71,6 +71,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p, const Ad
                         X[i][c] = make_float4(t[0], t[1], t[2], t[3]);
                     }
                     DY[i][c] = *reinterpret_cast<const float4*>(p.dy + row * p.lddy + col);
+                    if (p.dy_parts > 1) {                   // uniform: k-slices of a split-K dgrad, added in plane order (all loads in flight together)
+                        float4 e[3];
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            if (k < p.dy_parts) e[k - 1] = *reinterpret_cast<const float4*>(p.dy + (long)k * p.dy_part_stride + row * p.lddy + col);
+#pragma unroll
+                        for (int k = 1; k < 4; ++k)
+                            if (k < p.dy_parts) { DY[i][c].x += e[k - 1].x; DY[i][c].y += e[k - 1].y; DY[i][c].z += e[k - 1].z; DY[i][c].w += e[k - 1].w; }
+                    }
                     R[i][c] = p.dres ? *reinterpret_cast<const float4*>(p.dres + row * p.lddres + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
@@ -153,23 +162,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const LnBwdArgs p, const Ad
 
 // dgamma / dbeta += column sums of the [nblk][2][D] partials of up to 64 LayerNorms.  One workgroup per (LayerNorm, 64
 // columns of the 2*D): thread (c, rg) sums rows rg, rg+4, .. with 13 independent loads in flight, LDS folds the four groups.
-struct LnReduceArgs { const float* part[64]; float* dg[64]; float* db[64]; int nblk, D; };
+struct LnReduceArgs { const float* part[64]; float* dg[64]; float* db[64]; int rows[64]; int D; };
 __global__ __launch_bounds__(256) void ln_grad_reduce_kernel(const LnReduceArgs a) {
     __shared__ float red[4][64];
     const int ln = blockIdx.y, c = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + c;                   // 0 .. 2D-1: [gamma | beta]
     const float* src = a.part[ln];
+    const int nblk = a.rows[ln];
     float s = 0.f;
     if (col < 2 * a.D) {
         const int which = col / a.D, cc = col % a.D;
         // eight independent (clamped, then masked) loads per trip: the reduction is latency-bound, not bandwidth-bound
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int b0 = rg; b0 < a.nblk; b0 += 32) {
+        for (int b0 = rg; b0 < nblk; b0 += 32) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int b = b0 + 4 * u;
-                const float v = src[((long)min(b, a.nblk - 1) * 2 + which) * a.D + cc];
-                acc[u] += (b < a.nblk) ? v : 0.f;
+                const float v = src[((long)min(b, nblk - 1) * 2 + which) * a.D + cc];
+                acc[u] += (b < nblk) ? v : 0.f;
             }
         }
         s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
@@ -198,6 +208,8 @@ int s3d_launch_ln_fwd(const LnArgs& a, hipStream_t s) {
 
 int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s, AdamFillQueue* fillq) {
     S3D_REQUIRE(a.D % 4 == 0 && a.D <= 1024, "layernorm bwd: D=%d must be a multiple of 4 and <= 1024", a.D);
+    S3D_REQUIRE(a.dy_parts >= 0 && a.dy_parts <= 4 && (a.dy_parts <= 1 || (a.dy_part_stride & 3) == 0), "layernorm bwd: dy_parts=%d (<= 4), dy_part_stride=%ld (multiple of 4)",
+                a.dy_parts, a.dy_part_stride);
     if (a.rows <= 0) return 0;
     long blocks = (a.rows + 4 * MAX_RPW - 1) / (4 * MAX_RPW);
     if (a.rows <= 512) blocks = (a.rows + 3) / 4;         // few rows (final norm on the cls rows): one row per wave
@@ -227,7 +239,7 @@ int s3d_launch_ln_bwd(const LnBwdArgs& a, hipStream_t s, AdamFillQueue* fillq) {
     else if (rpw == 2) S3D_LN_BWD(2);
     else S3D_LN_BWD(1);
 #undef S3D_LN_BWD
-    S3D_CHECK_LAUNCH_V("ln_bwd", (rpw >= 4 ? 4 : rpw) * 100 + (a.D <= 256 ? 1 : a.D <= 512 ? 2 : 4) * 10 + (a.partial ? 1 : 0));
+    S3D_CHECK_LAUNCH_V("ln_bwd", (rpw >= 4 ? 4 : rpw) * 100 + (a.D <= 256 ? 1 : a.D <= 512 ? 2 : 4) * 10 + (a.partial ? 1 : 0) + (a.dy_parts > 1 ? 1000 : 0));
     return 0;
 }
 
@@ -235,9 +247,22 @@ int s3d_launch_ln_grad_reduce(const float* const* partial, float* const* dgamma,
                               hipStream_t s) {
     S3D_REQUIRE(n_ln >= 0 && n_ln <= 64 && nblk > 0 && D > 0, "layernorm_grad_reduce: n_ln=%d (<= 64), nblk=%d, D=%d", n_ln, nblk, D);
     if (n_ln == 0) return 0;
+    int rows[64];
+    for (int i = 0; i < n_ln; ++i) rows[i] = nblk;
+    return s3d_launch_ln_grad_reduce_rows(partial, dgamma, dbeta, rows, n_ln, D, s);
+}
+
+// ... with a row count per LayerNorm (the dgrad-epilogue LayerNorm backward writes one partial row per 64-row tile)
+int s3d_launch_ln_grad_reduce_rows(const float* const* partial, float* const* dgamma, float* const* dbeta, const int* rows, int n_ln, int D,
+                                   hipStream_t s) {
+    S3D_REQUIRE(n_ln >= 0 && n_ln <= 64 && D > 0, "layernorm_grad_reduce: n_ln=%d (<= 64), D=%d", n_ln, D);
+    if (n_ln == 0) return 0;
     LnReduceArgs a;
-    for (int i = 0; i < n_ln; ++i) { a.part[i] = partial[i]; a.dg[i] = dgamma[i]; a.db[i] = dbeta[i]; }
-    a.nblk = nblk; a.D = D;
+    for (int i = 0; i < n_ln; ++i) {
+        S3D_REQUIRE(rows[i] > 0, "layernorm_grad_reduce: LayerNorm %d has no partial rows", i);
+        a.part[i] = partial[i]; a.dg[i] = dgamma[i]; a.db[i] = dbeta[i]; a.rows[i] = rows[i];
+    }
+    a.D = D;
     hipLaunchKernelGGL(ln_grad_reduce_kernel, dim3((2 * D + 63) / 64, n_ln), dim3(256), 0, s, a);
     S3D_CHECK_LAUNCH("ln_grad_reduce");
     return 0;

@@ -208,6 +208,13 @@ UPDATE_WORKGROUPS = int(os.environ.get('S3D_UPDATE_WORKGROUPS', '0'))
 # update, measured 0.6 - 1.4 % SLOWER at cfg-2 (each launch slows down by what its share costs as a stream of its own:
 # profiles/r04_adam_fill.txt) -> opt-in (S3D_ADAM_FILL=1 / VoxelEngine.adam_fill = True).
 ADAM_FILL = os.environ.get('S3D_ADAM_FILL', '0') == '1'
+# Round 5: the small-batch backward as a dgrad chain + grouped wgrads (capi.hip: block_bwd_chain; S3dBlockScratch::wg_ring).  WGRAD_GROUP =
+# blocks per grouped wgrad launch (= ring slots; 0: the paired dgrad + wgrad launches of rounds 1 - 4), DGRAD_SPLITK = k-slices of the
+# fc1 / qkv dgrads (their planes are added by the LayerNorm backward).
+WGRAD_GROUP = int(os.environ.get('S3D_WGRAD_GROUP', '3'))
+DGRAD_SPLITK = int(os.environ.get('S3D_DGRAD_SPLITK', '3'))
+LN_BWD_FUSE = os.environ.get('S3D_LN_BWD_FUSE', '1') != '0'             # LayerNorm backward as the epilogue of the fc1 / qkv dgrads (row statistics)
+WGRAD_OVERWRITE = os.environ.get('S3D_WGRAD_OVERWRITE', '1') != '0'     # train_step: grouped wgrads store instead of read-modify-write
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
 
@@ -222,10 +229,14 @@ def ln_partial_blocks(rows):
 
 
 class _BlockScratch:
-    def __init__(self, M, D, H, hidden, BHN, device, depth=0, precise=False):
+    def __init__(self, M, D, H, hidden, BHN, device, depth=0, precise=False, wgrad_ring=None):
+        """wgrad_ring = (slots, dgrad_splitk, slot_bytes): the dy ring of the dgrad chain (S3dBlockScratch::wg_ring, round 5) -- every
+        block keeps d(x_out) / d(x_mid) / dh / dqkv in a slot of its own and the wgrads of `slots` blocks run as one grouped launch."""
         f32 = dict(dtype=torch.float32, device=device)
         b16 = dict(dtype=torch.bfloat16, device=device)
-        self.dxn = torch.empty(M, D, **f32)
+        planes = wgrad_ring[1] if wgrad_ring else 1
+        self._dxn_planes = torch.empty(planes, M, D, **f32)          # k-slices of the split-K dgrads (added by the LayerNorm backward)
+        self.dxn = self._dxn_planes[0]
         # dx_a and its bf16 copy share one allocation: the backward starts from "zero except the cls rows", one fill instead of two
         self._dxa_raw = torch.empty(M * D * (8 if precise else 6), dtype=torch.uint8, device=device)
         self.dx_a = self._dxa_raw[:M * D * 4].view(torch.float32).view(M, D)
@@ -246,6 +257,16 @@ class _BlockScratch:
             self.dqkv_lo = torch.empty(M, 3 * D, **b16); self.datt_lo = torch.empty(M, D, **b16)
             L.fill(self.c, dx_a_lo=self.dx_a_lo, dx_b_lo=self.dx_b_lo, dh_lo=self.dh_lo, dqkv_lo=self.dqkv_lo, datt_lo=self.datt_lo)
         self.M, self.D = M, D
+        self.wg_ring = None
+        if wgrad_ring and not precise:
+            slots, splitk, slot_bytes = wgrad_ring
+            self.wg_ring = torch.empty(slots * slot_bytes, dtype=torch.uint8, device=device)
+            L.fill(self.c, wg_ring=self.wg_ring, wg_slots=slots, dgrad_splitk=splitk)
+            if LN_BWD_FUSE and depth > 0:
+                # the LayerNorm backward launches folded into the fc1 / qkv dgrads (S3dBlockScratch::ln_aux / ln_rowstat)
+                self.ln_aux = torch.zeros(depth * 2 * (hidden + 3 * D), **f32)
+                self.ln_rowstat = torch.zeros(4 * M, **f32)
+                L.fill(self.c, ln_aux=self.ln_aux, ln_rowstat=self.ln_rowstat)
         nblk = ln_partial_blocks(M)
         if depth > 0 and nblk > 0:
             # column-sum partials of the 2*depth LayerNorms of one s3d_blocks_bwd call (S3dBlockScratch::ln_partial)
@@ -465,7 +486,11 @@ class VoxelEngine:
                                     precise=self.precise)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
-        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth, precise=self.precise)
+        ring = None
+        if WGRAD_GROUP > 0 and M <= 8192 and not self.group and not self.precise:
+            slot = int(self.lib.s3d_block_wgrad_slot_bytes(ctypes.byref(ws.blocks.shape)))
+            ring = (min(WGRAD_GROUP, 6, self.depth), max(1, min(DGRAD_SPLITK, 4)), slot)
+        ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth, precise=self.precise, wgrad_ring=ring)
         ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev, self.precise) if CLS_ONLY else (ws.scratch.c, None)       # scratch table of the (first) pass
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
@@ -817,7 +842,14 @@ class VoxelEngine:
                     self._fill = None
                 self._refresh_conv_planes()
                 return loss
-            self.backward(B)
+            # the fused step owns the gradient arena (zeroed by the previous step's Adam, no accumulation across backward calls unless the
+            # image branch adds its own backward): the grouped wgrads may store instead of read-modify-write
+            ws = self.workspace(B)
+            ws.sc1.wg_overwrite = 1 if (WGRAD_OVERWRITE and self.images is None and not self.group) else 0
+            try:
+                self.backward(B)
+            finally:
+                ws.sc1.wg_overwrite = 0
             self.adam_step(zero_grad=True)
             return loss
         main = torch.cuda.current_stream()

@@ -194,6 +194,154 @@ def test_gemm_pair_with_a_second_wgrad_riding_on_the_launch():
     assert rel_err(dWp, dxm.double().t() @ att.double()) < 2e-5 and rel_err(dbp, dxm.double().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('rows,K,N,want', [
+    (1664, 1536, 384, 3), (1664, 1152, 384, 3), (1664, 1152, 384, 4), (1664, 1536, 384, 2), (1664, 1536, 384, 1),   # cfg-2: fc1 / qkv dgrads
+    (208, 576, 192, 3),                   # cfg-1-sized, deit_tiny
+    (78, 392, 136, 3),                    # ragged: 78 rows, K not a multiple of 64 (partial last k-tile), N not a multiple of 64
+    (1000, 72, 64, 4),                    # fewer slices than asked for (two 64-tiles)
+])
+def test_gemm_dgrad_splitk_planes_and_their_sum_in_layernorm_bwd(rows, K, N, want):
+    """s3d_gemm_dgrad_splitk: the k-slices are STORED as partial planes (no atomics) and s3d_layernorm_bwd adds them (dy_parts); each plane
+    against the fp64 product of the same bf16-rounded operands over its k range, the LayerNorm backward against the one fed the summed dy."""
+    g = torch.Generator().manual_seed(500 + rows + K)
+    dy = torch.randn(rows, K, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(K, N, generator=g) * 0.05).to(DEV).to(torch.bfloat16)       # nn.Linear weight [out = K][in = N], read k-major
+    lib = L.lib()
+    ns = lib.s3d_gemm_dgrad_splitk_slices(K, want)
+    assert 1 <= ns <= want
+    planes = torch.full((ns + 1, rows, N), float('nan'), dtype=torch.float32, device=DEV)
+    ga = L.fill(L.S3dGemmArgs(), A_hi=dy, lda=K, B_hi=w, ldb=N, M=rows, N=N, K=K, C=planes, ldc=N, alpha=1.0)
+    for rep in range(2):                                                             # overwrites: the second call gives the same planes
+        L.check(lib.s3d_gemm_dgrad_splitk(ctypes.byref(ga), ns, ctypes.c_long(rows * N), L.current_stream()), 'dgrad_splitk')
+    kchunk = ((K + ns - 1) // ns + 63) // 64 * 64
+    for sl in range(ns):
+        k0, k1 = sl * kchunk, min(K, (sl + 1) * kchunk)
+        ref = dy[:, k0:k1].double() @ w[k0:k1].double()
+        assert rel_err(planes[sl], ref) < 1e-5, f'plane {sl}'
+    assert bool(torch.isnan(planes[ns]).all()), 'nothing behind the last plane is touched'
+    assert rel_err(planes[:ns].double().sum(0), dy.double() @ w.double()) < 1e-5
+    if N % 4 == 0 and N <= 1024:
+        x = torch.randn(rows, N, generator=g).to(DEV)
+        gamma = (1 + 0.1 * torch.randn(N, generator=g)).to(DEV)
+        mean = x.mean(1); rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt()
+        dres = torch.randn(rows, N, generator=g).to(DEV)
+        want_out = ops.layernorm_bwd(planes[:ns].sum(0).contiguous(), x, mean, rstd, gamma, dres=dres)
+        dx = torch.empty_like(x); dx_bf = torch.empty(rows, N, dtype=torch.bfloat16, device=DEV)
+        dg = torch.zeros(N, device=DEV); db = torch.zeros(N, device=DEV)
+        a = L.fill(L.S3dLnBwdArgs(), dy=planes, lddy=N, dy_parts=ns, dy_part_stride=rows * N, x=x, ldx=N, mean=mean, rstd=rstd, gamma=gamma,
+                   dres=dres, lddres=N, dx=dx, lddx=N, dx_bf=dx_bf, lddxbf=N, dgamma=dg, dbeta=db, rows=rows, D=N)
+        L.check(lib.s3d_layernorm_bwd(ctypes.byref(a), L.current_stream()), 'layernorm_bwd (planes)')
+        assert rel_err(dx, want_out[0]) < 2e-6 and rel_err(dg, want_out[2]) < 2e-5 and rel_err(db, want_out[3]) < 2e-5
+        assert rel_err(dx_bf.float(), want_out[1].float()) < 1e-2
+
+
+@pytest.mark.parametrize('rows,D,Hd', [(1664, 384, 1536), (208, 192, 768), (78, 136, 72)])
+def test_fused_layernorm_backward_chain_row_statistics(rows, D, Hd):
+    """The LayerNorm backward as a dgrad epilogue (s3d_ln_aux -> s3d_gemm_dgrad_dgelu -> s3d_gemm_dgrad_lnbwd): mlp.fc2's dgrad writes
+    dh = bf16(dy @ W2 * gelu'(hpre)) and accumulates the two per-row dots, mlp.fc1's dgrad applies norm2's backward to its own output.  Checked
+    against the composition the stand-alone kernels compute: fp64 products of the same bf16 operands -> nn.LayerNorm backward in fp64."""
+    g = torch.Generator().manual_seed(700 + rows)
+    lib = L.lib()
+    x_mid = torch.randn(rows, D, generator=g)                                        # LayerNorm-2 input
+    gamma = 1 + 0.2 * torch.randn(D, generator=g); beta = 0.1 * torch.randn(D, generator=g)
+    W1 = torch.randn(Hd, D, generator=g) * 0.05; b1 = 0.1 * torch.randn(Hd, generator=g)
+    W2 = torch.randn(D, Hd, generator=g) * 0.05
+    dxo = torch.randn(rows, D, generator=g)                                          # d(x_out)
+    dres = torch.randn(rows, D, generator=g)
+    mean = x_mid.mean(1); rstd = (x_mid.var(1, unbiased=False) + 1e-6).rsqrt()
+    xh = (x_mid - mean[:, None]) * rstd[:, None]
+    w1h, w1l = ops.split_bf16(W1.to(DEV))
+    pre = ((xh * gamma + beta).double() @ (w1h.double() + w1l.double()).cpu().t() + b1.double())       # what the split-bf16 forward computes
+    hpre = pre.float().to(DEV).to(torch.bfloat16)
+    w2h = W2.to(DEV).to(torch.bfloat16); dxo_h = dxo.to(DEV).to(torch.bfloat16)
+    keep = []                                                                        # device copies must outlive the launches that read them
+    def dev(t):
+        keep.append(t.to(DEV).contiguous())
+        return keep[-1]
+    u = torch.empty(Hd, device=DEV); c = torch.empty(Hd, device=DEV)
+    lay = (L.S3dLnAuxLayer * 1)()
+    L.fill(lay[0], w_hi=w1h, w_lo=w1l, bias=dev(b1), gamma=dev(gamma), beta=dev(beta), u=u, c=c, K=Hd)
+    L.check(lib.s3d_ln_aux(lay, 1, D, L.current_stream()), 'ln_aux')
+    assert rel_err(u, (w1h.double().cpu() * gamma.double()).mean(1)) < 1e-5
+    assert rel_err(c, b1.double() + (w1h.double() + w1l.double()).cpu() @ beta.double()) < 1e-5
+    # producer: fc2 dgrad * gelu' + row statistics (and it clears a buffer that is idle)
+    rs = torch.zeros(2, rows, device=DEV); idle = torch.full((300,), 7.0, device=DEV)
+    dh = torch.full((rows, Hd), float('nan'), dtype=torch.bfloat16, device=DEV)
+    ga = L.fill(L.S3dGemmArgs(), A_hi=dxo_h, lda=D, B_hi=w2h, ldb=Hd, M=rows, N=Hd, K=D, alpha=1.0, aux=hpre, ldaux=Hd, O_hi=dh, ldo=Hd)
+    st = L.fill(L.S3dRowStats(), u=u, c=c, rs1=rs[0], rs2=rs[1], zero_buf=idle, zero_n=256)
+    L.check(lib.s3d_gemm_dgrad_dgelu(ctypes.byref(ga), ctypes.byref(st), L.current_stream()), 'dgrad_dgelu')
+    ref_dh = (dxo_h.double() @ w2h.double()) * _gelu_grad(hpre)
+    assert rms_err(dh.double(), ref_dh) < 3e-3 and not torch.isnan(dh.float()).any()
+    assert bool((idle[:256] == 0).all()) and bool((idle[256:] == 7.0).all())
+    gdy = dh.double() @ w1h.double()                                                 # dy of the LayerNorm: what the fc1 dgrad computes from the ROUNDED dh
+    gg = gdy.cpu() * gamma.double()
+    s1_ref, s2_ref = gg.mean(1), (gg * xh.double()).mean(1)
+    scale = float(gg.abs().mean())
+    assert float((rs[0].double().cpu() - s1_ref).abs().max()) < 2e-4 * scale, 's1'
+    # s2 carries the bf16 rounding of the saved pre-activation (1e-4 of |dy gamma| by the estimate in bwd_gemm.hip)
+    assert float((rs[1].double().cpu() / D - s2_ref).abs().max()) < 1e-3 * scale, 's2'
+    # consumer: fc1 dgrad + norm2 backward epilogue
+    dx = torch.full((rows, D), float('nan'), device=DEV); dx_bf = torch.full((rows, D), float('nan'), dtype=torch.bfloat16, device=DEV)
+    nty = (rows + 63) // 64
+    part = torch.full((nty + 1, 2, D), float('nan'), device=DEV)
+    gb = L.fill(L.S3dGemmArgs(), A_hi=dh, lda=Hd, B_hi=w1h, ldb=D, M=rows, N=D, K=Hd, alpha=1.0)
+    ln = L.fill(L.S3dLnBwdArgs(), x=dev(x_mid), ldx=D, mean=dev(mean), rstd=dev(rstd), gamma=dev(gamma), dres=dev(dres), lddres=D, dx=dx, lddx=D,
+                dx_bf=dx_bf, lddxbf=D, rows=rows, D=D, partial=part, partial_blocks=nty)
+    st2 = L.fill(L.S3dRowStats(), rs1=rs[0], rs2=rs[1])
+    L.check(lib.s3d_gemm_dgrad_lnbwd(ctypes.byref(gb), ctypes.byref(ln), ctypes.byref(st2), L.current_stream()), 'dgrad_lnbwd')
+    rstd_d, xh_d = rstd.double(), xh.double()
+    ref_dx = rstd_d[:, None] * (gg - s1_ref[:, None] - xh_d * s2_ref[:, None]) + dres.double()
+    assert rel_err(dx, ref_dx) < 5e-4, 'dx'              # (s2 from the bf16-rounded pre-activation: 2.2e-4 measured at 1664 x 384)
+    assert rms_err(dx_bf.double(), ref_dx) < 3e-3
+    assert rel_err(part[:nty, 0].double().sum(0), (gdy.cpu() * xh_d).sum(0)) < 2e-5, 'dgamma partials'
+    assert rel_err(part[:nty, 1].double().sum(0), gdy.cpu().sum(0)) < 2e-5, 'dbeta partials'
+    assert bool(torch.isnan(part[nty]).all())
+    # ... and with atomics instead of partial rows
+    dg = torch.zeros(D, device=DEV); db = torch.zeros(D, device=DEV)
+    L.fill(ln, partial=None, partial_blocks=0, dgamma=dg, dbeta=db)
+    L.check(lib.s3d_gemm_dgrad_lnbwd(ctypes.byref(gb), ctypes.byref(ln), ctypes.byref(st2), L.current_stream()), 'dgrad_lnbwd (atomics)')
+    assert rel_err(dg, (gdy.cpu() * xh_d).sum(0)) < 2e-5 and rel_err(db, gdy.cpu().sum(0)) < 2e-5
+
+
+@pytest.mark.parametrize('rows,shapes,acc', [
+    (1664, [(384, 1536), (1536, 384), (384, 384), (1152, 384)] * 3, 1),       # cfg-2: three blocks' fc2 / fc1 / proj / qkv wgrads in one launch
+    (1664, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 0),           # overwrite mode
+    (208, [(192, 768), (768, 192), (192, 192), (576, 192)] * 2, 1),           # cfg-1-sized (partial last k-tile: 208 = 3 * 64 + 16)
+    (78, [(136, 72), (72, 136), (8, 8), (264, 40)], 1),                       # ragged edges on every side, odd row count
+])
+def test_gemm_wgrad_group_full_k_deterministic(rows, shapes, acc):
+    """s3d_gemm_wgrad_group: dW_i (+)= dy_i^T x_i and db_i (+)= colsum(dy_i) for a list of layers in ONE launch, every output tile owned by one
+    workgroup over the full k -- against fp64 products of the same bf16-rounded operands, twice (accumulate / overwrite semantics), and
+    bitwise equal from run to run (no split-K, no atomics)."""
+    g = torch.Generator().manual_seed(900 + rows + len(shapes))
+    lib = L.lib()
+    items = (L.S3dWgradItem * len(shapes))()
+    keep, refs = [], []
+    for i, (O, I) in enumerate(shapes):
+        pad_o, pad_i = (8 if i % 2 else 0), (16 if i % 3 == 0 else 0)             # row pitches wider than the matrices
+        dy = torch.zeros(rows, O + pad_o); dy[:, :O] = torch.randn(rows, O, generator=g)
+        x = torch.zeros(rows, I + pad_i); x[:, :I] = torch.randn(rows, I, generator=g)
+        dyh, xh = dy.to(DEV).to(torch.bfloat16), x.to(DEV).to(torch.bfloat16)
+        dW = torch.full((O, I + 4), 0.5, dtype=torch.float32, device=DEV)         # pre-existing content: kept (accumulate) or replaced
+        db = torch.full((O,), 0.25, dtype=torch.float32, device=DEV) if i % 4 != 2 else None
+        L.fill(items[i], dy=dyh, ld_dy=O + pad_o, out=O, x=xh, ld_x=I + pad_i, **{'in': I}, dW=dW, ldw=I + 4, db=db)
+        keep.append((dyh, xh, dW, db))
+        refs.append((dyh[:, :O].double().t() @ xh[:, :I].double(), dyh[:, :O].double().sum(0)))
+    snaps = []
+    for rep in (1, 2):
+        L.check(lib.s3d_gemm_wgrad_group(items, len(shapes), rows, ctypes.c_float(0.5), acc, L.current_stream()), 'wgrad_group')
+        for (dyh, xh, dW, db), (rw, rb), (O, I) in zip(keep, refs, shapes):
+            n = rep if acc else 1
+            base = 0.5 if acc else 0.0
+            assert rel_err(dW[:, :I] - base, 0.5 * n * rw) < 2e-5, f'dW pass {rep}'
+            assert bool((dW[:, I:] == 0.5).all()), 'pad columns of dW untouched'
+            if db is not None:
+                assert rel_err(db - (0.25 if acc else 0.0), 0.5 * n * rb) < 2e-5, f'db pass {rep}'
+        snaps.append([t.clone() for k in keep for t in k[2:] if t is not None])
+    if not acc:                                                                    # overwrite mode: two runs, bitwise the same result
+        assert all(torch.equal(a, b) for a, b in zip(*snaps))
+
+
 @pytest.mark.parametrize('M,N,K', [(65536, 64, 32), (70000, 128, 64), (66048, 256, 128), (300000, 64, 64), (66000, 64, 40), (66000, 192, 192), (33000, 192, 96)])   # k = 40: register-staged kernel
 def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
     """S3dGemmArgs::col_sums: the F32 epilogue of a point-path convolution also accumulates sum(y) and sum(y^2) per output channel

@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5: dgrad chain + grouped wgrads against the paired launches, same box.  Arguments: "label:VAR=val,VAR=val" specs (bench.py env).
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+line() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', d['value'], d['ms_per_step'])"; }
+for i in $(seq ${ROUNDS:-2}); do
+  for spec in "$@"; do
+    label=${spec%%:*}; envs=${spec#*:}
+    ( IFS=,; for kv in $envs; do export "$kv"; done; unset IFS; python bench.py ${CFG:+--config $CFG} ${STEPS} --no-cpu-baseline --no-roofline 2>/dev/null | line "$label" )
+  done
+done
