@@ -9,7 +9,10 @@ bool s3d_dgrad_splitk_ok(const S3dGemmArgs& a);
 int s3d_dgrad_splitk_slices(int K, int want);      // slices a request for `want` (1 .. 4) really gives (whole 64-tiles per slice)
 int s3d_launch_dgrad_splitk(const S3dGemmArgs& a, int nslice, long slice_stride, hipStream_t s);
 // dW_i (+)= alpha * dy_i^T x_i, db_i (+)= alpha * colsum(dy_i) for n <= 24 layers that share the row count K, one launch
-int s3d_launch_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, hipStream_t s);
+// fills (optional): up to 6 optimizer shares (adam_fill.h) that ride on the launch as filler workgroups behind the tiles
+struct AdamFill;
+int s3d_launch_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, hipStream_t s, const AdamFill* fills = nullptr,
+                           int nfill = 0);
 // the fused backward chain (see bwd_gemm.hip, "Row statistics"): fc2 dgrad * gelu' + row statistics; dgrad + LayerNorm backward epilogue;
 // the weights-only vectors u / c of the row statistics
 int s3d_launch_dgrad_dgelu(const S3dGemmArgs& a, const S3dRowStats* st, hipStream_t s);

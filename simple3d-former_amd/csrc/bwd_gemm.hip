@@ -21,6 +21,7 @@
 #include "gemm.h"
 #include "kmajor.h"
 #include "kernels.h"
+#include "adam_fill.h"
 
 #include <string.h>
 
@@ -388,9 +389,23 @@ struct WgGroup {
     int beta;                                                          // 1: accumulate into dW / db, 0: overwrite
 };
 
+// optimizer shares riding on the launch (adam_fill.h): ranges of the arena whose gradients are final -- the blocks of the PREVIOUS group --
+// updated by `blocks` filler workgroups behind the tiles.  The tiles are paced by LDS / the L2 -> LDS path with the HBM nearly idle, the
+// update is a pure HBM stream without LDS: the two share a CU without competing for the same resource.
+struct WgFill { AdamFill f[6]; int n, blocks; };
+
 template <int NS, int BK, bool KTAIL>
-__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g) {
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgGroup g, const WgFill fill) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if ((int)blockIdx.x >= g.total) {                                   // filler workgroup: every range, grid-strided over the fillers
+        const int fb = (int)blockIdx.x - g.total;
+        for (int r = 0; r < fill.n; ++r) {
+            AdamFill f = fill.f[r];
+            f.blocks = fill.blocks;
+            adam_fill_run(f, fb);
+        }
+        return;
+    }
     static_assert(BK == 32 || BK == 64, "k-tiles of 32 or 64 rows");
     constexpr int A_BYTES = BK * 256, STAGE = 2 * A_BYTES, PPW = BK / 8;   // A and B: BK k-rows x 128 columns each, BK / 4 pieces each
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -633,7 +648,7 @@ int s3d_launch_ln_aux(const S3dLnAuxLayer* layers, int n, int D, hipStream_t s) 
     return 0;
 }
 
-int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, int accumulate, hipStream_t s) {
+int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, int accumulate, hipStream_t s, const AdamFill* fills, int nfill) {
     S3D_REQUIRE(it != nullptr && n >= 1 && n <= WG_MAX, "wgrad_group: 1 .. %d problems per launch (got %d)", WG_MAX, n);
     S3D_REQUIRE(K >= 1, "wgrad_group: K=%d rows", K);
     WgGroup g;
@@ -652,6 +667,19 @@ int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, in
         flops += 2.0 * q.out * q.in * (double)K;
     }
     g.n = n; g.K = K; g.total = total; g.alpha = alpha; g.beta = accumulate ? 1 : 0;
+    WgFill fill;
+    memset(&fill, 0, sizeof(fill));
+    if (fills != nullptr && nfill > 0) {
+        S3D_REQUIRE(nfill <= 6, "wgrad_group: at most 6 optimizer ranges per launch (got %d)", nfill);
+        long n4 = 0;
+        for (int i = 0; i < nfill; ++i) { fill.f[i] = fills[i]; n4 += fills[i].n4; }
+        fill.n = nfill;
+        static const int fb_env = s3d_tune_int("S3D_WGRAD_FILL_BLOCKS");
+        long blocks = fb_env > 0 ? fb_env : 256;
+        if (blocks > (n4 + 255) / 256) blocks = (n4 + 255) / 256;
+        fill.blocks = (int)blocks;
+    }
+    const unsigned grid = (unsigned)(total + fill.blocks);
     // variant = ring depth x k-tile: in-flight bytes per CU are what paces this launch (every operand byte is a first touch from the
     // Infinity Cache / HBM at ~1.5 us; profiles/r05_wgrad_group_variants.txt)
     static const int v_env = s3d_tune_int("S3D_WGRAD_VARIANT");
@@ -665,10 +693,10 @@ int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, in
         static bool set0 = false, set1 = false;                                                                              \
         if ((K % BK_) != 0) {                                                                                                \
             set_lds_once(wgrad_group_kernel<NS_, BK_, true>, LDS, set1);                                                     \
-            hipLaunchKernelGGL((wgrad_group_kernel<NS_, BK_, true>), dim3((unsigned)total), dim3(256), LDS, s, g);           \
+            hipLaunchKernelGGL((wgrad_group_kernel<NS_, BK_, true>), dim3(grid), dim3(256), LDS, s, g, fill);               \
         } else {                                                                                                             \
             set_lds_once(wgrad_group_kernel<NS_, BK_, false>, LDS, set0);                                                    \
-            hipLaunchKernelGGL((wgrad_group_kernel<NS_, BK_, false>), dim3((unsigned)total), dim3(256), LDS, s, g);          \
+            hipLaunchKernelGGL((wgrad_group_kernel<NS_, BK_, false>), dim3(grid), dim3(256), LDS, s, g, fill);              \
         }                                                                                                                    \
     } while (0)
     // measured (profiles/r05_wgrad_group_variants.txt; 324 tiles = three cfg-2 blocks per launch): two workgroups per CU beat one with a
@@ -683,6 +711,6 @@ int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, in
 #undef S3D_WG_LAUNCH
     s3d_prof_end(s);
     const bool ktail = (K & 63) != 0;
-    S3D_CHECK_LAUNCH_V("wgrad_group", ktail ? 1 : 0);
+    S3D_CHECK_LAUNCH_V("wgrad_group", (ktail ? 1 : 0) + (fill.n ? 10 : 0));
     return 0;
 }

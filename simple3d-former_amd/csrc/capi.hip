@@ -242,6 +242,14 @@ struct WgradDefer {
     const bf16_t* dxa_cur = nullptr;               // d(x_out) (bf16) of the block about to run: the caller's dx_a_bf, then ring slots
     const float* aux = nullptr;                    // fused LayerNorm backward: the call's [u2 | c2 | u1 | c1] vectors, block by block in call order
     int aux_index = 0;
+    // optimizer update riding on the grouped launches (S3dAdamFill): arena ranges whose gradients are final -- the GEMM parameters of the blocks
+    // whose wgrads an EARLIER launch has finished -- go to the next launch as filler shares; ranges of the blocks it computes itself follow after it
+    const S3dAdamFill* af = nullptr;
+    long ready[6][2]; int nready = 0;              // {offset, count} in floats
+    long pend[24][2]; int npend = 0;               // ranges that become ready with the next flush
+    int* n_filled = nullptr;                       // running count of the ranges reported in af->filled
+    void defer_range(long off, long n) { if (npend < 24 && n >= 4) { pend[npend][0] = off; pend[npend][1] = n / 4 * 4; ++npend; } }
+    void ready_range(long off, long n) { if (nready < 6 && n >= 4) { ready[nready][0] = off; ready[nready][1] = n / 4 * 4; ++nready; } }
     WgSlot slot(int i) const {
         bf16_t* b = ring + (size_t)i * wg_slot_elems(M, D, Hd);
         return WgSlot{b, b + wg_pad(M * D), b + 2 * wg_pad(M * D), b + 2 * wg_pad(M * D) + wg_pad(M * Hd)};
@@ -251,7 +259,30 @@ struct WgradDefer {
         q.dy = dy; q.ld_dy = out; q.out = out; q.x = x; q.ld_x = in; q.in = in; q.dW = dW; q.ldw = in; q.db = db;
     }
     int flush(hipStream_t s) {
-        const int rc = n ? s3d_launch_wgrad_group(items, n, (int)M, 1.0f, accumulate, s) : 0;
+        AdamFill fills[6];
+        int nf = 0;
+        if (af != nullptr && n > 0) {
+            for (int i = 0; i < nready && *n_filled * 2 + 2 <= af->filled_cap; ++i) {
+                const long o = ready[i][0], cnt = ready[i][1];
+                AdamFill& f = fills[nf++];
+                f = adam_fill_none();
+                f.p = af->p + o; f.g = af->g + o; f.m = af->m + o; f.v = af->v + o;
+                f.hi = af->hi ? af->hi + o : nullptr; f.lo = af->lo ? af->lo + o : nullptr;
+                f.st = af->state; f.n4 = cnt / 4; f.zero_grad = af->zero_grad;
+                af->filled[2 * *n_filled] = o; af->filled[2 * *n_filled + 1] = cnt;
+                ++*n_filled;
+            }
+            nready = 0;
+        }
+        const int rc = n ? s3d_launch_wgrad_group(items, n, (int)M, 1.0f, accumulate, s, nf ? fills : nullptr, nf) : 0;
+        if (af != nullptr) {                           // what this launch has computed can ride on the next one (contiguous neighbours merged)
+            for (int i = 0; i < npend; ++i) {
+                if (nready > 0 && ready[nready - 1][0] + ready[nready - 1][1] == pend[i][0]) ready[nready - 1][1] += pend[i][1];
+                else if (nready > 0 && pend[i][0] + pend[i][1] == ready[nready - 1][0]) { ready[nready - 1][0] = pend[i][0]; ready[nready - 1][1] += pend[i][1]; }
+                else ready_range(pend[i][0], pend[i][1]);
+            }
+            npend = 0;
+        }
         n = 0; pending_blocks = 0;
         return rc;
     }
@@ -1013,12 +1044,13 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
         return 0;
     };
     WgradDefer wd;
-    const bool chain = wgrad_chain_ok(*sh, *w) && af == nullptr;
+    const bool chain = wgrad_chain_ok(*sh, *w);
     if (chain) {
         wd.ring = w->wg_ring; wd.slots = w->wg_slots < 6 ? w->wg_slots : 6; wd.splitk = w->dgrad_splitk > 0 ? w->dgrad_splitk : 1;
         wd.M = (size_t)sh->Bb * sh->N; wd.D = sh->D; wd.Hd = sh->hidden;
         wd.dxa_cur = w->dx_a_bf;
         wd.accumulate = w->wg_overwrite ? 0 : 1;
+        wd.af = af; wd.n_filled = &n_filled;
         if (w->ln_aux != nullptr && w->ln_rowstat != nullptr && !s3d_deterministic()) {
             // weights-only vectors of the row statistics for every dense block of this call, in call order (one launch)
             S3dLnAuxLayer layers[32];
@@ -1041,9 +1073,32 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     for (int i = first; i >= last; --i) {
         const bool cls_only = sh->cls_only_block == i + 1;
         if (cls_only) S3D_REQUIRE(w->dx_b_cls && w->dx_b_bf_cls && w->datt_cls, "s3d_blocks_bwd: cls_only_block needs the *_cls scratch buffers");
-        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, af ? &fq : nullptr, chain ? &wd : nullptr, i == last));
+        const bool on_chain = chain && !cls_only;
+        S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, (af && !chain) ? &fq : nullptr, chain ? &wd : nullptr, i == last));
         if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
-        if (af) {
+        if (af && chain) {
+            // dgrad chain: a block's GEMM gradients are final once the grouped launch that holds its wgrads has run (WgradDefer::flush moves
+            // its ranges from `pend` to `ready`); a block off the chain (class rows only) is final right here
+            const S3dBlockGrads& b = g[i];
+            const long D = sh->D, Hd = sh->hidden;
+            struct T { float* q; long n; } t[8] = {{b.qkv_w, 3 * D * D}, {b.qkv_b, 3 * D}, {b.proj_w, D * D}, {b.proj_b, D},
+                                                   {b.fc1_w, Hd * D}, {b.fc1_b, Hd}, {b.fc2_w, D * Hd}, {b.fc2_b, D}};
+            for (int x = 1; x < 8; ++x) for (int y = x; y > 0 && t[y].q < t[y - 1].q; --y) { const T tmp = t[y]; t[y] = t[y - 1]; t[y - 1] = tmp; }
+            long off = -1, len = 0;
+            bool whole = true;
+            for (int x = 0; x < 8; ++x) {
+                const long o = t[x].q - af->g;
+                if (t[x].q == nullptr || o < 0 || (o & 3) != 0 || (t[x].n & 3) != 0 || (off >= 0 && o != off + len)) { whole = false; break; }
+                if (off < 0) off = o;
+                len += t[x].n;
+            }
+            if (whole && off >= 0) {                   // (the arena keeps a block's GEMM parameters contiguous; anything else is left to the caller)
+                // NOTE: a chain block's ranges were registered BEFORE its flush when the flush happened inside block_bwd (group full / end of
+                // call): those gradients are final as well -- the flush has been enqueued -- so they go straight to `ready`
+                if (on_chain && wd.pending_blocks > 0) wd.defer_range(off, len);
+                else wd.ready_range(off, len);
+            }
+        } else if (af) {
             S3D_TRY(drain());
             fq.reset();
             if (i > last) {

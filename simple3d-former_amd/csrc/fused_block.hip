@@ -821,7 +821,7 @@ int launch_attn_bwd(const FusedAttnBwdArgs& a, hipStream_t s) {
     s3d_prof_begin(KEY, 2.0 * M * D * D + 10.0 * a.Bb * a.N * a.N * D, s);          // proj dgrad + (s, dp, dq, dk, dv) of every head
     hipLaunchKernelGGL((blk_attn_bwd_kernel<D>), dim3(grid), dim3(BW_THREADS), LDS, s, a);
     s3d_prof_end(s);
-    S3D_CHECK_LAUNCH_V("blk_attn_bwd", D);
+    S3D_CHECK_LAUNCH_V("blk_attn_bwd", D + (a.st_s1 ? 100000 : 0));
     return 0;
 }
 }  // namespace

@@ -835,11 +835,14 @@ class VoxelEngine:
                 # the rest in one launch at the end (bitwise the results of adam_step)
                 self.adam_begin()
                 self._adam_fill_begin()
+                ws = self.workspace(B)
+                ws.sc1.wg_overwrite = 1 if WGRAD_OVERWRITE else 0
                 try:
                     self.backward(B)
                     self._adam_fill_finish()
                 finally:
                     self._fill = None
+                    ws.sc1.wg_overwrite = 0
                 self._refresh_conv_planes()
                 return loss
             # the fused step owns the gradient arena (zeroed by the previous step's Adam, no accumulation across backward calls unless the

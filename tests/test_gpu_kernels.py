@@ -278,8 +278,12 @@ def test_fused_layernorm_backward_chain_row_statistics(rows, D, Hd):
     s1_ref, s2_ref = gg.mean(1), (gg * xh.double()).mean(1)
     scale = float(gg.abs().mean())
     assert float((rs[0].double().cpu() - s1_ref).abs().max()) < 2e-4 * scale, 's1'
-    # s2 carries the bf16 rounding of the saved pre-activation (1e-4 of |dy gamma| by the estimate in bwd_gemm.hip)
-    assert float((rs[1].double().cpu() / D - s2_ref).abs().max()) < 1e-3 * scale, 's2'
+    # s2: the kernel's arithmetic exactly (the dot of the rounded dh with the bf16 pre-activation minus c) ...
+    s2_formula = (dh.double() * (hpre.double() - c.double())).sum(1).cpu() / D
+    assert float((rs[1].double().cpu() / D - s2_formula).abs().max()) < 2e-5 * float(s2_formula.abs().max() + scale), 's2 arithmetic'
+    # ... and the identity it stands for, up to the bf16 rounding of the saved pre-activation / the weight's low plane: ~2^-9 sqrt(K) / D of
+    # |dh| |z| per row (1e-4 of |dy gamma| at cfg-2's K = 1536, D = 384; the three-tile shapes here average less)
+    assert float((rs[1].double().cpu() / D - s2_ref).abs().max()) < (1e-3 if Hd >= 512 else 4e-3) * scale, 's2'
     # consumer: fc1 dgrad + norm2 backward epilogue
     dx = torch.full((rows, D), float('nan'), device=DEV); dx_bf = torch.full((rows, D), float('nan'), dtype=torch.bfloat16, device=DEV)
     nty = (rows + 63) // 64
@@ -291,7 +295,9 @@ def test_fused_layernorm_backward_chain_row_statistics(rows, D, Hd):
     L.check(lib.s3d_gemm_dgrad_lnbwd(ctypes.byref(gb), ctypes.byref(ln), ctypes.byref(st2), L.current_stream()), 'dgrad_lnbwd')
     rstd_d, xh_d = rstd.double(), xh.double()
     ref_dx = rstd_d[:, None] * (gg - s1_ref[:, None] - xh_d * s2_ref[:, None]) + dres.double()
-    assert rel_err(dx, ref_dx) < 5e-4, 'dx'              # (s2 from the bf16-rounded pre-activation: 2.2e-4 measured at 1664 x 384)
+    assert rel_err(dx, ref_dx) < (5e-4 if Hd >= 512 else 4e-3), 'dx'    # (s2 from the bf16-rounded pre-activation: 2.2e-4 measured at 1664 x 384)
+    ref_dx_k = rstd_d[:, None] * (gg - rs[0].double().cpu()[:, None] - xh_d * (rs[1].double().cpu() / D)[:, None]) + dres.double()
+    assert rel_err(dx, ref_dx_k) < 2e-5, 'dx with the statistics the kernel was given'
     assert rms_err(dx_bf.double(), ref_dx) < 3e-3
     assert rel_err(part[:nty, 0].double().sum(0), (gdy.cpu() * xh_d).sum(0)) < 2e-5, 'dgamma partials'
     assert rel_err(part[:nty, 1].double().sum(0), gdy.cpu().sum(0)) < 2e-5, 'dbeta partials'
