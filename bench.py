@@ -67,6 +67,15 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0           # /opt/skills/guides/MI355X_MICROARCH.m
 EPI_NAMES = {0: 'bf16_bias', 1: 'gelu', 2: 'resid', 3: 'token', 4: 'f32', 5: 'dgelu', 6: 'atomic', 7: 'relu', 8: 'drelu'}
 
 
+# round 5 (csrc/bwd_gemm.hip): key family -> (description, rocprofv3 name stem)
+R5_KERNELS = {
+    10: ('wgrad_group_kernel<128x128 TN, full k, grouped layers, plain stores> (bf16)', 'wgrad_group_kernel<4, 32'),
+    11: ('dgrad_kernel<64x64 NN, k-slices as fp32 planes> (bf16)', 'dgrad_kernel<0, 3'),
+    12: ('dgrad_kernel<64x64 NN, gelu\' + LayerNorm row statistics> (bf16)', 'dgrad_kernel<1, 3'),
+    13: ('dgrad_kernel<64x64 NN, LayerNorm-backward epilogue, two wave groups> (bf16)', 'dgrad_kernel<2, 3'),
+}
+
+
 def _key_fields(key):
     key = int(key)
     kind, rest = key // 10 ** 11, key % 10 ** 11
@@ -82,6 +91,10 @@ def kernel_name(key):
         return f'blk_attn_kernel<{tail}> (fused norm1 + qkv + attention, split3)'
     if kind == 8:
         return f'blk_mlp1_kernel<{tail}> (fused norm2 + fc1 + GELU, split3)'
+    if kind == 9:
+        return f'blk_attn_bwd_kernel<{tail}> (fused proj dgrad + attention backward)'
+    if kind in R5_KERNELS:
+        return R5_KERNELS[kind][0]
     epi = EPI_NAMES.get(tail % 100, tail % 100)
     ta, tb, sp = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10
     lay = f'{"T" if ta else "N"}{"T" if not tb else "N"}'
@@ -105,6 +118,10 @@ def rocprof_name(key):
     kind, b0, b1, tail = _key_fields(key)
     if kind in (7, 8):
         return f'{"blk_attn_kernel" if kind == 7 else "blk_mlp1_kernel"}<{tail}>'
+    if kind == 9:
+        return f'blk_attn_bwd_kernel<{tail}>'
+    if kind in R5_KERNELS:
+        return R5_KERNELS[kind][1]
     tf = lambda v: 'true' if v else 'false'
     ta, tb, sp, epi = (tail // 10000) % 10, (tail // 1000) % 10, (tail // 100) % 10, tail % 100
     if kind == 2:

@@ -211,7 +211,7 @@ ADAM_FILL = os.environ.get('S3D_ADAM_FILL', '0') == '1'
 # Round 5: the small-batch backward as a dgrad chain + grouped wgrads (capi.hip: block_bwd_chain; S3dBlockScratch::wg_ring).  WGRAD_GROUP =
 # blocks per grouped wgrad launch (= ring slots; 0: the paired dgrad + wgrad launches of rounds 1 - 4), DGRAD_SPLITK = k-slices of the
 # fc1 / qkv dgrads (their planes are added by the LayerNorm backward).
-WGRAD_GROUP = int(os.environ.get('S3D_WGRAD_GROUP', '3'))
+WGRAD_GROUP = int(os.environ.get('S3D_WGRAD_GROUP', '4'))
 DGRAD_SPLITK = int(os.environ.get('S3D_DGRAD_SPLITK', '3'))
 LN_BWD_FUSE = os.environ.get('S3D_LN_BWD_FUSE', '1') != '0'             # LayerNorm backward as the epilogue of the fc1 / qkv dgrads (row statistics)
 WGRAD_OVERWRITE = os.environ.get('S3D_WGRAD_OVERWRITE', '1') != '0'     # train_step: grouped wgrads store instead of read-modify-write
