@@ -553,6 +553,13 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch override (non-headline experiments)')
     ap.add_argument('--wire', choices=['auto', 'fp32', 'bf16'], default='auto',
                     help="gradient all-reduce format: fp32 (DDP's arithmetic; auto = fp32) or bf16 (half the xGMI bytes, narrower than the reference)")
+    ap.add_argument('--single-update', action='store_true',
+                    help='N > 1 path: wait for every bucket, then ONE Adam launch (rounds 1 - 4) instead of Adam bucket by bucket as the all-reduces finish')
+    ap.add_argument('--bucket-blocks', type=int, default=None, help='uniform gradient buckets of this many blocks (default: geometric, --buckets)')
+    ap.add_argument('--standin-latency-us', type=float, default=0.0, help='fixed start-up cost added to every stand-in collective')
+    ap.add_argument('--standin-gbps', type=float, default=0.0,
+                    help='one-rank diagnostic (with --force-collectives): every bucket all-reduce is replaced by a copy kernel of that bus bandwidth on a '
+                         'side stream / graph branch -- what a LIVE collective branch costs the captured step (profiles/r05_dp_branch_tax.txt)')
     ap.add_argument('--event-graph', action='store_true',
                     help='ONE graph with an event-record node behind every backward segment, collectives launched from a side stream on '
                          'those events (measured slower than the default on this runtime: one graph per segment, collectives in between)')
@@ -603,7 +610,8 @@ def main():
     trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
                                   force_collectives=args.force_collectives,
                                   graph_collectives={'auto': 'auto', 'on': True, 'off': False}[args.graph_collectives], wire=wire,
-                                  event_graph=args.event_graph)
+                                  event_graph=args.event_graph, sliced_adam=not args.single_update, standin_gbps=args.standin_gbps,
+                                  blocks_per_bucket=args.bucket_blocks, standin_latency_us=args.standin_latency_us)
     trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
     ident = rccl_identity(dev, world)
     if world > 1:

@@ -131,7 +131,9 @@ int s3d_gemm_ln_fusable(int split, const S3dGemmArgs* args);
  * otherwise leaves col_sums NULL and lets s3d_batchnorm_fwd compute its own statistics. */
 int s3d_gemm_col_sums_ok(int split, int M, int N);
 
-/* Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
+/* ---- NOT part of the operator ABI: measurement / test aids (s3d_prof_*, s3d_cov_*, s3d_graph_marker / s3d_graph_events_at_markers,
+ * s3d_debug_*).  They exist for bench.py and the test suite, may change between versions, and a foreign-language binding should not bind them.
+ * Measurement aid (bench.py roofline leg): when enabled, every GEMM launch is bracketed by HIP events recorded on the
  * launch stream.  s3d_prof_collect synchronises those events and fills rows of 4 doubles
  * {kernel key, launches, total ms, total algorithmic flops (2*M*N*K)}; key digits = 1|BM|BN|ta|tb|split|epilogue for a
  * single problem, 2|BM dgrad|BM wgrad|000|epilogue for a fused dgrad + wgrad launch (decoded in bench.py).  Returns the number
@@ -381,6 +383,9 @@ int s3d_event_destroy(void* event);
 int s3d_graph_marker(int id, s3d_stream_t capturing_stream);
 int s3d_graph_events_at_markers(void* hip_graph, void* const* events, int n);
 int s3d_stream_wait_event(s3d_stream_t waiting_stream, void* event);
+/* NOT part of the operator ABI -- measurement aid: copies nbytes (16-byte multiple) with 16 workgroups paced to gbps GB/s (a stand-in
+ * with the duration and footprint of a ring all-reduce on one GPU; simple3d-former_amd/parallel.py, profiles/r05_dp_branch_tax.txt). */
+int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ timm Block
  * One pre-norm transformer block: x += attn(norm1(x)); x += mlp(norm2(x))  (timm==0.3.2 Block.forward, invoked by
@@ -453,9 +458,12 @@ typedef struct S3dBlockScratch {  /* backward scratch shared by all blocks */
      * dgrad_splitk (1 .. 4; 0 = 1): k-slices of the fc1 / qkv dgrads on that path; dxn must then hold dgrad_splitk planes of [M][D]. */
     uint16_t* wg_ring; int wg_slots; int dgrad_splitk;
     /* ... and the LayerNorm backward kernels of that chain folded into the dgrads (see S3dRowStats): ln_aux = per block [u2 | c2 | u1 | c1] =
-     * 2 * (hidden + 3 D) floats (filled by s3d_blocks_bwd itself, one s3d_ln_aux launch per call), ln_rowstat = 4 * M floats, ZERO when the
+     * 2 * (hidden + 3 D) floats, block i at i * that (filled by s3d_blocks_bwd itself, one s3d_ln_aux launch per call, or by s3d_blocks_ln_aux), ln_rowstat = 4 * M floats, ZERO when the
      * first backward runs (the chain's own launches clear what they have consumed).  Both NULL: stand-alone LayerNorm backward launches. */
     float* ln_aux; float* ln_rowstat;
+    int ln_aux_valid;                             /* 1: the caller has run s3d_blocks_ln_aux for the blocks of this call since the last parameter
+                                                   * update (a backward issued as several s3d_blocks_bwd calls computes the vectors once); 0: every call
+                                                   * computes the vectors of its own blocks.  ln_aux is indexed by block: depth * 2 * (hidden + 3 D) floats. */
     int wg_overwrite;                             /* 1: the grouped wgrads STORE dW / db instead of adding to them (the caller knows the gradient
                                                    * arena is not accumulating across backward calls: no read of the old values) */
 } S3dBlockScratch;
@@ -484,6 +492,10 @@ int s3d_blocks_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, con
 int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockGrads* grads,
                    const S3dBlockActs* acts, const S3dBlockScratch* scratch, int first, int last,
                    s3d_stream_t stream);
+/* the weights-only row-statistics vectors (S3dBlockScratch::ln_aux) of blocks last .. first in one launch; set scratch->ln_aux_valid = 1 for the
+ * s3d_blocks_bwd calls that follow, until the parameters change */
+int s3d_blocks_ln_aux(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockScratch* scratch, int first, int last,
+                      s3d_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ group_embed
  * nn.TransformerEncoderLayer(d_model=D, dim_feedforward=D, nhead=4) exactly as the reference builds and feeds it

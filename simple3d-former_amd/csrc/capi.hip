@@ -240,8 +240,8 @@ struct WgradDefer {
     S3dWgradItem items[24];
     int n = 0, pending_blocks = 0, next = 0;
     const bf16_t* dxa_cur = nullptr;               // d(x_out) (bf16) of the block about to run: the caller's dx_a_bf, then ring slots
-    const float* aux = nullptr;                    // fused LayerNorm backward: the call's [u2 | c2 | u1 | c1] vectors, block by block in call order
-    int aux_index = 0;
+    const float* aux = nullptr;                    // fused LayerNorm backward: the [u2 | c2 | u1 | c1] vectors, indexed by block
+    int block = 0;                                 // the block about to run
     // optimizer update riding on the grouped launches (S3dAdamFill): arena ranges whose gradients are final -- the GEMM parameters of the blocks
     // whose wgrads an EARLIER launch has finished -- go to the next launch as filler shares; ranges of the blocks it computes itself follow after it
     const S3dAdamFill* af = nullptr;
@@ -442,7 +442,7 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
     // fused: the two LayerNorm backward launches run as epilogues of the fc1 / qkv dgrads (bwd_gemm.hip, "Row statistics"): four launches
     // per block.  aux = this block's [u2 | c2 | u1 | c1]; rowstat = [norm2: s1, s2 | norm1: s1, s2], each [M]
     const bool fused = wd.aux != nullptr;
-    const float* aux = fused ? wd.aux + (size_t)wd.aux_index * 2 * (Hd + 3 * D) : nullptr;
+    const float* aux = fused ? wd.aux + (size_t)wd.block * 2 * (Hd + 3 * D) : nullptr;
     float* rs = w.ln_rowstat;
     const int nty = (int)((M + 63) / 64);
     S3dRowStats st;
@@ -515,7 +515,6 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
     }
     wd.next = next;
     wd.dxa_cur = dxa_next;
-    ++wd.aux_index;
     return 0;
 }
 
@@ -648,6 +647,24 @@ int enc_bwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncGrads& gr,
 namespace {
 // the dgrad chain + grouped wgrads replace the paired launches where the fused attention backward runs (small token counts, dense
 // blocks, plain-bf16 backward) and the caller has provided the ring
+// weights-only vectors of the row statistics (bwd_gemm.hip) for the dense blocks last .. first, indexed by block: one launch per <= 16 blocks
+int blocks_ln_aux(const S3dBlockShape& sh, const S3dBlockParams* p, const S3dBlockScratch& w, int first, int last, hipStream_t s) {
+    S3dLnAuxLayer layers[32];
+    int nl = 0;
+    const size_t per = 2 * ((size_t)sh.hidden + 3 * (size_t)sh.D);
+    for (int i = first; i >= last; --i) {
+        if (sh.cls_only_block == i + 1) continue;
+        float* base = w.ln_aux + (size_t)i * per;
+        layers[nl++] = S3dLnAuxLayer{p[i].fc1_w_hi, p[i].fc1_w_lo, p[i].fc1_b, p[i].ln2_w, p[i].ln2_b, base, base + sh.hidden, sh.hidden};
+        layers[nl++] = S3dLnAuxLayer{p[i].qkv_w_hi, p[i].qkv_w_lo, p[i].qkv_b, p[i].ln1_w, p[i].ln1_b, base + 2 * sh.hidden, base + 2 * sh.hidden + 3 * sh.D, 3 * sh.D};
+        if (nl == 32 || i == last) {
+            S3D_TRY(s3d_launch_ln_aux(layers, nl, sh.D, s));
+            nl = 0;
+        }
+    }
+    if (nl) S3D_TRY(s3d_launch_ln_aux(layers, nl, sh.D, s));
+    return 0;
+}
 bool wgrad_chain_ok(const S3dBlockShape& sh, const S3dBlockScratch& w) {
     if (w.wg_ring == nullptr || w.wg_slots < 1 || w.dx_a_lo != nullptr || bwd_streams_enabled()) return false;
     if (sh.fuse != 0 || !s3d_fused_attn_bwd_ok(sh.Bb, sh.N, sh.D, sh.H)) return false;
@@ -930,6 +947,30 @@ int s3d_graph_marker(int id, s3d_stream_t s) {
     S3D_CHECK_LAUNCH("graph_marker");
     return 0;
 }
+// Measurement aid (parallel.py: BucketedGradReducer stand-in): copies nbytes with a few workgroups (gbps / 5) paced to `gbps` GB/s against the 100 MHz
+// wall clock -- the footprint (a few CUs) and duration a ring all-reduce of the same bytes has on RCCL's stream, for measuring what a live
+// side branch costs a captured step graph on one GPU.
+__global__ __launch_bounds__(256) void s3d_paced_copy_kernel(u32x4* dst, const u32x4* src, long n16, float bytes_per_tick) {
+    const long per = (n16 + gridDim.x - 1) / gridDim.x, b = (long)blockIdx.x * per, e = b + per < n16 ? b + per : n16;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    long chunk = 0;
+    for (long i = b; i < e; i += 256, ++chunk) {
+        if (i + threadIdx.x < e) dst[i + threadIdx.x] = src[i + threadIdx.x];
+        const float due = (float)((chunk + 1) * 4096) / bytes_per_tick;
+        while ((float)(__builtin_amdgcn_s_memrealtime() - t0) < due) __builtin_amdgcn_s_sleep(2);
+    }
+}
+int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t s) {
+    S3D_REQUIRE(dst && src && nbytes >= 16 && (nbytes & 15) == 0 && gbps > 0.f, "s3d_debug_paced_copy: 16-byte multiples, a positive rate");
+    // one workgroup of this loop moves ~7 GB/s (measured: 16 workgroups 118 GB/s): enough of them that the pacing, not the copy, sets the rate
+    int wgs = (int)(gbps / 5.0f) + 1;
+    wgs = wgs < 8 ? 8 : wgs > 128 ? 128 : wgs;
+    const float bytes_per_tick = gbps * 10.0f / wgs;                    // GB/s = bytes per ns; one tick of the 100 MHz clock = 10 ns
+    hipLaunchKernelGGL(s3d_paced_copy_kernel, dim3(wgs), dim3(256), 0, st(s), static_cast<u32x4*>(dst), static_cast<const u32x4*>(src), nbytes / 16,
+                       bytes_per_tick);
+    S3D_CHECK_LAUNCH("paced_copy");
+    return 0;
+}
 int s3d_graph_events_at_markers(void* graph, void* const* events, int n) {
     S3D_REQUIRE(graph && events && n >= 1 && n <= 64, "s3d_graph_events_at_markers: graph, 1..64 events");
     hipGraph_t g = static_cast<hipGraph_t>(graph);
@@ -1052,28 +1093,15 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
         wd.accumulate = w->wg_overwrite ? 0 : 1;
         wd.af = af; wd.n_filled = &n_filled;
         if (w->ln_aux != nullptr && w->ln_rowstat != nullptr && !s3d_deterministic()) {
-            // weights-only vectors of the row statistics for every dense block of this call, in call order (one launch)
-            S3dLnAuxLayer layers[32];
-            int nl = 0;
-            const size_t per = 2 * ((size_t)sh->hidden + 3 * (size_t)sh->D);
-            for (int i = first; i >= last && nl + 2 <= 32; --i) {
-                if (sh->cls_only_block == i + 1) continue;
-                float* base = w->ln_aux + (size_t)(nl / 2) * per;
-                layers[nl++] = S3dLnAuxLayer{p[i].fc1_w_hi, p[i].fc1_w_lo, p[i].fc1_b, p[i].ln2_w, p[i].ln2_b, base, base + sh->hidden, sh->hidden};
-                layers[nl++] = S3dLnAuxLayer{p[i].qkv_w_hi, p[i].qkv_w_lo, p[i].qkv_b, p[i].ln1_w, p[i].ln1_b, base + 2 * sh->hidden, base + 2 * sh->hidden + 3 * sh->D, 3 * sh->D};
-            }
-            int dense = 0;
-            for (int i = first; i >= last; --i) dense += sh->cls_only_block == i + 1 ? 0 : 1;
-            if (nl == 2 * dense && nl > 0) {                    // (more than 16 dense blocks in one call: stand-alone LayerNorm backward)
-                S3D_TRY(s3d_launch_ln_aux(layers, nl, sh->D, st(s)));
-                wd.aux = w->ln_aux;
-            }
+            if (!w->ln_aux_valid) S3D_TRY(blocks_ln_aux(*sh, p, *w, first, last, st(s)));
+            wd.aux = w->ln_aux;
         }
     }
     for (int i = first; i >= last; --i) {
         const bool cls_only = sh->cls_only_block == i + 1;
         if (cls_only) S3D_REQUIRE(w->dx_b_cls && w->dx_b_bf_cls && w->datt_cls, "s3d_blocks_bwd: cls_only_block needs the *_cls scratch buffers");
         const bool on_chain = chain && !cls_only;
+        wd.block = i;
         S3D_TRY(block_bwd(*sh, p[i], g[i], a[i], *w, st(s), partial ? &lp : nullptr, cls_only, (af && !chain) ? &fq : nullptr, chain ? &wd : nullptr, i == last));
         if (lp.n + 2 > 64) S3D_TRY(lp.flush(*w, sh->D, st(s)));
         if (af && chain) {
@@ -1130,6 +1158,11 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     }
     if (af) { S3D_TRY(drain()); *af->n_filled = n_filled; }
     return lp.flush(*w, sh->D, st(s));
+}
+
+int s3d_blocks_ln_aux(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockScratch* w, int first, int last, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && w && w->ln_aux && first >= last && last >= 0, "s3d_blocks_ln_aux: shape, params, scratch->ln_aux, first >= last >= 0");
+    return blocks_ln_aux(*sh, p, *w, first, last, st(s));
 }
 
 int s3d_encoder_layer_fwd(const S3dEncShape* sh, const S3dEncParams* p, const S3dEncActs* a, s3d_stream_t s) {

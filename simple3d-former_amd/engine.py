@@ -258,6 +258,7 @@ class _BlockScratch:
             L.fill(self.c, dx_a_lo=self.dx_a_lo, dx_b_lo=self.dx_b_lo, dh_lo=self.dh_lo, dqkv_lo=self.dqkv_lo, datt_lo=self.datt_lo)
         self.M, self.D = M, D
         self.wg_ring = None
+        self.ln_aux = None
         if wgrad_ring and not precise:
             slots, splitk, slot_bytes = wgrad_ring
             self.wg_ring = torch.empty(slots * slot_bytes, dtype=torch.uint8, device=device)
@@ -350,6 +351,7 @@ class VoxelEngine:
         self.set_optimizer(lr=lr, betas=betas, eps=eps)
         self._ws = {}
         self._graphs = {}
+        self.grads_owned = False            # True while a fused step that owns the gradient arena runs its backward (blocks_backward_range)
         self.capture_epoch = 0              # bumped whenever something baked into captured graphs changes (set_dropout)
         self.world_size = 1
         # group_embed encoder-layer dropout: 0 = eval mode; set_dropout(0.1) = the reference's training mode (hash-based masks)
@@ -698,18 +700,27 @@ class VoxelEngine:
             if on_segment is not None:
                 on_segment(i)
 
-    def grad_buckets(self, n_buckets=3):
+    def grad_buckets(self, n_buckets=3, blocks_per_bucket=None):
         """Splits the backward into `n_buckets` block ranges and returns (segments, [(start, end) arena slices]) such
         that slice i holds exactly the gradients that are final once segment i has run (arena is in forward order).
         Bucket sizes shrink geometrically in backward order (depth 12, 4 buckets: blocks 11-6, 5-3, 2-1, 0 + tokenizer):
         the all-reduce of the LAST bucket cannot hide behind any compute, so it is the smallest; the first one has the
-        whole rest of backward to hide behind, so it is the largest."""
-        n = max(1, min(n_buckets, self.depth))
-        # boundaries (in blocks from the input side): depth / 2^(n-1), ..., depth / 2, depth
-        bounds = [0] + [max(k, self.depth // 2 ** (n - k)) for k in range(1, n)] + [self.depth]
-        for k in range(1, n + 1):                       # strictly increasing even for tiny depths
-            bounds[k] = max(bounds[k], bounds[k - 1] + 1)
-        bounds[n] = self.depth
+        whole rest of backward to hide behind, so it is the largest.
+        blocks_per_bucket = k: UNIFORM buckets of k blocks instead (depth 12, k = 2: 11-10 | 9-8 | .. | 1-0 + tokenizer) -- the wire then
+        starts after k blocks of backward instead of after half of it, which matters when the wire time of the whole gradient is about
+        as long as the backward itself (cfg-2: 0.6 ms of fp32 ring all-reduce against a 0.7 ms backward, profiles/r05_dp_branch_tax.txt)."""
+        if blocks_per_bucket:
+            k = max(1, int(blocks_per_bucket))
+            n = (self.depth + k - 1) // k
+            bounds = [max(0, self.depth - (n - j) * k) for j in range(n)] + [self.depth]
+            bounds[0] = 0
+        else:
+            n = max(1, min(n_buckets, self.depth))
+            # boundaries (in blocks from the input side): depth / 2^(n-1), ..., depth / 2, depth
+            bounds = [0] + [max(k, self.depth // 2 ** (n - k)) for k in range(1, n)] + [self.depth]
+            for k in range(1, n + 1):                       # strictly increasing even for tiny depths
+                bounds[k] = max(bounds[k], bounds[k - 1] + 1)
+            bounds[n] = self.depth
         segments, slices = [], []
         end = self.arena.numel
         for k in range(n, 0, -1):
@@ -724,11 +735,21 @@ class VoxelEngine:
         fill = getattr(self, '_fill', None)
         if fill is not None:
             ws.sc1.adam_fill = ctypes.addressof(fill['args'])
+        # the caller owns the gradient arena for this step (train_step, the data-parallel trainers: zeroed by the previous Adam, nothing else
+        # accumulates into it): the grouped wgrads store instead of read-modify-write
+        ws.sc1.wg_overwrite = 1 if (self.grads_owned and WGRAD_OVERWRITE and not self.group and self.images is None) else 0
+        if (first, last) != (self.depth - 1, 0) and ws.scratch.ln_aux is not None and not self.group:
+            # a backward issued in segments: the weights-only vectors of the fused LayerNorm backward once, in front of the first segment
+            if first == self.depth - 1:
+                L.check(self.lib.s3d_blocks_ln_aux(ctypes.byref(ws.blocks.shape), self.bparams, ctypes.byref(ws.sc1), self.depth - 1, 0,
+                                                   L.current_stream()), 'blocks_ln_aux')
+            ws.sc1.ln_aux_valid = 1
         try:
             L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
                                             ctypes.byref(ws.sc1), first, last, L.current_stream()), 'blocks_bwd')
         finally:
             ws.sc1.adam_fill = None
+            ws.sc1.ln_aux_valid = 0
         if fill is not None:
             n = fill['n'].value
             fill['done'] += [(int(fill['ranges'][2 * i]), int(fill['ranges'][2 * i + 1])) for i in range(n)]
@@ -804,13 +825,18 @@ class VoxelEngine:
         """optimizer.step() bookkeeping (step count, bias corrections) once per step; adam_apply slices follow it."""
         L.check(self.lib.s3d_adam_begin(L.ptr(self.adam_state), L.current_stream()), 'adam begin')
 
-    def adam_apply(self, start, end, zero_grad=True, max_workgroups=0):
-        """Adam on the arena slice [start, end) on the current stream (gradients of the slice must be final there)."""
+    def adam_apply(self, start, end, zero_grad=True, max_workgroups=0, wire=None):
+        """Adam on the arena slice [start, end) on the current stream (gradients of the slice must be final there).  wire: the flat bf16
+        gradient buffer of the data-parallel wire format (the slice's gradient is read from it, the fp32 arena only zeroed)."""
         a = self.arena
         off = lambda t, b: ctypes.c_void_p(t.data_ptr() + b * start)
-        L.check(self.lib.s3d_adam_apply(off(a.p, 4), off(a.g, 4), None, off(a.m, 4), off(a.v, 4), off(a.hi, 2), off(a.lo, 2),
-                                        ctypes.c_long(end - start), L.ptr(self.adam_state), 1 if zero_grad else 0,
-                                        int(max_workgroups), L.current_stream()), 'adam slice')
+        L.check(self.lib.s3d_adam_apply(off(a.p, 4), off(a.g, 4), None if wire is None else off(wire, 2), off(a.m, 4), off(a.v, 4),
+                                        off(a.hi, 2), off(a.lo, 2), ctypes.c_long(end - start), L.ptr(self.adam_state),
+                                        1 if zero_grad else 0, int(max_workgroups), L.current_stream()), 'adam slice')
+
+    def adam_end(self):
+        """Behind the last adam_apply of a step: what adam_step does after its kernel (the padded tokenizer-weight planes)."""
+        self._refresh_conv_planes()
 
     def pack_grads(self, start, end, wire):
         """gradient arena [start, end) -> bf16 wire buffer [start, end) (round to nearest even), on the current stream."""
@@ -835,24 +861,22 @@ class VoxelEngine:
                 # the rest in one launch at the end (bitwise the results of adam_step)
                 self.adam_begin()
                 self._adam_fill_begin()
-                ws = self.workspace(B)
-                ws.sc1.wg_overwrite = 1 if WGRAD_OVERWRITE else 0
+                self.grads_owned = True
                 try:
                     self.backward(B)
                     self._adam_fill_finish()
                 finally:
                     self._fill = None
-                    ws.sc1.wg_overwrite = 0
+                    self.grads_owned = False
                 self._refresh_conv_planes()
                 return loss
             # the fused step owns the gradient arena (zeroed by the previous step's Adam, no accumulation across backward calls unless the
             # image branch adds its own backward): the grouped wgrads may store instead of read-modify-write
-            ws = self.workspace(B)
-            ws.sc1.wg_overwrite = 1 if (WGRAD_OVERWRITE and self.images is None and not self.group) else 0
+            self.grads_owned = True
             try:
                 self.backward(B)
             finally:
-                ws.sc1.wg_overwrite = 0
+                self.grads_owned = False
             self.adam_step(zero_grad=True)
             return loss
         main = torch.cuda.current_stream()

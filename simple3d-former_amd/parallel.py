@@ -32,13 +32,21 @@ class BucketedGradReducer:
     prepare(start, end), if given, runs on the current stream right before bucket [start, end) is handed to the collective (the
     bf16 wire format packs the finished fp32 slice into the flat bf16 tensor there)."""
 
-    def __init__(self, flat_grad, slices, group=None, force=False, prepare=None):
+    def __init__(self, flat_grad, slices, group=None, force=False, prepare=None, standin_gbps=0.0, standin_latency_us=0.0):
+        """standin_gbps > 0 (diagnostics, one rank): instead of the collective -- which launches NOTHING at world size 1 -- bucket i is
+        copied into a scratch buffer by a few workgroups paced to about that rate, on a side stream forked from the current one: a kernel of
+        the duration and footprint a ring all-reduce of the bucket would have, so that the cost of a LIVE side branch in a captured step
+        graph (profiles/r03_graph_branch_probe.txt) can be measured without peers (profiles/r05_dp_branch_tax.txt)."""
         self.flat, self.slices, self.group = flat_grad, list(slices), group
         self.force = force                   # issue the collective even at world size 1 (exercises the RCCL path)
         self.prepare = prepare
         self.skip = False                    # diagnostics only (bench.py): time the step with the collectives suppressed
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._works = []
+        self._works = {}
+        self.standin_gbps = float(standin_gbps)
+        self.standin_latency_us = float(standin_latency_us)             # fixed cost per collective added to the stand-in (ring start-up)
+        self._standin_stream = None
+        self._standin_buf = None
         covered = sorted(self.slices)
         assert covered[0][0] == 0 and covered[-1][1] == flat_grad.numel() and \
             all(a[1] == b[0] for a, b in zip(covered, covered[1:])), 'buckets must tile the arena exactly'
@@ -49,12 +57,43 @@ class BucketedGradReducer:
             self.prepare(s, e)
         if (self.world == 1 and not self.force) or self.skip:
             return
-        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.standin_gbps > 0 and self.world == 1 and self.flat.is_cuda:
+            self._works[i] = self._standin(s, e)
+            return
+        self._works[i] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _standin(self, s, e):
+        import ctypes
+        from . import _lib as L
+        if self._standin_stream is None:
+            self._standin_stream = torch.cuda.Stream()
+            self._standin_buf = torch.empty_like(self.flat)
+        side, cur = self._standin_stream, torch.cuda.current_stream()
+        side.wait_stream(cur)                                           # fork: the bucket is final on the compute stream
+        nbytes = (e - s) * self.flat.element_size()
+        # duration = latency + bytes / rate, expressed as one rate for the paced copy
+        gbps = self.standin_gbps
+        if self.standin_latency_us > 0:
+            gbps = nbytes / (self.standin_latency_us * 1e3 + nbytes / self.standin_gbps)
+        with torch.cuda.stream(side):
+            L.check(L.lib().s3d_debug_paced_copy(ctypes.c_void_p(self._standin_buf.data_ptr() + s * self.flat.element_size()),
+                                                 ctypes.c_void_p(self.flat.data_ptr() + s * self.flat.element_size()),
+                                                 ctypes.c_long(nbytes), ctypes.c_float(gbps), L.current_stream()), 'paced_copy')
+        return side
+
+    def wait_one(self, i):
+        """The current stream waits for bucket i's collective (no host block on GPU backends); other buckets stay in flight."""
+        w = self._works.pop(i, None)
+        if w is None:
+            return
+        if isinstance(w, torch.cuda.Stream):
+            torch.cuda.current_stream().wait_stream(w)                  # join of the stand-in branch
+        else:
+            w.wait()
 
     def wait(self):
-        for w in self._works:
-            w.wait()            # makes the current stream wait for the collective (no host block on GPU backends)
-        self._works = []
+        for i in sorted(self._works):
+            self.wait_one(i)
 
 
 def broadcast_parameters(flat_param, src=0, group=None):
@@ -106,7 +145,7 @@ class DataParallelTrainer:
     """Fused training step (forward, loss, backward, all-reduce, Adam) for one rank."""
 
     def __init__(self, engine, n_buckets=None, group=None, use_graphs=True, force_collectives=False, graph_collectives='auto',
-                 wire='fp32', event_graph=False):
+                 wire='fp32', event_graph=False, sliced_adam=True, standin_gbps=0.0, blocks_per_bucket=None, standin_latency_us=0.0):
         """event_graph (opt-in, with use_graphs): forward + the whole backward are captured as ONE flat graph with an external
         event-record node behind every backward segment (s3d_graph_marker / s3d_graph_events_at_markers); the all-reduce of bucket k is
         launched from the host on a side stream that waits for "segment k done" only, so it overlaps the later segments and the
@@ -140,20 +179,33 @@ class DataParallelTrainer:
             else:
                 graph_collectives = False
         self.graph_collectives = bool(graph_collectives)
+        n_buckets_given = n_buckets
         if n_buckets is None:
             n_buckets = 4 if (self.graph_collectives and use_graphs) else 2
         broadcast_parameters(engine.arena.p, 0, group)                 # DDP-constructor broadcast (C2)
         engine.refresh_weight_planes()
-        self.segments, self.slices = engine.grad_buckets(n_buckets if (self.world > 1 or force_collectives) else 1)
+        live = self.world > 1 or force_collectives
+        if blocks_per_bucket is None and n_buckets_given is None and live and getattr(engine, 'depth', 0) >= 8:
+            # round 5 default: UNIFORM buckets of depth / 4 blocks (cfg-2: 11-9 | 8-6 | 5-3 | 2-0 + tokenizer).  With a live kernel of the
+            # duration of an 8-rank fp32 ring all-reduce per bucket on the side branch (profiles/r05_dp_branch_tax.txt) the step takes
+            # 1.93 ms against 2.06 ms with the geometric buckets of rounds 3 - 4 (the wire starts after three blocks of backward instead of
+            # six, and the whole gradient's wire time -- 0.7 ms -- is as long as the backward); 6 / 12 buckets: 2.11 / 2.38 ms.
+            blocks_per_bucket = max(1, engine.depth // 4)
+        if blocks_per_bucket and live:
+            self.segments, self.slices = engine.grad_buckets(blocks_per_bucket=blocks_per_bucket)
+        else:
+            self.segments, self.slices = engine.grad_buckets(n_buckets if live else 1)
         if wire not in ('fp32', 'bf16'):
             raise ValueError(f"wire must be 'fp32' or 'bf16', not {wire!r}")
         self.wire = None
         if wire == 'bf16':
             self.wire = torch.zeros(engine.arena.g.numel(), dtype=torch.bfloat16, device=engine.arena.g.device)
             self.reducer = BucketedGradReducer(self.wire, self.slices, group, force=force_collectives,
-                                               prepare=lambda s, e: engine.pack_grads(s, e, self.wire))
+                                               prepare=lambda s, e: engine.pack_grads(s, e, self.wire), standin_gbps=standin_gbps,
+                                               standin_latency_us=standin_latency_us)
         else:
-            self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives)
+            self.reducer = BucketedGradReducer(engine.arena.g, self.slices, group, force=force_collectives, standin_gbps=standin_gbps,
+                                               standin_latency_us=standin_latency_us)
         # keep the lr / betas / eps the engine was built with (the reference's default lr is 0.05, train_cls_voxel.py:373); only the
         # 1/world averaging is this trainer's business
         engine.set_optimizer(grad_scale=1.0 / self.world)
@@ -163,6 +215,11 @@ class DataParallelTrainer:
         self.event_graph = bool(event_graph) and not self.graph_collectives
         self._side = None                   # the stream the bucket collectives are issued from in event_graph mode
         self._cap = None
+        # optimizer.step() bucket by bucket (round 5): Adam on bucket k's arena slice as soon as ITS all-reduce has finished, while the
+        # later buckets are still on the wire -- only the last (smallest) bucket's wire time and update stay exposed, instead of every
+        # bucket's wait followed by one update over the whole arena.  Same arithmetic (s3d_adam_begin + s3d_adam_apply == s3d_adam_step).
+        self.sliced_adam = sliced_adam and hasattr(engine, 'adam_apply') and len(self.slices) > 1
+        engine.grads_owned = True           # this trainer's step owns the gradient arena: zeroed by its Adam, one backward per step
 
     def collectives_mode(self):
         """How this trainer's captured step issues the bucket all-reduces (bench.py prints it)."""
@@ -177,14 +234,29 @@ class DataParallelTrainer:
     def set_optimizer(self, lr=None, betas=None, eps=None):
         self.eng.set_optimizer(lr=lr, betas=betas, eps=eps, grad_scale=1.0 / self.world)
 
+    def _update(self, k=None):
+        """optimizer.step(): k = None -> every bucket (waits for the collectives as it goes); k -> bucket k only (sliced mode)."""
+        eng = self.eng
+        if not self.sliced_adam:
+            self.reducer.wait()
+            eng.adam_step(zero_grad=True, wire=self.wire)
+            return
+        ks = range(len(self.slices)) if k is None else [k]
+        for i in ks:
+            if i == 0:
+                eng.adam_begin()                                        # step count / bias corrections once per step
+            self.reducer.wait_one(i)
+            eng.adam_apply(*self.slices[i], zero_grad=True, wire=self.wire)
+            if i == len(self.slices) - 1:
+                eng.adam_end()
+
     # ---- eager step -------------------------------------------------------------------------------------------
     def step_eager(self, x, y, weight=None):
         eng, B = self.eng, x.shape[0]
         eng.advance_dropout_seed()
         loss = eng.forward_loss(x, y, weight)
         eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
-        self.reducer.wait()
-        eng.adam_step(zero_grad=True, wire=self.wire)
+        self._update()
         return loss
 
     # ---- HIP-graph step ---------------------------------------------------------------------------------------
@@ -210,7 +282,7 @@ class DataParallelTrainer:
         with torch.cuda.stream(side):                                   # warm-up: kernel attributes, workspaces
             for k in range(len(self.segments)):
                 self._phase(k, B, sx, sy, weight)
-            eng.adam_step(zero_grad=True, wire=self.wire)
+            self._update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for t, sv in zip(state, snap):
@@ -226,8 +298,7 @@ class DataParallelTrainer:
                 for k in range(len(self.segments)):
                     self._phase(k, B, sx, sy, weight)
                     self.reducer.launch(k)                              # a side branch of the graph: overlaps the next segment
-                self.reducer.wait()
-                eng.adam_step(zero_grad=True, wire=self.wire)
+                self._update()
             self._cap = dict(B=B, graphs=[], whole=g, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
             self._guarded_first_replay(g, state)
             return self._cap
@@ -255,9 +326,7 @@ class DataParallelTrainer:
                     L.check(lib.s3d_graph_marker(k, L.current_stream()), 'graph_marker')
             L.check(lib.s3d_graph_events_at_markers(ctypes.c_void_p(g.raw_cuda_graph()), (ctypes.c_void_p * len(events))(*events),
                                                     len(events)), 'graph_events_at_markers')
-            g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt):
-                eng.adam_step(zero_grad=True, wire=self.wire)
+            g_opt = self._capture_update()
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._cap = dict(B=B, graphs=[], fwd_bwd=g, events=events, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss,
@@ -269,11 +338,35 @@ class DataParallelTrainer:
             with torch.cuda.graph(g):
                 self._phase(k, B, sx, sy, weight)
             graphs.append(g)
-        g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_opt):
-            eng.adam_step(zero_grad=True, wire=self.wire)
+        g_opt = self._capture_update()
         self._cap = dict(B=B, graphs=graphs, opt=g_opt, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
         return self._cap
+
+    def _capture_update(self):
+        """The optimizer as graph(s) for the host-launched modes: one graph, or (sliced) one per bucket -- replayed behind that bucket's wait.
+        The collectives are NOT part of these graphs (the reducer has nothing in flight while they are captured)."""
+        eng = self.eng
+        if not self.sliced_adam:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.adam_step(zero_grad=True, wire=self.wire)
+            return [g]
+        graphs = []
+        for k in range(len(self.slices)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._update(k)
+            graphs.append(g)
+        return graphs
+
+    def _replay_update(self, graphs):
+        if len(graphs) == 1 and not self.sliced_adam:
+            self.reducer.wait()
+            graphs[0].replay()
+            return
+        for k, g in enumerate(graphs):
+            self.reducer.wait_one(k)
+            g.replay()
 
     def _release_events(self):
         if self._cap is not None and self._cap.get('events'):
@@ -337,16 +430,16 @@ class DataParallelTrainer:
                 L.check(lib.s3d_stream_wait_event(ctypes.c_void_p(side.cuda_stream), ev), 'stream_wait_event')
                 with torch.cuda.stream(side):
                     self.reducer.launch(k)
-            self.reducer.wait()             # the compute stream waits for every collective ...
-            cur.wait_stream(side)           # ... and for whatever else the side stream did (wire packing at world size 1)
-            cap['opt'].replay()
+            cur.wait_stream(side)           # whatever the side stream did besides the collectives (wire packing at world size 1)
+            self._replay_update(cap['opt'])                             # the compute stream waits for the collectives bucket by bucket
             return cap['loss'][0]
         for k, g in enumerate(cap['graphs']):
             g.replay()
             self.reducer.launch(k)          # RCCL all-reduce of bucket k overlaps the next segment's replay
-        self.reducer.wait()
         if cap['opt'] is not None:
-            cap['opt'].replay()
+            self._replay_update(cap['opt'])
+        else:
+            self.reducer.wait()
         return cap['loss'][0]
 
     def step(self, x, y, weight=None):

@@ -88,6 +88,20 @@ class FakeEngine:
         if zero_grad:
             self.arena.g.zero_()
 
+    # the sliced update (s3d_adam_begin / s3d_adam_apply): per-step bookkeeping once, then one arena slice at a time
+    def adam_begin(self):
+        self.update_log = getattr(self, 'update_log', []) + ['begin']
+
+    def adam_apply(self, start, end, zero_grad=True, max_workgroups=0, wire=None):
+        g = self.arena.g[start:end] if wire is None else wire[start:end].float()
+        self.arena.p[start:end].add_(g, alpha=-self.lr * self.grad_scale)
+        if zero_grad:
+            self.arena.g[start:end].zero_()
+        self.update_log.append((start, end))
+
+    def adam_end(self):
+        self.update_log.append('end')
+
 
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
@@ -114,6 +128,8 @@ def _worker(rank, world, port, q, wire='fp32'):
         red = BucketedGradReducer(flat, [(6, 10), (0, 6)])
         red.launch(0); red.launch(1); red.wait()
         assert int(eng.dropout_seed) == 1000003 * rank + 3       # advanced once per step
+        # optimizer.step() ran bucket by bucket, in the order the buckets' collectives were launched, once per step
+        assert tr.sliced_adam and eng.update_log == (['begin'] + [tuple(sl_) for sl_ in tr.slices] + ['end']) * 3, eng.update_log
         q.put((rank, eng.arena.p.clone(), flat.clone(), tr.segments, tr.slices))
     finally:
         dist.destroy_process_group()
@@ -273,6 +289,26 @@ def test_shard_indices_matches_distributed_sampler():
             ref = list(iter(DistributedSampler(ds, num_replicas=world, rank=rank, seed=0)))
             assert shard_indices(n, world, rank, seed=0) == ref
     assert shard_indices(6, 2, 1, shuffle=False) == [1, 3, 5]
+
+
+def test_sliced_update_equals_the_single_update():
+    """DataParallelTrainer(sliced_adam=True) (default) and sliced_adam=False walk the same parameters: one process, three steps."""
+    torch.manual_seed(3)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    out = []
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    dist.init_process_group('gloo', rank=0, world_size=1)        # (forced collectives need a group; one rank is enough here)
+    try:
+        for sliced in (True, False):
+            eng = FakeEngine(seed=5)
+            tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=False, force_collectives=True, graph_collectives=False, sliced_adam=sliced)
+            assert tr.sliced_adam == sliced and len(tr.slices) == 3
+            for _ in range(3):
+                tr.step_eager(X, Y)
+            out.append(eng.arena.p.clone())
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(out[0], out[1])
 
 
 def test_reducer_is_a_noop_without_process_group():
