@@ -504,7 +504,8 @@ int s3d_blocks_ln_aux(const S3dBlockShape* shape, const S3dBlockParams* params, 
  * ACROSS the samples of the batch; ReLU feed-forward D -> Dff -> D; LayerNorm eps 1e-5.  Rows are r = g*Nb + t.
  * Dropout (p = 0.1, four sites: attention weights, after out_proj, after the ReLU, after linear2) uses a counter-based
  * hash mask keep = mix32(index, seed, site) >= p*2^32 -- for the attention weights (site 0) one hash per pair of adjacent keys, 16 bits
- * per decision; csrc/common.h drop_keep / drop_keep_attn == oracle.voxel_oracle.hash_keep_mask (torch's RNG stream cannot be reproduced); dropout_p = 0 gives
+ * per decision: there p is resolved to 2^-16 (the drop rate is floor(p 2^16) / 2^16: 0.09999 for p = 0.1, and 0 for p < 2^-16) while kept
+ * weights are still scaled by 1 / (1 - p), i.e. E[mask scale] deviates from 1 by at most 1.5e-5 relative (the oracle uses the same rule); csrc/common.h drop_keep / drop_keep_attn == oracle.voxel_oracle.hash_keep_mask (torch's RNG stream cannot be reproduced); dropout_p = 0 gives
  * the eval-mode layer. */
 typedef struct S3dEncShape {
     int G, Nb, D, H, Dff;

@@ -189,12 +189,12 @@ bool bwd_streams_enabled() {
 int dgrad_and_wgrad(int epi, const GemmArgs& dg, const GemmArgs& wg, hipStream_t s, BwdStreams* bs, AdamFillQueue* fq = nullptr,
                     const GemmArgs* wg2 = nullptr) {
     if (bs == nullptr) return s3d_launch_gemm_pair(epi, dg, wg, s, fq, wg2);
-    if (wg2) S3D_TRY(s3d_launch_gemm(true, true, false, EPI_ATOMIC, *wg2, 0, bs->side));
     if (hipEventRecord(bs->ready, s) != hipSuccess || hipStreamWaitEvent(bs->side, bs->ready, 0) != hipSuccess) {
         s3d_set_error("backward streams: fork failed");
         return 3;
     }
     S3D_TRY(s3d_launch_gemm(true, true, false, EPI_ATOMIC, wg, 0, bs->side));
+    if (wg2) S3D_TRY(s3d_launch_gemm(true, true, false, EPI_ATOMIC, *wg2, 0, bs->side));       // (behind the fork: its operands come from `s` too)
     return s3d_launch_gemm(false, true, false, epi, dg, 1, s);
 }
 // `s` waits for every wgrad issued so far (before a buffer they read is overwritten / before the block returns)

@@ -215,6 +215,8 @@ WGRAD_GROUP = int(os.environ.get('S3D_WGRAD_GROUP', '4'))
 DGRAD_SPLITK = int(os.environ.get('S3D_DGRAD_SPLITK', '3'))
 LN_BWD_FUSE = os.environ.get('S3D_LN_BWD_FUSE', '1') != '0'             # LayerNorm backward as the epilogue of the fc1 / qkv dgrads (row statistics)
 WGRAD_OVERWRITE = os.environ.get('S3D_WGRAD_OVERWRITE', '1') != '0'     # train_step: grouped wgrads store instead of read-modify-write
+# stored dropout mask of the group encoder layer's attention (S3dEncActs::attn_mask): one bit per weight, quadratic in the batch
+ATTN_MASK_BUDGET_BYTES = int(float(os.environ.get('S3D_ATTN_MASK_BUDGET_GB', '8')) * 2 ** 30)
 FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm + head + CE + their backward in two launches
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
 
@@ -459,10 +461,24 @@ class VoxelEngine:
         """S3dEncActs::attn_mask: one bit per attention weight of the seq-first encoder layer, written by the forward while it evaluates
         the dropout hash and read by the two backward kernels (long sequences only: the cooperative kernels, G >= 192)."""
         e = ws.enc
-        if self.dropout_p > 0 and ws.G >= 192 and getattr(e, 'attn_mask', None) is None and os.environ.get('S3D_NO_ATTN_MASK') != '1':   # (A/B knob)
-            t = (ws.G + 31) // 32
-            e.attn_mask = torch.zeros(self.ntok * self.enc_heads * t * t * 32 + 256, dtype=torch.int32, device=self.device)
-            e.acts.attn_mask = e.attn_mask.data_ptr()
+        t = (ws.G + 31) // 32
+        words = self.ntok * self.enc_heads * t * t * 32 + 256      # grows with G^2: 3.5 GB at cfg-3 batch 64, 14 GB at batch 128
+        want = (self.dropout_p > 0 and ws.G >= 192 and os.environ.get('S3D_NO_ATTN_MASK') != '1'       # (A/B knob)
+                and words * 4 <= ATTN_MASK_BUDGET_BYTES)             # above the budget the kernels evaluate the hash (bit-identical, ~2 % slower)
+        if not want:
+            e.acts.attn_mask = None                                  # ... also after set_dropout(0): nothing reads it in eval mode
+            if self.dropout_p == 0:
+                self._attn_mask = None                               # released with the workspaces' references gone
+            return
+        buf = getattr(self, '_attn_mask', None)                      # ONE buffer for every batch-size workspace, sized for the largest G seen
+        if buf is None or buf.numel() < words:
+            buf = torch.zeros(words, dtype=torch.int32, device=self.device)
+            self._attn_mask = buf
+            self.capture_epoch += 1                                  # captured graphs hold the old pointer
+            for other in self._ws.values():
+                if getattr(other, 'enc', None) is not None and other.enc.acts.attn_mask:
+                    other.enc.acts.attn_mask = buf.data_ptr()
+        e.acts.attn_mask = buf.data_ptr()
 
     def advance_dropout_seed(self):
         """Fresh dropout masks for the next forward: one device-side increment (graph-replay safe).  Every path that trains calls

@@ -103,7 +103,7 @@ def broadcast_parameters(flat_param, src=0, group=None):
 
 def graph_collectives_preflight(device_index, group=None, timeout_s=None):
     """Can this job replay RCCL all-reduces captured in a HIP graph?  Every rank starts `_graph_collective_preflight.py` as a child
-    process on its own device (same RANK / WORLD_SIZE, rendezvous port MASTER_PORT + 13), waits at most timeout_s
+    process on its own device (same RANK / WORLD_SIZE, rendezvous on a free port that rank 0 picks and broadcasts), waits at most timeout_s
     (S3D_PREFLIGHT_TIMEOUT, default 150 s) and kills it otherwise; the verdicts are combined with a MIN all-reduce over the caller's
     (eager) process group, so all ranks take the same branch.  Returns (ok, detail).  ~10 - 20 s, once per trainer."""
     import os
@@ -113,8 +113,24 @@ def graph_collectives_preflight(device_index, group=None, timeout_s=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     env = dict(os.environ)
-    env.update(RANK=str(rank), WORLD_SIZE=str(world), S3D_PREFLIGHT_DEVICE=str(device_index),
-               MASTER_ADDR=env.get('MASTER_ADDR', '127.0.0.1'), MASTER_PORT=str(int(env.get('MASTER_PORT', '29500')) + 13))
+    # rendezvous of the children: rank 0 picks a free port on its own address and tells the others over the caller's (eager) process group --
+    # works for tcp:// / file:// initialised jobs without MASTER_* variables, on several nodes, and for two trainers on one host
+    addr, port = env.get('MASTER_ADDR', '127.0.0.1'), int(env.get('MASTER_PORT', '29500')) + 13
+    if dist.is_initialized() and world > 1:
+        import socket
+        if rank == 0:
+            with socket.socket() as sk:
+                sk.bind(('', 0))
+                port = sk.getsockname()[1]
+            if 'MASTER_ADDR' not in env:
+                try:
+                    addr = socket.gethostbyname(socket.gethostname())
+                except OSError:
+                    addr = '127.0.0.1'
+        box = [addr, port]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        addr, port = box[0], int(box[1])
+    env.update(RANK=str(rank), WORLD_SIZE=str(world), S3D_PREFLIGHT_DEVICE=str(device_index), MASTER_ADDR=str(addr), MASTER_PORT=str(port))
     env.pop('TORCHELASTIC_RUN_ID', None)
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_graph_collective_preflight.py')
     detail = ''
@@ -138,6 +154,9 @@ def graph_collectives_preflight(device_index, group=None, timeout_s=None):
         if ok and int(flag.item()) == 0:
             detail = 'another rank failed the preflight'
         ok = bool(int(flag.item()))
+    if not ok:
+        import warnings
+        warnings.warn(f'[s3d] graph-collective preflight failed ({detail}): one HIP graph per backward segment with host-launched collectives instead')
     return ok, detail
 
 
