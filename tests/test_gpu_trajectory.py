@@ -146,3 +146,38 @@ def test_fifty_step_trajectory_tracks_the_oracle(deterministic):
     assert abs(acc - acc_ref) <= 1.0 / 32 + 1e-9, (acc, acc_ref)
     print(f'50-step trajectory: worst relative loss deviation {worst:.3e}; loss {ref_curve[0]:.3f} -> {ref_curve[-1]:.3f}; '
           f'held-out accuracy {acc:.3f} (oracle {acc_ref:.3f}), {int(clear.sum())}/32 clear-cut decisions all equal')
+
+
+def test_trained_state_fixture_from_the_reference_optimizer():
+    """the HIP fused training step against a fixture produced by the REFERENCE model trained with the reference's own
+    optimizer (torch.optim.Adam(lr = 1e-3), train_cls_voxel.py:195,277-288; tests/golden/make_golden_trained.py): 60 steps on a fixed learnable
+    batch set in cfg-1 geometry.  The loss trajectory is reproduced step by step and the held-out class decisions -- 6 distinct classes,
+    logits that depend on the input -- are identical wherever the reference's top-2 gap exceeds 2e-3 (all 32 here)."""
+    import json
+    import numpy as np
+    from tests._util import GOLDEN
+    z = np.load(f'{GOLDEN}/trained_cfg1_small_v30_adam60.npz')
+    cfg = json.loads(str(z['cfg']))
+    kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')}
+    sd = vo.init_state_dict(seed=9, exercise_all=False, portable=True, **kw)
+    eng = s3d.VoxelEngine(device=DEV, lr=cfg['lr'], **kw)
+    eng.load_state_dict(sd)
+    data = [vo.synthetic_class_batch(cfg['batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=500 + i) for i in range(cfg['n_batches'])]
+    data = [(x.to(DEV), y.to(DEV)) for x, y in data]
+    worst = 0.0
+    for step in range(cfg['steps']):
+        x, y = data[step % len(data)]
+        loss = float(eng.train_step(x, y))
+        ref = float(z['losses'][step])
+        rel = abs(loss - ref) / max(abs(ref), 1e-6)
+        worst = max(worst, rel)
+        assert rel <= 5e-3, f'step {step}: HIP loss {loss:.5f} vs reference {ref:.5f} (rel {rel:.2e})'
+    xh, yh = vo.synthetic_class_batch(cfg['held_batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=999)
+    logits = eng.forward(xh.to(DEV)).cpu().numpy()
+    clear = z['held_top2_gap'] > 2e-3
+    assert int(clear.sum()) >= 24 and len(set(z['held_argmax'].tolist())) >= 6
+    np.testing.assert_array_equal(logits.argmax(1)[clear], z['held_argmax'][clear])
+    err = float(np.abs(logits - z['held_logits']).max())
+    print(f'trained-state fixture: worst relative loss deviation over 60 steps {worst:.2e}; held-out logits within {err:.2e}; '
+          f'{int(clear.sum())}/32 decisions ({len(set(z["held_argmax"].tolist()))} classes) equal')
+    assert err <= 0.05 * float(np.abs(z['held_logits']).max()), err          # 60 plain-bf16 backward steps apart: the trajectory bound, not the 1e-3 forward bar

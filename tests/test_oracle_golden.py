@@ -112,3 +112,37 @@ def test_forward_images_and_lwf_loss_match_reference():
     assert abs(float(loss) - float(z['loss'])) <= 1e-5
     assert set(grads) == set(json.loads(str(z['grad_names'])))
     check_grads_against_golden(z, grads, rtol=1e-4, atol=1e-7)
+
+
+def _trained_fixture():
+    z = np.load(f'{GOLDEN}/trained_cfg1_small_v30_adam60.npz')
+    cfg = json.loads(str(z['cfg']))
+    kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')}
+    sd = vo.init_state_dict(seed=9, exercise_all=False, portable=True, **kw)
+    fp = np.array([[float(sd[k].double().sum()), float(sd[k].double().abs().sum())] for k in sorted(sd)])
+    np.testing.assert_allclose(fp, z['fingerprint'], rtol=1e-12, atol=1e-12)         # the same initial parameters as the reference run
+    data = [vo.synthetic_class_batch(cfg['batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=500 + i) for i in range(cfg['n_batches'])]
+    held = vo.synthetic_class_batch(cfg['held_batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=999)
+    return z, cfg, sd, data, held
+
+
+def test_oracle_training_trajectory_matches_the_reference_optimizer():
+    """Trained-state fixture (tests/golden/make_golden_trained.py): the REFERENCE model trained with torch.optim.Adam(lr = 1e-3) for 60
+    steps.  The oracle's forward / autograd / adam_step walk the same losses and end at the same held-out decisions: 6 distinct classes,
+    every top-2 gap above 1e-2 -- the argmax criterion on logits that DO depend on the input."""
+    z, cfg, sd, data, held = _trained_fixture()
+    fk = dict(backbone=cfg['backbone'], embed_layer=cfg['embed_layer'], cell=cfg['cell'], patch=cfg['patch'])
+    names = vo.used_param_names(sd)
+    m = {k: torch.zeros_like(sd[k]) for k in names}
+    v = {k: torch.zeros_like(sd[k]) for k in names}
+    for step in range(cfg['steps']):
+        x, y = data[step % len(data)]
+        _, loss, grads = vo.loss_and_grads(sd, x, y, **fk)
+        assert abs(float(loss) - float(z['losses'][step])) <= 2e-4 * max(1.0, abs(float(z['losses'][step]))), (step, float(loss), float(z['losses'][step]))
+        for k, g in grads.items():
+            vo.adam_step(sd[k], g, m[k], v[k], step + 1, lr=cfg['lr'])
+    with torch.no_grad():
+        logits = vo.forward(sd, held[0], **fk)
+    np.testing.assert_allclose(logits.numpy(), z['held_logits'], rtol=0, atol=5e-3)      # 60 steps of fp32 round-off apart
+    np.testing.assert_array_equal(logits.argmax(1).numpy(), z['held_argmax'])
+    assert len(set(z['held_argmax'].tolist())) >= 6 and float(z['held_top2_gap'].min()) > 1e-2
