@@ -139,7 +139,7 @@ def rocprof_name(key):
     return f'gemm_kernel<{b0}, {b1}, {tf(ta)}, {tf(tb)}, {tf(sp)}, {epi}>'
 
 
-PMC_TRAFFIC_FILE = 'profiles/r04_pmc_step_traffic.json'           # cfg-2; main() switches to ..._pmc_<config>_traffic.json for the others
+PMC_TRAFFIC_FILE = 'profiles/r05_pmc_step_traffic.json'           # cfg-2; main() switches to ..._pmc_<config>_traffic.json for the others
 
 
 def pmc_traffic(key):
@@ -588,9 +588,10 @@ def main():
     global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE, PMC_TRAFFIC_FILE
     conf = CONFIGS[args.config]
     if args.config != 'cfg2':
-        PMC_TRAFFIC_FILE = f'profiles/r04_pmc_{args.config}_traffic.json'     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh
-        if not os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)):
-            PMC_TRAFFIC_FILE = f'profiles/r03_pmc_{args.config}_traffic.json'
+        for rnd in ('r05', 'r04', 'r03'):                     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh; the newest passes that exist
+            PMC_TRAFFIC_FILE = f'profiles/{rnd}_pmc_{args.config}_traffic.json'
+            if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)):
+                break
     CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
 
     import torch.distributed as dist

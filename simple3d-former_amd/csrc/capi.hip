@@ -12,6 +12,7 @@
 #include "attention.h"
 #include "bwd_gemm.h"
 #include "fused_block.h"
+#include "fused_mlp.h"
 #include "gemm.h"
 #include "kernels.h"
 #include "s3d_hip.h"
@@ -115,6 +116,19 @@ int block_fwd(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dBlockAc
     g.ln_lo = split ? a.xn2_lo : nullptr; g.ld_ln = D; g.ln_mean = a.mean2; g.ln_rstd = a.rstd2;
     const bool fused2 = s3d_gemm_ln_fusable(split, g);
     S3D_TRY(s3d_launch_gemm(false, false, split, EPI_RESID, g, 1, s));
+    // the whole MLP branch as one launch (fused_mlp.hip): deit_tiny at thousands of rows -- the point path's transformer
+    static const int mlp_full_off = s3d_tune_int("S3D_FUSED_MLP_FULL");            // 0: the three-launch sequence (A/B in the tuning build)
+    const bool mlp_full = split && sh.fuse >= 0 && !cls_only && sh.ln_tickets == nullptr && a.hpre_lo == nullptr && mlp_full_off != 0 &&
+                          s3d_fused_mlp_full_ok(M, D, Hd);
+    if (mlp_full) {
+        FusedMlpArgs fm;
+        memset(&fm, 0, sizeof(fm));
+        fm.x = a.x_mid; fm.gamma = p.ln2_w; fm.beta = p.ln2_b; fm.eps = sh.eps;
+        fm.w_hi = p.fc1_w_hi; fm.w_lo = p.fc1_w_lo; fm.bias = p.fc1_b;
+        fm.xn_hi = a.xn2_hi; fm.xn_lo = nullptr; fm.mean = a.mean2; fm.rstd = a.rstd2;
+        fm.hpre = a.hpre; fm.hact_hi = a.hact_hi; fm.M = M; fm.hidden = Hd;
+        return s3d_launch_fused_mlp_full(fm, p.fc2_w_hi, p.fc2_w_lo, p.fc2_b, a.x_out, D, s);
+    }
     if (fuse_mlp) {
         FusedMlpArgs fm;
         fm.x = a.x_mid; fm.gamma = p.ln2_w; fm.beta = p.ln2_b; fm.eps = sh.eps;
