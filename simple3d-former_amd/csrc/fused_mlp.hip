@@ -15,6 +15,12 @@
 //   * W1 / W2 chunks (both planes, 48 KB per chunk) arrive through a three-stage LDS-DMA ring (global_load_lds_dwordx4, source-side slot
 //     swizzle: 384-byte W1 rows alias like 128-byte ones -> dma_swz64 on the low slot bits; 64-byte W2 rows -> dma_swz32).
 // Three MFMAs per product (hi hi + hi lo + lo hi): the forward's precision.
+//
+// MEASURED (profiles/r05_fused_mlp_d192.txt): 163 us per launch at cfg-4 (257 bands = two rounds of ~81 us on 256 CUs) against 11.4 + 64.5 +
+// 63.6 us for the three launches it replaces -- the cfg-4 step gains 1.5 % (15.34 -> 15.12 ms), cfg-5 nothing.  An ablation says why it is
+// not the 35 us the MFMA count promises: without MFMAs, weight stream and activation stores the launch still takes 70 % of its time -- a
+// 16-row wave tile reads 48 KB of weight fragments from LDS per 72 MFMAs, and the GELU / split epilogue is ~300 wave64 VALU instructions per
+// chunk (4 cycles each); with one or two waves per SIMD these phases run one after the other instead of overlapping.
 #include "fused_mlp.h"
 #include "dma_tile.h"
 #include "gemm.h"
@@ -26,7 +32,7 @@ constexpr int FM_W1P = FM_CH * FM_D * 2;                                        
 constexpr int FM_W2P = FM_D * FM_CH * 2;                                        // bytes of one W2 chunk plane: 192 rows x 64 B = 12 KB
 constexpr int FM_STAGE = 2 * FM_W1P + 2 * FM_W2P;                               // 48 KB
 constexpr int FM_NS = 3;
-constexpr int FM_PPW = FM_STAGE / 1024 / 4;                                     // DMA pieces per wave per stage: 12
+constexpr int FM_PIECES = FM_STAGE / 1024;                                      // 1 KB DMA pieces per stage: 48 = [W1 hi 12 | W1 lo 12 | W2 hi 12 | W2 lo 12]
 
 struct FusedMlpFullArgs {
     const float* x; const float* gamma; const float* beta; float eps;
@@ -44,28 +50,30 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     hi = h.v; lo = l.v;
 }
 
-template <int RPW>
-__global__ __launch_bounds__(256) void blk_mlp_full_kernel(const FusedMlpFullArgs p) {
+template <int RPW, int NW>
+__global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFullArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RF = RPW / 16;                                        // 16-row fragments per wave
     constexpr int KS = FM_D / 32;                                       // k-steps of fc1: 6
     constexpr int OF = FM_D / 16;                                       // output fragments of fc2: 12
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const long row0 = ((long)blockIdx.x * 4 + wave) * RPW;
+    constexpr int FM_PPW = FM_PIECES / NW;                              // pieces per wave: 12 (four waves) or 6 (eight)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    const long row0 = ((long)blockIdx.x * NW + wave) * RPW;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     float* sb1 = reinterpret_cast<float*>(smem + FM_NS * FM_STAGE);     // [768] fc1 bias
 
-    // ---- weight stream: wave w issues pieces 12 w .. 12 w + 11 of a stage = [W1 hi 12 | W1 lo 12 | W2 hi 12 | W2 lo 12]
+    // ---- weight stream: the stage's 48 pieces are dealt out to the waves in order; plane = piece / 12: W1 hi, W1 lo, W2 hi, W2 lo
     const bf16_t* gp[FM_PPW];
     long gstep[1];
     {
-        // wave 0: W1 hi, wave 1: W1 lo, wave 2: W2 hi, wave 3: W2 lo
-        if (wave < 2) {
-            const bf16_t* base = wave == 0 ? p.w1_hi : p.w1_lo;
+        const int plane = (wave * FM_PPW) / 12, p0 = (wave * FM_PPW) % 12;      // (a wave's pieces lie in one plane: 12 % FM_PPW == 0)
+        if (plane < 2) {
+            const bf16_t* base = plane == 0 ? p.w1_hi : p.w1_lo;
 #pragma unroll
             for (int j = 0; j < FM_PPW; ++j) {
-                const int t = j * 64 + lane;                            // 16-byte slot of the chunk plane: 32 rows x 24 slots
+                const int t = (p0 + j) * 64 + lane;                     // 16-byte slot of the chunk plane: 32 rows x 24 slots
                 const int r = t / 24, s = t % 24;                       // LDS row r = f * 16 + i holds hidden unit (i >> 2) * 8 + f * 4 + (i & 3)
                 const int u = ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3);
                 const int src = (s & ~7) | ((s & 7) ^ dma_swz64(r));    // LDS slot (r, s) holds global 16-byte chunk `src` of that unit's row
@@ -73,10 +81,10 @@ __global__ __launch_bounds__(256) void blk_mlp_full_kernel(const FusedMlpFullArg
             }
             gstep[0] = (long)FM_CH * FM_D;                              // next chunk: 32 rows further
         } else {
-            const bf16_t* base = wave == 2 ? p.w2_hi : p.w2_lo;
+            const bf16_t* base = plane == 2 ? p.w2_hi : p.w2_lo;
 #pragma unroll
             for (int j = 0; j < FM_PPW; ++j) {
-                const int r = j * 16 + (lane >> 2), s = lane & 3;       // 192 rows x 4 slots (32 units)
+                const int r = (p0 + j) * 16 + (lane >> 2), s = lane & 3;        // 192 rows x 4 slots (32 units)
                 gp[j] = base + (long)r * FM_H + ((s ^ dma_swz32(r)) << 3);
             }
             gstep[0] = FM_CH;                                           // next chunk: 32 columns further
@@ -92,7 +100,7 @@ __global__ __launch_bounds__(256) void blk_mlp_full_kernel(const FusedMlpFullArg
 
     // ---- norm2 in registers (B-operand layout): lane = (row l15 of fragment rf, k-group g)
     bf16x8 xh[RF][KS], xl[RF][KS];
-    for (int i = tid; i < FM_H; i += 256) sb1[i] = p.b1[i];
+    for (int i = tid; i < FM_H; i += 64 * NW) sb1[i] = p.b1[i];
 #pragma unroll
     for (int rf = 0; rf < RF; ++rf) {
         const long row = row0 + rf * 16 + l15;
@@ -143,7 +151,10 @@ __global__ __launch_bounds__(256) void blk_mlp_full_kernel(const FusedMlpFullArg
         for (int of = 0; of < OF; ++of) out[rf][of] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int c = 0; c < FM_NCH; ++c) {
-        if (c + FM_NS - 1 <= FM_NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FM_NS - 2) * FM_PPW) : "memory");
+        // stage c must have landed.  Younger than its pieces (vmcnt retires in issue order): the two 16-byte stores per row fragment of each
+        // of the last NS - 1 chunks and the pieces of the NS - 2 stages behind it -- they may all stay in flight (waiting for them too
+        // exposed a store acknowledgement + most of a DMA latency at every chunk: 182 us per launch at cfg-4)
+        if (c + FM_NS - 1 <= FM_NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FM_NS - 2) * FM_PPW + (FM_NS - 1) * 2 * RF) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c + FM_NS - 1 < FM_NCH) issue(c + FM_NS - 1);
@@ -230,10 +241,12 @@ void set_lds_once(K kern, int bytes, bool& done) {
 
 }  // namespace
 
-bool s3d_fused_mlp_full_ok(long M, int D, int hidden) { return D == FM_D && hidden == FM_H && M >= 4096; }
+// From ~24 k rows on (cfg-4: 32 896): there the launch beats LayerNorm + fc1 + fc2 as three launches by 1.5 % of the step; at cfg-5's 16 416
+// rows (129 bands on 256 CUs) the two are equal (profiles/r05_fused_mlp_d192.txt), so the three launches stay.
+bool s3d_fused_mlp_full_ok(long M, int D, int hidden) { return D == FM_D && hidden == FM_H && M >= 24576; }
 
 int s3d_launch_fused_mlp_full(const FusedMlpArgs& a, const bf16_t* w2_hi, const bf16_t* w2_lo, const float* b2, float* x_out, int D, hipStream_t s) {
-    S3D_REQUIRE(s3d_fused_mlp_full_ok(a.M, D, a.hidden), "fused MLP: D = 192, hidden = 768, >= 4096 rows (got D=%d hidden=%d M=%ld)", D, a.hidden, a.M);
+    S3D_REQUIRE(s3d_fused_mlp_full_ok(a.M, D, a.hidden), "fused MLP: D = 192, hidden = 768, >= 24576 rows (got D=%d hidden=%d M=%ld)", D, a.hidden, a.M);
     S3D_REQUIRE(a.x && a.gamma && a.beta && a.w_hi && a.w_lo && a.bias && w2_hi && w2_lo && b2 && x_out && a.xn_hi && a.mean && a.rstd && a.hpre && a.hact_hi,
                 "fused MLP: null pointer");
     FusedMlpFullArgs f;
@@ -243,19 +256,13 @@ int s3d_launch_fused_mlp_full(const FusedMlpArgs& a, const bf16_t* w2_hi, const 
     constexpr int LDS = FM_NS * FM_STAGE + FM_H * 4;
     constexpr long long KEY = 1500000000000LL + 192;                    // bench.py: 15 = fused norm2 + fc1 + GELU + fc2 + residual
     if (s3d_prof_skipped(KEY)) return 0;
-    // rows per wave: 32 (bands of 128) when that still gives every CU a band, else 16 (bands of 64)
-    static const int rpw_env = s3d_tune_int("S3D_FUSED_MLP_RPW");
-    const bool wide = rpw_env > 0 ? rpw_env == 32 : (a.M + 127) / 128 >= 224;
+    // Eight waves of 16 rows (bands of 128 rows, two waves per SIMD).  Measured (profiles/r05_fused_mlp_d192.txt): four waves of 32 rows -- every
+    // weight fragment read serving two row fragments, one wave per SIMD -- take 211 us per launch at cfg-4 against 163, four waves of 16 rows 238.
     s3d_prof_begin(KEY, 2.0 * 2.0 * (double)a.M * FM_D * FM_H, s);
-    if (wide) {
-        static bool set = false;
-        set_lds_once(blk_mlp_full_kernel<32>, LDS, set);
-        hipLaunchKernelGGL((blk_mlp_full_kernel<32>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, s, f);
-    } else {
-        static bool set = false;
-        set_lds_once(blk_mlp_full_kernel<16>, LDS, set);
-        hipLaunchKernelGGL((blk_mlp_full_kernel<16>), dim3((unsigned)((a.M + 63) / 64)), dim3(256), LDS, s, f);
-    }
+    static bool set = false;
+    set_lds_once(blk_mlp_full_kernel<16, 8>, LDS, set);
+    hipLaunchKernelGGL((blk_mlp_full_kernel<16, 8>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), LDS, s, f);
+    const bool wide = false;
     s3d_prof_end(s);
     S3D_CHECK_LAUNCH_V("blk_mlp_full", wide ? 32 : 16);
     return 0;
