@@ -193,15 +193,20 @@ def test_cfg5_full_size_parity():
     _point_fullsize_parity('seg', 2048, 22, 50, 32, rtol=4e-3)
 
 
-@pytest.mark.parametrize('dropout', [0.0, 0.1])
-def test_cfg3_reduced_batch_training_step_matches_oracle(dropout):
+@pytest.mark.parametrize('B,dropout', [(4, 0.0), (4, 0.1), (7, 0.1)])
+def test_cfg3_reduced_batch_training_step_matches_oracle(B, dropout):
     """BASELINE cfg-3 in its real geometry (deit_base H=3, 128^3 grid, cell 9, patch 14, group_embed) at batch 4: 11 760 pass-1 token
     rows (the 'long' GEMM dispatch from 8192 rows: 128x256 / 256x128 tiles, 128x128 split-K wgrads), 784 keys per (position, head) in
     the seq-first encoder layer (cooperative long-sequence attention kernels), packed 15-token pairs in pass 1 -- i.e. the kernel
     instantiations of the benched batch-64 step -- one full training-mode step against the CPU oracle: logits, loss, every gradient.
-    dropout = 0.1: nn.TransformerEncoderLayer's training mode with the counter-based mask the oracle shares."""
+    dropout = 0.1: nn.TransformerEncoderLayer's training mode with the counter-based mask the oracle shares.
+    Batch 7 (round 5, VERDICT r04 'weak' item 2): 20 580 pass-1 rows = 81 row tiles of 256 -- the qkv and fc1 forward launches and every long
+    dgrad (qkv / fc1 / fc2 * gelu' / proj) then take the 256 x 256 eight-wave tiles (gemm_nt_fat_kernel<BF16_BIAS | GELU>, gemm_nn_fat_kernel<F32 |
+    DGELU | BF16_BIAS>: their workgroups fill 95 % of the rounds they occupy; checked with the launch-coverage hooks, tools/r5/cov_b7.py) -- a
+    MODEL-level comparison with the oracle for the kernels that are a third of the benched batch-64 step, not only the operator-level tests.
+    (The residual forward launches -- proj, fc2: N = 768 -- only reach that tile from ~38 k rows = batch 13, beyond what the CPU oracle
+    finishes in a test; they stay covered at operator level, test_gemm_fat_forward_tile.)"""
     kw = dict(backbone='deit_base_patch16_224', embed_layer='VoxelEmbed_no_average', voxel_size=128, cell=9, patch=14, n_classes=55)
-    B = 4
     sd = vo.init_state_dict(seed=9, pos_embedding='group_embed', exercise_all=True, **kw)
     x, y = vo.synthetic_batch(B, 128, 55, seed=9)
     eng = s3d.VoxelEngine(device=DEV, pos_embedding='group_embed', **kw)
@@ -223,4 +228,4 @@ def test_cfg3_reduced_batch_training_step_matches_oracle(dropout):
     assert set(grads) == set(ref_grads)
     stats = check_grads_against_oracle(grads, ref_grads, rtol=3e-3)
     worst = max(stats.items(), key=lambda kv: kv[1][0])
-    print(f'cfg-3 B=4 dropout {dropout}: logits err {err:.2e}, worst grad rms err / rms {worst[1][0]:.4f} ({worst[0]}), worst entry {max(v[2] for v in stats.values()):.3f}')
+    print(f'cfg-3 B={B} dropout {dropout}: logits err {err:.2e}, worst grad rms err / rms {worst[1][0]:.4f} ({worst[0]}), worst entry {max(v[2] for v in stats.values()):.3f}')
