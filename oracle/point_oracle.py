@@ -324,6 +324,30 @@ def init_state_dict(*, backbone, n_classes, d_points, seed=9, variant='3DViT', h
     return sd
 
 
+def synthetic_class_points(batch, n_points, labels, seed=9, variant='3DViT'):
+    """A LEARNABLE portable synthetic classification batch (trained-state fixture, tests/golden/make_golden_points_trained.py): the
+    label stretches the cloud along z -- the i-th entry of `labels` scales z by 0.15 + 0.85 i / (len - 1) before the unit-sphere projection --
+    and tilts every normal towards +z by the same amount, so both the geometry (FPS / kNN neighbourhoods) and the per-point features carry
+    it.  Same FPS start recipe as synthetic_points."""
+    u = lambda shape, s: vo.portable_uniform(shape, seed, 7100 + s)
+    labels = list(labels)
+    pick = (u((batch,), 4) * len(labels)).long().clamp(max=len(labels) - 1)
+    y = torch.tensor(labels, dtype=torch.long)[pick]
+    a = (0.15 + 0.85 * pick.double() / max(1, len(labels) - 1)).view(batch, 1, 1)
+    xyz = u((batch, n_points, 3), 1) * 2 - 1
+    xyz = torch.cat([xyz[..., :2], xyz[..., 2:] * a], dim=-1)
+    r = xyz.norm(dim=-1, keepdim=True)
+    xyz = torch.where(r > 1, xyz / r, xyz)
+    nrm = u((batch, n_points, 3), 2) * 2 - 1
+    nrm = torch.cat([nrm[..., :2], nrm[..., 2:] + 2.0 * a], dim=-1)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True).clamp(min=1e-9)
+    x = torch.cat([xyz, nrm], dim=-1).float().contiguous()
+    _, S, _ = level_plan(variant, 4, n_points)
+    n_in = ([n_points] + S)[:len(S)]
+    starts = tuple((u((batch,), 10 + i) * n).long().clamp(max=n - 1) for i, n in enumerate(n_in))
+    return x, y, starts
+
+
 def synthetic_points(batch, n_points, d_points, n_classes, task, seed=9, variant='3DViT'):
     """xyz uniform in the unit ball (cf. pc_normalize, pointnet_util.py:15-20), unit normals, for
     part-seg a one-hot(16) object label appended (train_partseg.py:143); targets randint.  Integer-hash generator."""
