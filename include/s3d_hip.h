@@ -91,7 +91,7 @@ int s3d_gemm_pair3(int epi_dgrad, const S3dGemmArgs* dgrad, const S3dGemmArgs* w
  *   s3d_gemm_dgrad_splitk: "dx = dy @ W" (A = dy [M][K] k-contiguous, B = W [K][N] k-major, fp32 C, alpha; no bias) on 64 x 64 tiles with
  *   the k range cut into nslice slices of whole 64-tiles; slice s STORES its partial product at C + s * slice_stride (elements), and the
  *   consumer adds the planes (s3d_layernorm_bwd: S3dLnBwdArgs::dy_parts / dy_part_stride).  No atomics: bitwise reproducible.
- *   s3d_gemm_wgrad_group: for n <= 24 layers with the same row count K: dW_i[out][in] (+)= alpha * dy_i[K][out]^T x_i[K][in] and, when db is
+ *   s3d_gemm_wgrad_group: for n <= 48 layers with the same row count K: dW_i[out][in] (+)= alpha * dy_i[K][out]^T x_i[K][in] and, when db is
  *   set, db_i[out] (+)= alpha * colsum(dy_i); 128 x 128 output tiles over the full K, one workgroup per tile, plain read-modify-write
  *   (accumulate = 1) or overwrite (accumulate = 0): no split-K, no atomics, bitwise reproducible.  out, in, ld_dy, ld_x multiples of 8.
  *   s3d_gemm_dgrad_splitk_slices: the slices a request for `want` (1 .. 4) really gives for this K -- pass THAT count to both calls. */

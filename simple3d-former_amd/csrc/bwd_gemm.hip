@@ -376,11 +376,11 @@ __global__ __launch_bounds__(256) void ln_aux_kernel(const LnAuxArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // grouped wgrad: for every problem i,  dW_i[Mo][No] (+)= alpha * dy_i[K][Mo]^T x_i[K][No],  db_i[Mo] (+)= alpha * colsum(dy_i)
-constexpr int WG_MAX = 24;
+constexpr int WG_MAX = 48;                                             // 48 x 64-byte entries: the launch's kernel arguments stay under 4 KB
 struct WgProb {
     const bf16_t* dy; const bf16_t* x; float* dW; float* db;
-    long ld_dy, ld_x, ldw;
-    int Mo, No, ntx, tile0;                                            // tiles [tile0, tile0 + ntx * nty) of the launch
+    int ld_dy, ld_x, ldw;
+    int Mo, No, ntx, tile0, pad_;                                            // tiles [tile0, tile0 + ntx * nty) of the launch
 };
 struct WgGroup {
     WgProb p[WG_MAX];
@@ -658,10 +658,10 @@ int s3d_launch_wgrad_group(const S3dWgradItem* it, int n, int K, float alpha, in
     for (int i = 0; i < n; ++i) {
         const S3dWgradItem& q = it[i];
         S3D_REQUIRE(q.dy && q.x && q.dW && q.out >= 8 && q.in >= 8 && (q.out & 7) == 0 && (q.in & 7) == 0 && (q.ld_dy & 7) == 0 && (q.ld_x & 7) == 0 &&
-                        (q.ldw & 3) == 0 && q.ld_dy >= q.out && q.ld_x >= q.in && q.ldw >= q.in,
+                        (q.ldw & 3) == 0 && q.ld_dy >= q.out && q.ld_x >= q.in && q.ldw >= q.in && q.ld_dy < (1L << 31) && q.ld_x < (1L << 31) && q.ldw < (1L << 31),
                     "wgrad_group: problem %d: out=%d in=%d ld_dy=%ld ld_x=%ld ldw=%ld (multiples of 8; ldw of 4)", i, q.out, q.in, q.ld_dy, q.ld_x, q.ldw);
         WgProb& p = g.p[i];
-        p.dy = q.dy; p.x = q.x; p.dW = q.dW; p.db = q.db; p.ld_dy = q.ld_dy; p.ld_x = q.ld_x; p.ldw = q.ldw; p.Mo = q.out; p.No = q.in;
+        p.dy = q.dy; p.x = q.x; p.dW = q.dW; p.db = q.db; p.ld_dy = (int)q.ld_dy; p.ld_x = (int)q.ld_x; p.ldw = (int)q.ldw; p.Mo = q.out; p.No = q.in;
         p.ntx = (q.in + 127) / 128; p.tile0 = total;
         total += p.ntx * ((q.out + 127) / 128);
         flops += 2.0 * q.out * q.in * (double)K;

@@ -251,7 +251,7 @@ struct WgradDefer {
     bf16_t* ring = nullptr;
     int slots = 0, splitk = 1, accumulate = 1;
     size_t M = 0, D = 0, Hd = 0;
-    S3dWgradItem items[24];
+    S3dWgradItem items[48];
     int n = 0, pending_blocks = 0, next = 0;
     const bf16_t* dxa_cur = nullptr;               // d(x_out) (bf16) of the block about to run: the caller's dx_a_bf, then ring slots
     const float* aux = nullptr;                    // fused LayerNorm backward: the [u2 | c2 | u1 | c1] vectors, indexed by block
@@ -260,9 +260,9 @@ struct WgradDefer {
     // whose wgrads an EARLIER launch has finished -- go to the next launch as filler shares; ranges of the blocks it computes itself follow after it
     const S3dAdamFill* af = nullptr;
     long ready[6][2]; int nready = 0;              // {offset, count} in floats
-    long pend[24][2]; int npend = 0;               // ranges that become ready with the next flush
+    long pend[48][2]; int npend = 0;               // ranges that become ready with the next flush
     int* n_filled = nullptr;                       // running count of the ranges reported in af->filled
-    void defer_range(long off, long n) { if (npend < 24 && n >= 4) { pend[npend][0] = off; pend[npend][1] = n / 4 * 4; ++npend; } }
+    void defer_range(long off, long n) { if (npend < 48 && n >= 4) { pend[npend][0] = off; pend[npend][1] = n / 4 * 4; ++npend; } }
     void ready_range(long off, long n) { if (nready < 6 && n >= 4) { ready[nready][0] = off; ready[nready][1] = n / 4 * 4; ++nready; } }
     WgSlot slot(int i) const {
         bf16_t* b = ring + (size_t)i * wg_slot_elems(M, D, Hd);
@@ -455,7 +455,10 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
     const long plane = M * D;
     // fused: the two LayerNorm backward launches run as epilogues of the fc1 / qkv dgrads (bwd_gemm.hip, "Row statistics"): four launches
     // per block.  aux = this block's [u2 | c2 | u1 | c1]; rowstat = [norm2: s1, s2 | norm1: s1, s2], each [M]
-    const bool fused = wd.aux != nullptr;
+    // fa: attn.proj's dgrad + the attention backward as one launch (small token counts); otherwise -- the point path's 257-token sequences --
+    // the library GEMM tiles and the generic attention backward run the chain, and only the wgrads change (deferred, grouped, full K)
+    const bool fa = s3d_fused_attn_bwd_ok(sh.Bb, sh.N, D, sh.H);
+    const bool fused = wd.aux != nullptr && fa;
     const float* aux = fused ? wd.aux + (size_t)wd.block * 2 * (Hd + 3 * D) : nullptr;
     float* rs = w.ln_rowstat;
     const int nty = (int)((M + 63) / 64);
@@ -484,22 +487,36 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
         st.u = st.c = nullptr; st.rs1 = rs; st.rs2 = rs + M; st.zero_buf = nullptr; st.zero_n = 0;
         S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
     } else {
-        const int sl1 = s3d_dgrad_splitk_slices(Hd, wd.splitk);
-        S3D_TRY(s3d_launch_dgrad_splitk(g, sl1, plane, s));
-        lb.dy_parts = sl1; lb.dy_part_stride = plane;
+        if (fa) {
+            const int sl1 = s3d_dgrad_splitk_slices(Hd, wd.splitk);
+            S3D_TRY(s3d_launch_dgrad_splitk(g, sl1, plane, s));
+            lb.dy_parts = sl1; lb.dy_part_stride = plane;
+        } else {
+            S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+        }
         if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
         S3D_TRY(s3d_launch_ln_bwd(lb, s));
     }
     wd.push(S.dh, Hd, a.xn2_hi, D, gr.fc1_w, gr.fc1_b);
-    AttnArgs at;                // (only for the lse layout question)
+    AttnArgs at;
     memset(&at, 0, sizeof(at));
     at.Bb = sh.Bb; at.H = sh.H; at.N = sh.N; at.D = D; at.sb = sh.N; at.st = 1;
+    at.scale = 1.0f / sqrtf((float)(D / sh.H));
+    if (!fa) {
+        g = gemm_zero();        // datt = dx_mid @ Wproj, then dq / dk / dv
+        g.A_hi = S.dxb; g.lda = D; g.B_hi = p.proj_w_hi; g.ldb = D; g.M = (int)M; g.N = D; g.K = D; g.O_hi = w.datt; g.ldo = D;
+        S3D_TRY(s3d_launch_gemm(false, true, false, EPI_BF16_BIAS, g, 1, s));
+        at.qkv_hi = a.qkv_hi; at.qkv_lo = a.qkv_lo; at.ld = 3 * D; at.out_hi = a.att_hi; at.out_lo = sh.split ? a.att_lo : nullptr;
+        at.ldo = D; at.lse = a.lse;
+        at.dout = w.datt; at.lddo = D; at.dqkv = S.dqkv; at.lddq = 3 * D; at.delta = w.delta;
+        S3D_TRY(s3d_launch_attention_bwd(at, s));
+    }
     FusedAttnBwdArgs fb{};      // datt = dx_mid @ Wproj per head slice, then dq / dk / dv   [+ norm1's row statistics]
     fb.dxm = S.dxb; fb.lddxm = D; fb.w_hi = p.proj_w_hi; fb.qkv_hi = a.qkv_hi;
     fb.lse = a.lse; fb.dqkv = S.dqkv; fb.Bb = sh.Bb; fb.N = sh.N; fb.H = sh.H; fb.scale = 1.0f / sqrtf((float)(D / sh.H));
     fb.lse_packed = s3d_attention_pairs_packed(at) ? 1 : 0;
     if (fused) { fb.st_u = aux + 2 * Hd; fb.st_c = aux + 2 * Hd + 3 * D; fb.st_s1 = rs + 2 * M; fb.st_s2 = rs + 3 * M; }
-    S3D_TRY(s3d_launch_fused_attn_bwd(fb, D, s));
+    if (fa) S3D_TRY(s3d_launch_fused_attn_bwd(fb, D, s));
     wd.push(S.dxb, D, a.att_hi, D, gr.proj_w, gr.proj_b);
     wd.push(S.dqkv, 3 * D, a.xn1_hi, D, gr.qkv_w, gr.qkv_b);
     ++wd.pending_blocks;
@@ -520,10 +537,15 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
         st.rs1 = rs + 2 * M; st.rs2 = rs + 3 * M; st.zero_buf = rs; st.zero_n = (int)(2 * M);      // norm2's statistics are consumed: cleared here
         S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
     } else {
-        const int sl2 = s3d_dgrad_splitk_slices(3 * D, wd.splitk);
-        S3D_TRY(s3d_launch_dgrad_splitk(g, sl2, plane, s));
+        if (fa) {
+            const int sl2 = s3d_dgrad_splitk_slices(3 * D, wd.splitk);
+            S3D_TRY(s3d_launch_dgrad_splitk(g, sl2, plane, s));
+            lb.dy_parts = sl2; lb.dy_part_stride = plane;
+        } else {
+            S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+            lb.dy_parts = 0; lb.dy_part_stride = 0;
+        }
         if (flush_now) S3D_TRY(wd.flush(s));
-        lb.dy_parts = sl2; lb.dy_part_stride = plane;
         if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
         S3D_TRY(s3d_launch_ln_bwd(lb, s));
     }
@@ -681,7 +703,10 @@ int blocks_ln_aux(const S3dBlockShape& sh, const S3dBlockParams* p, const S3dBlo
 }
 bool wgrad_chain_ok(const S3dBlockShape& sh, const S3dBlockScratch& w) {
     if (w.wg_ring == nullptr || w.wg_slots < 1 || w.dx_a_lo != nullptr || bwd_streams_enabled()) return false;
-    if (sh.fuse != 0 || !s3d_fused_attn_bwd_ok(sh.Bb, sh.N, sh.D, sh.H)) return false;
+    // small token counts: the fused attention backward; long sequences at many rows (where a dgrad + wgrad pair is two launches anyway): the
+    // library tiles with the wgrads deferred
+    if (sh.fuse != 0) return false;
+    if (!s3d_fused_attn_bwd_ok(sh.Bb, sh.N, sh.D, sh.H) && (long)sh.Bb * sh.N <= 8192) return false;
     return (sh.D & 7) == 0 && (sh.hidden & 7) == 0 && w.dgrad_splitk >= 0 && w.dgrad_splitk <= 4;
 }
 }  // namespace
@@ -1101,7 +1126,7 @@ int s3d_blocks_bwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     WgradDefer wd;
     const bool chain = wgrad_chain_ok(*sh, *w);
     if (chain) {
-        wd.ring = w->wg_ring; wd.slots = w->wg_slots < 6 ? w->wg_slots : 6; wd.splitk = w->dgrad_splitk > 0 ? w->dgrad_splitk : 1;
+        wd.ring = w->wg_ring; wd.slots = w->wg_slots < 12 ? w->wg_slots : 12; wd.splitk = w->dgrad_splitk > 0 ? w->dgrad_splitk : 1;
         wd.M = (size_t)sh->Bb * sh->N; wd.D = sh->D; wd.Hd = sh->hidden;
         wd.dxa_cur = w->dx_a_bf;
         wd.accumulate = w->wg_overwrite ? 0 : 1;

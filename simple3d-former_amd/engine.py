@@ -231,7 +231,7 @@ def ln_partial_blocks(rows):
 
 
 class _BlockScratch:
-    def __init__(self, M, D, H, hidden, BHN, device, depth=0, precise=False, wgrad_ring=None):
+    def __init__(self, M, D, H, hidden, BHN, device, depth=0, precise=False, wgrad_ring=None, ln_bwd_fuse=True):
         """wgrad_ring = (slots, dgrad_splitk, slot_bytes): the dy ring of the dgrad chain (S3dBlockScratch::wg_ring, round 5) -- every
         block keeps d(x_out) / d(x_mid) / dh / dqkv in a slot of its own and the wgrads of `slots` blocks run as one grouped launch."""
         f32 = dict(dtype=torch.float32, device=device)
@@ -265,7 +265,7 @@ class _BlockScratch:
             slots, splitk, slot_bytes = wgrad_ring
             self.wg_ring = torch.empty(slots * slot_bytes, dtype=torch.uint8, device=device)
             L.fill(self.c, wg_ring=self.wg_ring, wg_slots=slots, dgrad_splitk=splitk)
-            if LN_BWD_FUSE and depth > 0:
+            if LN_BWD_FUSE and ln_bwd_fuse and depth > 0:
                 # the LayerNorm backward launches folded into the fc1 / qkv dgrads (S3dBlockScratch::ln_aux / ln_rowstat)
                 self.ln_aux = torch.zeros(depth * 2 * (hidden + 3 * D), **f32)
                 self.ln_rowstat = torch.zeros(4 * M, **f32)

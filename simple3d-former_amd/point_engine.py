@@ -29,6 +29,9 @@ import torch
 from . import _lib as L
 from .engine import BACKBONES, LN_EPS, ParamArena, _BlockScratch, _BlockWorkspace, _round_up
 
+# blocks whose wgrads share one grouped full-K launch on the long-sequence dgrad chain (capi.hip: block_bwd_chain); 0 = paired launches
+POINT_WGRAD_GROUP = int(os.environ.get('S3D_POINT_WGRAD_GROUP', '12'))
+
 KNN = 16
 BN_EPS = 1e-5
 GEOM_STREAM = os.environ.get('S3D_POINT_GEOM_STREAM', '1') != '0'    # geometry chain on a side stream (see PointEngine._geometry)
@@ -514,7 +517,13 @@ class PointEngine:
         M = B * ws.ntok
         ws.zero_pos = torch.zeros(ws.ntok, D, **f32)
         ws.blocks = _BlockWorkspace(self.depth, B, ws.ntok, D, self.H, 4 * D, dev, self.split)
-        ws.scratch = _BlockScratch(M, D, self.H, 4 * D, B * self.H * ws.ntok, dev, depth=self.depth)
+        ring = None
+        if POINT_WGRAD_GROUP > 0 and M > 8192:
+            # the blocks' wgrads leave the backward chain: dy tensors kept in a ring, up to six blocks' weight gradients as one full-K launch
+            # (capi.hip: block_bwd_chain, the long-sequence variant)
+            slot = int(self.lib.s3d_block_wgrad_slot_bytes(ctypes.byref(ws.blocks.shape)))
+            ring = (min(POINT_WGRAD_GROUP, 12, self.depth), 1, slot)
+        ws.scratch = _BlockScratch(M, D, self.H, 4 * D, B * self.H * ws.ntok, dev, depth=self.depth, wgrad_ring=ring, ln_bwd_fuse=False)
         ws.nstats = torch.empty(2, M, **f32)
         ws.xn = torch.empty(M, D, **f32)                       # norm(x) incl. cls rows
         ws.t = torch.empty(B * S1, D, **f32); ws.tp = torch.empty(2, B * S1, D, **b16)
