@@ -537,6 +537,8 @@ def _attn_ref(q, k, v):
 
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first', [(4, 6, 26, 64, False), (3, 3, 15, 256, False), (2, 3, 197, 256, False),
                                                 (5, 4, 100, 192, True), (2, 3, 257, 64, False), (64, 6, 26, 64, False),
+                                                # 9 / 17 tiles: five waves per workgroup (attention.hip: coop_five); 8 tiles: four
+                                                (2, 3, 513, 64, False), (2, 3, 250, 64, False),
                                                 (3, 4, 20, 96, True), (5, 4, 32, 48, False), (3, 2, 7, 64, False), (2, 2, 2, 64, False),
                                                 # even batch, N <= 16, contiguous: two sequences share one 32-row tile (pack_pairs)
                                                 (392, 3, 15, 256, False), (6, 6, 10, 64, False), (4, 4, 16, 48, False), (8, 3, 15, 192, False),
