@@ -504,6 +504,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
     // U rows per trip, every load of the trip in flight before the first use: one row per trip leaves a wave with 1.5 KB outstanding,
     // and the pass ran at 2.9 TB/s -- latency x bytes in flight, not HBM
     const long stride = (long)gridDim.x * l.rpb;
+    // The exact dx sums to zero over the rows of every channel; its bf16 copy does not -- the rounding residues of 2 M rows are a random walk,
+    // and whatever multiplies dx by a column of non-zero mean (a bias, post-ReLU features) picks up mean x (that walk) where the exact
+    // product cancels: 4 - 7 % of the small gradients of the classification model's input layers (profiles/r04_point_grad_noise.txt).  So the
+    // residue is carried: every element is rounded with the thread's running residue added, and what the threads of a workgroup are left
+    // with goes onto the last element of the quad's first row lane.  The column sum of the stored bf16 then misses the exact one by at most
+    // half an ulp per WORKGROUP instead of per element.
+    f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+    u32x2* last_p = nullptr;
+    union { u32x2 w; bf16_t h[4]; } last_o;
+    last_o.w = u32x2{0u, 0u};
     for (long r0 = (long)blockIdx.x * l.rpb + l.sub; r0 < rows; r0 += U * stride) {
         f32x4 xv[U], d[U];
         unsigned ab[U], kk[U];
@@ -530,10 +540,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
                 const bool on = xv[u][i] * a[i] + b[i] > 0.f && (!arg || kk[u] == ((ab[u] >> (8 * i)) & 255u));
                 const float gq = on ? d[u][i] : 0.f;
                 const float xh = (xv[u][i] - m[i]) * rs[i];
-                o.h[i] = f2bf(a[i] * (gq - s1[i] - xh * s2[i]));
+                const float v = a[i] * (gq - s1[i] - xh * s2[i]) + carry[i];
+                o.h[i] = f2bf(v);
+                carry[i] = v - bf2f(o.h[i]);
             }
-            *reinterpret_cast<u32x2*>(dx + r * lddx + c) = o.w;
+            last_p = reinterpret_cast<u32x2*>(dx + r * lddx + c);
+            *last_p = o.w;
+            last_o.w = o.w;
         }
+    }
+    __shared__ f32x4 left[256];
+    left[threadIdx.x] = carry;
+    __syncthreads();
+    if (l.sub == 0 && last_p != nullptr) {
+        const int c4 = C >> 2;
+        f32x4 e = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < l.rpb; ++j) e += left[j * c4 + l.q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) last_o.h[i] = f2bf(bf2f(last_o.h[i]) + e[i]);
+        *last_p = last_o.w;
     }
 }
 

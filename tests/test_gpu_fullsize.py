@@ -175,22 +175,21 @@ def _point_fullsize_parity(task, n_points, d_points, n_classes, B, rtol, loose=N
 
 
 def test_cfg4_full_size_parity():
-    """Gradient bar 10 % rms (rtol 1e-2) where the voxel configurations hold 3 % and cfg-5 4 %.  Measured and explained
-    (tools/probes/point_grad_noise_probe.py, profiles/r04_point_grad_noise.txt): the gradient that leaves a train-mode BatchNorm sums
-    to ZERO over the rows of every channel; it is stored as bf16 (S3dBnArgs::dx), whose rounding residues do not sum to zero, so
-    everything that multiplies it by a column with a non-zero MEAN -- the feature columns of the set-abstraction convolution, the
-    relu(.) inputs of fc1.2 / fc_pos_embed.2, the all-ones column of a bias -- picks up mean * (random walk of residues) where the
-    exact product cancels.  Column by column the error of TransitionDown 0's conv-0 weight follows |mean f| / std f: 1.8 % of the
-    column's gradient at a ratio of 0.03, 21 % at 6.3.  The classification model is hit hardest (one gradient row per cloud,
-    broadcast to its 1024 points: x.mean(1), models/3DViT/model.py:325 -- weakly correlated with the features): 4 - 7 % on the input
-    MLPs / that convolution / cls_token, identical in deterministic mode (rounding, not atomic order), regression coefficient
-    alpha = 1.000 +- 0.007 (no bias); from the transformer blocks upward everything is below 1 %.  The one tensor with a wider
-    entry / block bar is that convolution's weight (columns of very different mean-to-spread ratio share a 64 x 64 block)."""
-    _point_fullsize_parity('cls', 1024, 6, 40, 128, rtol=1e-2, loose={'transition_downs.0.sa.mlp_convs.0.weight': 1.5})
+    """Gradient bar 5 % rms (rtol 5e-3), no loosened tensor.  Until round 4 the bar was 10 %: the gradient that leaves a train-mode
+    BatchNorm sums to ZERO over the rows of every channel, its bf16 copy (S3dBnArgs::dx) did not, and everything that multiplies it by
+    a column with a non-zero MEAN -- the feature columns of the set-abstraction convolution, the relu(.) inputs of fc1.2 /
+    fc_pos_embed.2, the all-ones column of a bias -- picked up mean * (random walk of 2 M rounding residues) where the exact product
+    cancels (tools/probes/point_grad_noise_probe.py, profiles/r04_point_grad_noise.txt): 6.9 % on fc_pos_embed.0.bias, 4.9 % (27 % in the
+    worst 64 x 64 block) on TransitionDown 0's conv-0 weight.  Round 5: the apply kernel carries the rounding residue from element to
+    element (points.hip: bn_bwd_apply_vec_kernel), the stored column sums miss zero by half an ulp per workgroup -> 2.4 % / 1.7 % (5.4 %
+    worst block) on those two.  What is left on top is cls_token (4.3 - 4.7 %, unchanged): the sum of 128 per-cloud class-row gradients
+    that went through twelve plain-bf16 block backwards (models/3DViT/model.py:325: every token row carries 1/257 of the pooled
+    gradient) -- rounding noise of the backward itself, alpha = 0.998."""
+    _point_fullsize_parity('cls', 1024, 6, 40, 128, rtol=5e-3)
 
 
 def test_cfg5_full_size_parity():
-    _point_fullsize_parity('seg', 2048, 22, 50, 32, rtol=4e-3)
+    _point_fullsize_parity('seg', 2048, 22, 50, 32, rtol=2e-3)       # 2 % rms bar (4 % until the BatchNorm dx residue carry of round 5); worst 0.9 %
 
 
 @pytest.mark.parametrize('B,dropout', [(4, 0.0), (4, 0.1), (7, 0.1)])

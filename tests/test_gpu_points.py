@@ -94,6 +94,42 @@ def test_batchnorm_relu_max_fwd_bwd(rows, C, K):
     assert rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
 
 
+@pytest.mark.parametrize('rows,C,K', [(524288, 64, 0), (32768 * 16, 64, 16)])
+def test_batchnorm_backward_bf16_dx_keeps_its_zero_column_sums(rows, C, K):
+    """The gradient that leaves a train-mode BatchNorm sums to zero over the rows of every channel (pointnet_util.py:238-241); its bf16
+    copy (S3dBnArgs::dx) keeps that property to within half an ulp per WORKGROUP because the apply kernel carries the rounding residue
+    from element to element (points.hip: bn_bwd_apply_vec_kernel) -- plain rounding leaves a random walk over all rows, which the
+    consumers multiply by their columns' means (the 4 - 7 % gradient errors of cfg-4's input layers until round 4)."""
+    g = torch.Generator().manual_seed(C + K)
+    x = torch.randn(rows, C, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.1 * torch.randn(C, generator=g); beta = 0.1 * torch.randn(C, generator=g)
+    xr = x.clone().double().requires_grad_(True)
+    y = F.relu(F.batch_norm(xr, None, None, gamma.double(), beta.double(), training=True, eps=1e-5))
+    if K:
+        y = y.view(rows // K, K, C).max(dim=1)[0]
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = xr.grad
+    f = lambda t: t.to(DEV)
+    xd, gd, bd, dyd = f(x), f(gamma), f(beta), f(dy)
+    mean = torch.zeros(C, device=DEV); rstd = torch.zeros(C, device=DEV); sums = torch.zeros(2 * C, dtype=torch.float64, device=DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    out = torch.empty(y.shape, device=DEV); arg = torch.zeros(y.shape, dtype=torch.uint8, device=DEV)
+    dx = torch.empty(rows, C, dtype=torch.bfloat16, device=DEV); dg = torch.zeros(C, device=DEV); db = torch.zeros(C, device=DEV)
+    a = L.fill(L.S3dBnArgs(), x=xd, ldx=C, rows=rows, C=C, K=K, eps=1e-5, momentum=0.1, gamma=gd, beta=bd, mean=mean, rstd=rstd,
+               run_mean=rmd, run_var=rvd, sums=sums, y=out, ldo=C, arg=arg, dy=dyd, lddy=C, dx=dx, lddx=C, dgamma=dg, dbeta=db)
+    L.check(L.lib().s3d_batchnorm_fwd(ctypes.byref(a), L.current_stream()), 'bn fwd')
+    L.check(L.lib().s3d_batchnorm_bwd(ctypes.byref(a), L.current_stream()), 'bn bwd')
+    got = dx.double().cpu()
+    assert rel_err(got, ref) < 1.5e-2
+    assert float(ref.sum(0).abs().max()) < 1e-9 * rows                     # the exact gradient: zero column sums
+    walk = (ref.float().to(torch.bfloat16).double() - ref).sum(0)           # what rounding every element on its own leaves per channel
+    kept = got.sum(0)
+    ratio = float(kept.pow(2).mean().sqrt() / walk.pow(2).mean().sqrt())
+    print(f'bf16 dx column sums: rms {float(kept.pow(2).mean().sqrt()):.3e} against {float(walk.pow(2).mean().sqrt()):.3e} for plain rounding ({ratio:.3f})')
+    assert ratio < 0.4
+
+
 def test_gather_scatter_interp():
     g = torch.Generator().manual_seed(5)
     B, N, S, K, C = 2, 40, 10, 16, 8
