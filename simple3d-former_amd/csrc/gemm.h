@@ -20,6 +20,10 @@ typedef S3dGemmArgs GemmArgs;
 // ta/tb: operand stored k-major.  splitk <= 0: automatic (wgrad only).  Returns 0 on success.
 int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a, int splitk, hipStream_t stream);
 
+// row-stream kernel (rowstream_gemm.hip): forward NT, split precision, F32 epilogue, K <= 96, N <= 192, >= 32768 rows
+bool s3d_rowstream_gemm_ok(bool split, int epi, const GemmArgs& a);
+int s3d_launch_rowstream_gemm(const GemmArgs& a, hipStream_t stream);
+
 // forward NT RESID launch that would run the fused LayerNorm epilogue (GemmArgs::ln_tickets), see gemm.hip
 bool s3d_gemm_ln_fusable(bool split, const GemmArgs& a);
 int s3d_gemm_pick_tile(int M, int N, int splitk, bool split);

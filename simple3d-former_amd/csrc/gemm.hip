@@ -2104,8 +2104,13 @@ int s3d_launch_gemm(bool ta, bool tb, bool split, int epi, const GemmArgs& a_in,
     if (tb) S3D_REQUIRE((a.N % 8) == 0, "gemm: N=%d must be a multiple of 8 for a k-major B", a.N);
     if (split) S3D_REQUIRE(a.A_lo && a.B_lo, "gemm: split mode needs lo planes");
     if (a.col_sums)
-        S3D_REQUIRE(!ta && !tb && epi == EPI_F32 && s3d_gemm_col_sums_ok(split ? 1 : 0, a.M, a.N),
+        S3D_REQUIRE(!ta && !tb && epi == EPI_F32 && (s3d_gemm_col_sums_ok(split ? 1 : 0, a.M, a.N) || s3d_rowstream_gemm_ok(split, epi, a)),
                     "gemm: col_sums needs the forward F32 epilogue on 128x128 tiles (M=%d N=%d; ask s3d_gemm_col_sums_ok)", a.M, a.N);
+
+    // millions of rows against a weight matrix that fits in LDS (the point path's 1x1 convolutions): one wave per 16-row chunk, no tiles
+    static const int rowstream_off = s3d_tune_int("S3D_ROWSTREAM");     // tuning builds: 0 = the 128 x 128 tiles
+    if (!ta && !tb && rowstream_off != 0 && s3d_rowstream_gemm_ok(split, epi, a))
+        return s3d_launch_rowstream_gemm(a, stream);
 
     if (ta && tb) {   // wgrad: split-K with fp32 atomics
         S3D_REQUIRE(epi == EPI_ATOMIC, "gemm: TN supports only the atomic epilogue");

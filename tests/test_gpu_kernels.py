@@ -369,6 +369,31 @@ def test_gemm_column_sums_for_the_following_batchnorm(M, N, K):
     assert L.lib().s3d_gemm_col_sums_ok(1, 1664, 384) == 0
 
 
+@pytest.mark.parametrize('M,N,K,sums', [(40000, 96, 96, True), (33001, 96, 48, False), (32768 + 5, 192, 96, False), (50000, 48, 48, True),
+                                        (1 << 20, 96, 96, True), (33000, 64, 40, True), (32768, 128, 8, False), (65536 + 17, 192, 96, True),
+                                        (131072, 48, 24, False)])
+def test_gemm_rowstream_convolution(M, N, K, sums):
+    """rowstream_gemm.hip: the point path's 1x1 convolutions / per-point projections (pointnet_util.py:238-241 at >= 32768 rows, K <= 96,
+    N <= 192) -- every wave multiplies 16-row chunks straight from global memory against weight planes staged in LDS.  Against the fp64
+    product of the same split operands; ragged M, K not a multiple of 32, two column passes, the BatchNorm column sums."""
+    g = torch.Generator().manual_seed(M % 977 + N + K)
+    x = (torch.randn(M, K, generator=g) * 1.3 + 0.2).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.2).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    xh, xl = ops.split_bf16(x); wh, wl = ops.split_bf16(w)
+    ldc = N + 4                                                # a padded output pitch: nothing may land in the pad columns
+    y = torch.full((M, ldc), 7.0, device=DEV)
+    s = torch.zeros(2 * N, dtype=torch.float64, device=DEV) if sums else None
+    kw = dict(col_sums=s) if sums else {}
+    ops.gemm(0, 0, 1, 'F32', A_hi=xh, A_lo=xl, lda=K, B_hi=wh, B_lo=wl, ldb=K, M=M, N=N, K=K, bias=b, C=y, ldc=ldc, alpha=0.5, **kw)
+    ref = 0.5 * ((xh.double() + xl.double()) @ (wh.double() + wl.double()).t()) + b.double()
+    assert rel_err(y[:, :N], ref) < 1e-5
+    assert float((y[:, N:] - 7.0).abs().max()) == 0.0
+    if sums:
+        yd = y[:, :N].double()
+        assert rel_err(s[:N], yd.sum(0)) < 1e-6 and rel_err(s[N:], (yd * yd).sum(0)) < 1e-6
+
+
 def test_gemm_wgrad_into_a_sub_matrix():
     """The factored set-abstraction convolution accumulates d(Wf) INSIDE the conv weight's gradient: C = dW + 3 columns, ldc = 3 + I."""
     g = torch.Generator().manual_seed(13)
