@@ -314,6 +314,9 @@ def test_fused_layernorm_backward_chain_row_statistics(rows, D, Hd):
     (1664, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 0),           # overwrite mode
     (208, [(192, 768), (768, 192), (192, 192), (576, 192)] * 2, 1),           # cfg-1-sized (partial last k-tile: 208 = 3 * 64 + 16)
     (78, [(136, 72), (72, 136), (8, 8), (264, 40)], 1),                       # ragged edges on every side, odd row count
+    (1000, [(304, 320), (64, 192), (192, 256), (448, 128), (320, 72), (136, 200)], 1),   # 1.5 / 2.5 / 3.5 tiles per side, partial last k-tile
+    (32896, [(192, 768), (768, 192), (192, 192), (576, 192)] * 2, 0),         # cfg-4: the point path's blocks (257-token sequences x 128 clouds)
+    (16416 + 8, [(192, 768), (768, 192), (192, 192), (576, 192)] * 3, 1),     # cfg-5 rows + a k tail, accumulate
 ])
 def test_gemm_wgrad_group_full_k_deterministic(rows, shapes, acc):
     """s3d_gemm_wgrad_group: dW_i (+)= dy_i^T x_i and db_i (+)= colsum(dy_i) for a list of layers in ONE launch, every output tile owned by one
