@@ -122,6 +122,11 @@ int s3d_ln_aux(const S3dLnAuxLayer* layers, int n, int D, s3d_stream_t stream); 
 struct S3dLnBwdArgs;
 int s3d_gemm_dgrad_dgelu(const S3dGemmArgs* args, const S3dRowStats* stats, s3d_stream_t stream);   /* O_hi = bf16(A @ B * gelu'(aux)); stats may be NULL */
 int s3d_gemm_dgrad_lnbwd(const S3dGemmArgs* args, const struct S3dLnBwdArgs* ln, const S3dRowStats* stats, s3d_stream_t stream);
+/* The same for 192-wide layers at many rows (deit_tiny: the point path's 257 / 513-token sequences): 64 x 192 tiles hold WHOLE rows, so the row
+ * statistics come from the tile itself -- no producer, any dgrad that feeds a LayerNorm backward (fc1 -> norm2, qkv -> norm1).  N == 192,
+ * K % 32 == 0; ln->partial (if set) receives one row of [2][192] column sums per 64-row tile (ln->partial_blocks >= ceil(M / 64)).
+ * Replaces a dgrad with the F32 epilogue + s3d_layernorm_bwd (models/3DViT/model.py:318-320 backward). */
+int s3d_gemm_dgrad_lnrows(const S3dGemmArgs* args, const struct S3dLnBwdArgs* ln, s3d_stream_t stream);
 int s3d_gemm_dgrad_splitk_slices(int K, int want);
 int s3d_gemm_dgrad_splitk(const S3dGemmArgs* args, int nslice, long slice_stride, s3d_stream_t stream);
 int s3d_gemm_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, s3d_stream_t stream);

@@ -18,3 +18,6 @@ int s3d_launch_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha,
 int s3d_launch_dgrad_dgelu(const S3dGemmArgs& a, const S3dRowStats* st, hipStream_t s);
 int s3d_launch_dgrad_lnbwd(const S3dGemmArgs& a, const S3dLnBwdArgs& ln, const S3dRowStats* st, hipStream_t s);
 int s3d_launch_ln_aux(const S3dLnAuxLayer* layers, int n, int D, hipStream_t s);
+// the same for 192-wide layers with WHOLE rows per workgroup (64 x 192 tiles): the row statistics come from the tile itself
+bool s3d_dgrad_lnrows_ok(const S3dGemmArgs& a, const S3dLnBwdArgs& ln);
+int s3d_launch_dgrad_lnrows(const S3dGemmArgs& a, const S3dLnBwdArgs& ln, hipStream_t s);

@@ -347,6 +347,201 @@ __global__ __launch_bounds__(256 * KS) void dgrad_kernel(const DgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// dgrad + LayerNorm backward for 192-wide layers (deit_tiny: the point path's 32 896 / 16 416 token rows), WHOLE rows per workgroup:
+// dx = LayerNorm'(dy = A @ B) + dres with the row statistics taken from the tile itself -- a 64 x 192 tile IS 64 complete rows, so no
+// producer-side statistics are needed (fc1 -> norm2 and qkv -> norm1 alike).  Replaces a 128 x 128-tile dgrad that writes dy as fp32
+// (25 MB) plus the ln_bwd_kernel that reads it back: 30 + 29 us -> one launch (cfg-4).
+// 256 threads = 2 x 2 waves of 32 x 96; k-tiles of 32: A 64 rows x 64 B + B three k-major panels of 32 x 64 = 16 KB per stage, NS stages.
+struct DgradLnRowsArgs {
+    const bf16_t* A; const bf16_t* B;
+    long lda, ldb;
+    int M, K;
+    float alpha;
+    const float* x; long ldx; const float* mean; const float* rstd; const float* gamma; const float* dres; long lddres;
+    float* dx; long lddx; bf16_t* dx_bf; long lddxbf;
+    float* partial; float* dgamma; float* dbeta;                         // partial: [row tiles][2][192] column sums (else atomics)
+};
+
+template <int NS>
+__global__ __launch_bounds__(256) void dgrad_lnrows_kernel(const DgradLnRowsArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int N = 192, STAGE = 16384, PPW = 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ty = blockIdx.x, m0 = ty * 64;
+    const int ntiles = p.K >> 5;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
+    // DMA pieces of a stage (1 KB each): wave w -> A rows 16 w .. + 15 (64 B each, chunk swizzle (row >> 2) & 3) and k-rows 8 w .. + 7 of the
+    // three B panels (128 B each, kmajor_swz<64>)
+    const bf16_t* gpa;
+    const bf16_t* gpb[3];
+    {
+        const int row = wave * 16 + (lane >> 2), slot = lane & 3;
+        gpa = p.A + (long)min(m0 + row, p.M - 1) * p.lda + ((slot ^ ((row >> 2) & 3)) << 3);
+        const int r = wave * 8 + (lane >> 3), c = lane & 7, cg = c ^ kmajor_swz<64>(r);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) gpb[q] = p.B + (long)r * p.ldb + q * 64 + cg * 8;
+    }
+    const long gstep_b = 32 * p.ldb;
+    auto issue = [&](int t) {
+        const unsigned dst = lds0 + (unsigned)((t % NS) * STAGE + wave * 1024);
+        glds16(gpa + (long)t * 32, dst);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) glds16(gpb[q] + (long)t * gstep_b, dst + 4096 + q * 4096);
+    };
+    f32x4 acc[2][6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < ntiles) issue(u);
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + NS - 1 <= ntiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + NS - 1 < ntiles) issue(t + NS - 1);
+        const unsigned char* sA = smem + (t % NS) * STAGE;
+        const unsigned char* sB = sA + 4096;
+        bf16x8 a[2], b[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 32 + i * 16 + (lane & 15);
+            a[i] = *reinterpret_cast<const bf16x8*>(sA + row * 64 + (((lane >> 4) ^ ((row >> 2) & 3)) << 4));
+        }
+        const int kq8 = (lane >> 4) * 8;
+        if (wn == 0) {                                                  // columns 0 .. 95: panel 0, first half of panel 1
+            bf16x8 b4[4], b2[2];
+            frags_kmajor<64, 4>(sB, 0, kq8, lane, b4);
+            frags_kmajor<64, 2>(sB + 4096, 0, kq8, lane, b2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = b4[j];
+            b[4] = b2[0]; b[5] = b2[1];
+        } else {                                                        // columns 96 .. 191: second half of panel 1, panel 2
+            bf16x8 b4[4], b2[2];
+            frags_kmajor<64, 2>(sB + 4096, 32, kq8, lane, b2);
+            frags_kmajor<64, 4>(sB + 8192, 0, kq8, lane, b4);
+            b[0] = b2[0]; b[1] = b2[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[2 + j] = b4[j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+    }
+    // park the accumulators (lane = row, four consecutive columns per fragment): complete rows of dy in LDS
+    constexpr int LDC = N + 4;
+    float* ct = reinterpret_cast<float*>(smem);                         // fp32 [64][LDC] = 50 KB of the 64 KB ring
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            *reinterpret_cast<f32x4*>(ct + (wm * 32 + i * 16 + (lane & 15)) * LDC + wn * 96 + j * 16 + (lane >> 4) * 4) = acc[i][j] * p.alpha;
+    __syncthreads();
+    // thread t: columns 64 q + 8 (t & 7) .. + 7 (q = 0, 1, 2) of rows (t >> 3) and (t >> 3) + 32 -- the eight lanes of an octet hold a whole row
+    const int c8 = 8 * (tid & 7);
+    const float* __restrict__ xin = p.x;                                // (restrict: the second row's loads may pass the first row's stores)
+    const float* __restrict__ rin = p.dres;
+    float* __restrict__ dxo = p.dx;
+    bf16_t* __restrict__ dxb = p.dx_bf;
+    float g8[3][8], cg[3][8], cb[3][8];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gamma + 64 * q + c8 + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g8[q][4 * h + e] = gm[e]; cg[q][4 * h + e] = 0.f; cb[q][4 * h + e] = 0.f; }
+        }
+    const float inv_n = 1.0f / (float)N;
+    // both rows' inputs are requested before either is used (a load issued next to its use costs its whole latency, twice per workgroup)
+    f32x4 xr[2][3][2], rr[2][3][2];
+    float rmean[2], rrstd[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const long mr = min((long)m0 + (tid >> 3) + 32 * it, (long)p.M - 1);
+        rmean[it] = p.mean[mr]; rrstd[it] = p.rstd[mr];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                xr[it][q][h] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xin + mr * p.ldx + 64 * q + c8 + 4 * h));
+                rr[it][q][h] = rin ? *reinterpret_cast<const f32x4*>(rin + mr * p.lddres + 64 * q + c8 + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = (tid >> 3) + 32 * it;
+        const bool ok = m0 + r < p.M;
+        const float mean = rmean[it], rstd = rrstd[it];
+        float dy[3][8], xh[3][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(ct + r * LDC + 64 * q + c8 + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = d4[e] * g8[q][4 * h + e], xv = (xr[it][q][h][e] - mean) * rstd;
+                    dy[q][4 * h + e] = d4[e]; xh[q][4 * h + e] = xv;
+                    s1 += g; s2 = fmaf(g, xv, s2);
+                }
+            }
+        s1 = oct_sum(s1) * inv_n; s2 = oct_sum(s2) * inv_n;
+        s1 = __shfl(s1, lane & ~7, 64); s2 = __shfl(s2, lane & ~7, 64);  // (oct_sum leaves the total in lane & 7 == 0 and its mirror)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float d[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * h + e;
+                    d[k] = rstd * (dy[q][k] * g8[q][k] - s1 - xh[q][k] * s2) + rr[it][q][h][e];
+                    if (ok) { cg[q][k] = fmaf(dy[q][k], xh[q][k], cg[q][k]); cb[q][k] += dy[q][k]; }
+                }
+            }
+            if (ok) {
+                if (dxo) {
+                    *reinterpret_cast<f32x4*>(dxo + (long)(m0 + r) * p.lddx + 64 * q + c8) = f32x4{d[0], d[1], d[2], d[3]};
+                    *reinterpret_cast<f32x4*>(dxo + (long)(m0 + r) * p.lddx + 64 * q + c8 + 4) = f32x4{d[4], d[5], d[6], d[7]};
+                }
+                if (dxb) {
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf2(d[2 * e], d[2 * e + 1]);
+                    *reinterpret_cast<u32x4*>(dxb + (long)(m0 + r) * p.lddxbf + 64 * q + c8) = o;
+                }
+            }
+        }
+    }
+    if (p.partial != nullptr || p.dgamma != nullptr) {                 // uniform: column sums of dy xh / dy over the tile's rows
+        __syncthreads();                                               // every thread has read its rows of ct
+        float* red = reinterpret_cast<float*>(smem);                    // [32 row pairs][2][192]
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<f32x4*>(red + ((tid >> 3) * 2 + 0) * N + 64 * q + c8 + 4 * h) = f32x4{cg[q][4 * h], cg[q][4 * h + 1], cg[q][4 * h + 2], cg[q][4 * h + 3]};
+                *reinterpret_cast<f32x4*>(red + ((tid >> 3) * 2 + 1) * N + 64 * q + c8 + 4 * h) = f32x4{cb[q][4 * h], cb[q][4 * h + 1], cb[q][4 * h + 2], cb[q][4 * h + 3]};
+            }
+        __syncthreads();
+        for (int idx = tid; idx < 2 * N; idx += 256) {
+            const int which = idx / N, col = idx % N;
+            float sum = 0.f;
+#pragma unroll 8
+            for (int rp = 0; rp < 32; ++rp) sum += red[(rp * 2 + which) * N + col];
+            if (p.partial) p.partial[((long)ty * 2 + which) * N + col] = sum;
+            else atomic_add_f32((which ? p.dbeta : p.dgamma) + col, sum);
+        }
+    }
+}
+
 // ---- weights-only vectors of the row statistics (see above): for every row k of a Linear weight W [K][D] that follows a LayerNorm
 //      (gamma, beta):  u[k] = mean_n(W_hi[k][n] gamma[n])  (the dgrad multiplies by the HIGH plane),  c[k] = b[k] + sum_n (W_hi + W_lo)[k][n] beta[n]
 //      (the forward's pre-activation was computed from both planes).  One wave per row, eight rows per workgroup.
@@ -629,6 +824,35 @@ int s3d_launch_dgrad_lnbwd(const GemmArgs& a, const LnBwdArgs& ln, const S3dRowS
     d.in_s1 = st->rs1; d.in_s2 = st->rs2; d.inv_d = 1.0f / (float)a.N; d.zero_buf = st->zero_buf; d.zero_n = st->zero_n;
     S3D_REQUIRE(st->zero_n <= ((a.N + 63) / 64) * ((a.M + 63) / 64) * 256, "dgrad_lnbwd: zero_n=%d exceeds the launch's threads", st->zero_n);
     return launch_dgrad<DG_LNBWD>(d, 1300000000000LL + 64064, 2.0 * a.M * a.N * a.K, "dgrad_lnbwd", ln.partial ? 1 : 0, s);      // bench.py: 13
+}
+
+// dx = LayerNorm'(dy = a.A @ a.B) + dres for 192-wide layers, whole rows per workgroup (no producer statistics); ln->dy is ignored
+bool s3d_dgrad_lnrows_ok(const GemmArgs& a, const LnBwdArgs& ln) {
+    return a.N == 192 && ln.D == 192 && a.M > 0 && ln.rows == a.M && a.K >= 32 && (a.K & 31) == 0 && (a.lda & 7) == 0 && (a.ldb & 7) == 0 && a.A_hi && a.B_hi &&
+           a.bias == nullptr && ln.x && ln.mean && ln.rstd && ln.gamma && (ln.dx || ln.dx_bf) && ln.drop_thr == 0 && ln.dx_bf_lo == nullptr && ln.dy_parts == 0 &&
+           (ln.ldx & 3) == 0 && (ln.lddres & 3) == 0 && (ln.lddx & 3) == 0 && (ln.lddxbf & 7) == 0 && (ln.partial == nullptr || ln.partial_blocks >= (a.M + 63) / 64);
+}
+int s3d_launch_dgrad_lnrows(const GemmArgs& a, const LnBwdArgs& ln, hipStream_t s) {
+    S3D_REQUIRE(s3d_dgrad_lnrows_ok(a, ln), "dgrad_lnrows: M=%d N=%d K=%d: 192 columns, K a multiple of 32, a LayerNorm over the same rows", a.M, a.N, a.K);
+    DgradLnRowsArgs d;
+    memset(&d, 0, sizeof(d));
+    d.A = a.A_hi; d.B = a.B_hi; d.lda = a.lda; d.ldb = a.ldb; d.M = a.M; d.K = a.K; d.alpha = a.alpha;
+    d.x = ln.x; d.ldx = ln.ldx; d.mean = ln.mean; d.rstd = ln.rstd; d.gamma = ln.gamma; d.dres = ln.dres; d.lddres = ln.lddres;
+    d.dx = ln.dx; d.lddx = ln.lddx; d.dx_bf = ln.dx_bf; d.lddxbf = ln.lddxbf;
+    d.partial = ln.partial; d.dgamma = ln.dgamma; d.dbeta = ln.dbeta;
+    constexpr long long KEY = 1400000000000LL + 64192;                  // bench.py: 14 = dgrad + LayerNorm backward, whole rows
+    if (s3d_prof_skipped(KEY)) return 0;
+    s3d_prof_begin(KEY, 2.0 * a.M * a.N * a.K, s);
+    // three stages = 48 KB of ring, 50 KB with the fp32 row tile of the epilogue: THREE workgroups per CU, so that cfg-4's 514 tiles are one
+    // round of resident workgroups (at four stages = two per CU, 512 slots, the last two tiles ran alone: 45 us per launch)
+    constexpr int NS = 3, LDS = 64 * 196 * 4;
+    static_assert(LDS >= NS * 16384, "ring fits");
+    static bool set = false;
+    set_lds_once(dgrad_lnrows_kernel<NS>, LDS, set);
+    hipLaunchKernelGGL((dgrad_lnrows_kernel<NS>), dim3((unsigned)((a.M + 63) / 64)), dim3(256), LDS, s, d);
+    s3d_prof_end(s);
+    S3D_CHECK_LAUNCH_V("dgrad_lnrows", ln.partial ? 1 : 0);
+    return 0;
 }
 
 int s3d_launch_ln_aux(const S3dLnAuxLayer* layers, int n, int D, hipStream_t s) {

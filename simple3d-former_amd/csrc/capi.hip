@@ -487,15 +487,22 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
         st.u = st.c = nullptr; st.rs1 = rs; st.rs2 = rs + M; st.zero_buf = nullptr; st.zero_n = 0;
         S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
     } else {
-        if (fa) {
-            const int sl1 = s3d_dgrad_splitk_slices(Hd, wd.splitk);
-            S3D_TRY(s3d_launch_dgrad_splitk(g, sl1, plane, s));
-            lb.dy_parts = sl1; lb.dy_part_stride = plane;
+        // 192-wide layers at many rows (the point path): 64 x 192 tiles hold whole rows, the LayerNorm backward is the dgrad's epilogue
+        const bool rows_fused = !fa && nty <= w.ln_partial_blocks && lp != nullptr && !s3d_deterministic() && s3d_dgrad_lnrows_ok(g, lb);
+        if (rows_fused) {
+            lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b, nty); lb.partial_blocks = w.ln_partial_blocks;
+            S3D_TRY(s3d_launch_dgrad_lnrows(g, lb, s));
         } else {
-            S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+            if (fa) {
+                const int sl1 = s3d_dgrad_splitk_slices(Hd, wd.splitk);
+                S3D_TRY(s3d_launch_dgrad_splitk(g, sl1, plane, s));
+                lb.dy_parts = sl1; lb.dy_part_stride = plane;
+            } else {
+                S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
+            }
+            if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
+            S3D_TRY(s3d_launch_ln_bwd(lb, s));
         }
-        if (lp) { lb.partial = lp->slot(w, D, gr.ln2_w, gr.ln2_b); lb.partial_blocks = w.ln_partial_blocks; }
-        S3D_TRY(s3d_launch_ln_bwd(lb, s));
     }
     wd.push(S.dh, Hd, a.xn2_hi, D, gr.fc1_w, gr.fc1_b);
     AttnArgs at;
@@ -537,13 +544,22 @@ int block_bwd_chain(const S3dBlockShape& sh, const S3dBlockParams& p, const S3dB
         st.rs1 = rs + 2 * M; st.rs2 = rs + 3 * M; st.zero_buf = rs; st.zero_n = (int)(2 * M);      // norm2's statistics are consumed: cleared here
         S3D_TRY(s3d_launch_dgrad_lnbwd(g, lb, &st, s));
     } else {
+        lb.dy_parts = 0; lb.dy_part_stride = 0;
+        const bool rows_fused = !fa && nty <= w.ln_partial_blocks && lp != nullptr && !s3d_deterministic() && s3d_dgrad_lnrows_ok(g, lb);
+        if (rows_fused) {
+            if (flush_now) S3D_TRY(wd.flush(s));                     // (the epilogue writes the next block's d(x_out): pending wgrads first)
+            lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b, nty); lb.partial_blocks = w.ln_partial_blocks;
+            S3D_TRY(s3d_launch_dgrad_lnrows(g, lb, s));
+            wd.next = next;
+            wd.dxa_cur = dxa_next;
+            return 0;
+        }
         if (fa) {
             const int sl2 = s3d_dgrad_splitk_slices(3 * D, wd.splitk);
             S3D_TRY(s3d_launch_dgrad_splitk(g, sl2, plane, s));
             lb.dy_parts = sl2; lb.dy_part_stride = plane;
         } else {
             S3D_TRY(s3d_launch_gemm(false, true, false, EPI_F32, g, 1, s));
-            lb.dy_parts = 0; lb.dy_part_stride = 0;
         }
         if (flush_now) S3D_TRY(wd.flush(s));
         if (lp) lb.partial = lp->slot(w, D, gr.ln1_w, gr.ln1_b);
@@ -722,7 +738,10 @@ struct Carver {
     }
 };
 // LayerNorm-backward partial rows per LayerNorm: engine.py::ln_partial_blocks
-int ws_ln_partial_blocks(long rows) { return rows <= 8192 ? 208 : 416; }
+int ws_ln_partial_blocks(long rows, int D) {
+    if (D == 192 && rows > 8192) return (int)std::max<long>(416, (rows + 63) / 64);      // one row of partials per 64-row tile (dgrad_lnrows_kernel)
+    return rows <= 8192 ? 208 : 416;
+}
 size_t block_ws_layout(const S3dBlockShape& sh, int depth, int bwd, void* base, S3dBlockActs* acts, S3dBlockScratch* sc, size_t* zoff, size_t* zbytes) {
     const bool ring = (bwd & 2) != 0;            // with_backward = 2 / 3: + the dy ring of the dgrad chain (3 slots, 3 k-slices)
     const size_t M = (size_t)sh.Bb * sh.N, D = sh.D, Hd = sh.hidden, BHN = (size_t)sh.Bb * sh.H * sh.N;
@@ -752,7 +771,7 @@ size_t block_ws_layout(const S3dBlockShape& sh, int depth, int bwd, void* base, 
         s.dx_a_bf = c.take<uint16_t>(M * D); s.dx_b_bf = c.take<uint16_t>(M * D);
         s.dh = c.take<uint16_t>(M * Hd); s.dqkv = c.take<uint16_t>(M * 3 * D); s.datt = c.take<uint16_t>(M * D);
         s.delta = c.take<float>(BHN);
-        s.ln_partial_blocks = ws_ln_partial_blocks((long)M);
+        s.ln_partial_blocks = ws_ln_partial_blocks((long)M, (int)D);
         s.ln_partial = c.take<float>((size_t)2 * depth * s.ln_partial_blocks * 2 * D);
         if (ring) {
             s.wg_slots = depth < 3 ? depth : 3; s.dgrad_splitk = 3;
@@ -835,6 +854,10 @@ int s3d_gemm_dgrad_dgelu(const S3dGemmArgs* a, const S3dRowStats* stats, s3d_str
 int s3d_gemm_dgrad_lnbwd(const S3dGemmArgs* a, const S3dLnBwdArgs* ln, const S3dRowStats* stats, s3d_stream_t s) {
     S3D_REQUIRE(a != nullptr && ln != nullptr, "s3d_gemm_dgrad_lnbwd: null args");
     return s3d_launch_dgrad_lnbwd(*a, *ln, stats, st(s));
+}
+int s3d_gemm_dgrad_lnrows(const S3dGemmArgs* a, const S3dLnBwdArgs* ln, s3d_stream_t s) {
+    S3D_REQUIRE(a != nullptr && ln != nullptr, "s3d_gemm_dgrad_lnrows: null args");
+    return s3d_launch_dgrad_lnrows(*a, *ln, st(s));
 }
 int s3d_ln_aux(const S3dLnAuxLayer* layers, int n, int D, s3d_stream_t s) { return s3d_launch_ln_aux(layers, n, D, st(s)); }
 int s3d_gemm_wgrad_group(const S3dWgradItem* items, int n, int K, float alpha, int accumulate, s3d_stream_t s) {

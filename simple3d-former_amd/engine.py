@@ -221,12 +221,16 @@ FUSE_LOSS_END = os.environ.get('S3D_FUSE_LOSS_END', '1') != '0'     # final norm
 LN_PARTIAL_BLOCKS = int(os.environ.get('S3D_LN_PARTIAL_BLOCKS', '-1'))    # 0: LayerNorm backward uses atomics; -1: by row count
 
 
-def ln_partial_blocks(rows):
+def ln_partial_blocks(rows, D=None):
     """Workgroups (= rows of column-sum partials) of a LayerNorm backward over `rows` rows: 208 at cfg-2's 1664 rows (two rows per
     wave); 416 for the 16 k - 190 k-row passes of the point path / cfg-3, where 208 four-wave workgroups leave every SIMD with one
     wave and the narrow (D = 192) rows with too few bytes in flight (cfg-4: 16.54 -> 16.32 ms; cfg-3 / cfg-5 unchanged)."""
     if LN_PARTIAL_BLOCKS >= 0:
         return LN_PARTIAL_BLOCKS
+    if D == 192 and rows > 8192:
+        # the 192-wide dgrads of the point path carry their LayerNorm backward as an epilogue on 64-row tiles (bwd_gemm.hip:
+        # dgrad_lnrows_kernel): one row of partials per tile
+        return max(416, (rows + 63) // 64)
     return 208 if rows <= 8192 else 416
 
 
@@ -270,7 +274,7 @@ class _BlockScratch:
                 self.ln_aux = torch.zeros(depth * 2 * (hidden + 3 * D), **f32)
                 self.ln_rowstat = torch.zeros(4 * M, **f32)
                 L.fill(self.c, ln_aux=self.ln_aux, ln_rowstat=self.ln_rowstat)
-        nblk = ln_partial_blocks(M)
+        nblk = ln_partial_blocks(M, D)
         if depth > 0 and nblk > 0:
             # column-sum partials of the 2*depth LayerNorms of one s3d_blocks_bwd call (S3dBlockScratch::ln_partial)
             self.ln_partial = torch.empty(2 * depth, nblk, 2, D, **f32)

@@ -8,7 +8,7 @@ ORACLE_COMPARED = {
     'test_gemm_forward_nt', 'test_gemm_catches_transposes', 'test_gemm_dgrad_nn', 'test_gemm_wgrad_tn_with_bias_grad',
     'test_gemm_pair_dgrad_and_wgrad_tight', 'test_gemm_pair_with_a_second_wgrad_riding_on_the_launch', 'test_gemm_column_sums_for_the_following_batchnorm', 'test_gemm_rowstream_convolution', 'test_gemm_wgrad_into_a_sub_matrix',
     'test_gemm_dgrad_splitk_planes_and_their_sum_in_layernorm_bwd', 'test_gemm_wgrad_group_full_k_deterministic',
-    'test_fused_layernorm_backward_chain_row_statistics',
+    'test_fused_layernorm_backward_chain_row_statistics', 'test_dgrad_with_whole_row_layernorm_backward',
     'test_gemm_epilogues_gelu_resid_token_dgelu', 'test_gemm_fat_forward_tile', 'test_gemm_fat_dgrad_tile', 'test_layernorm_fwd_bwd', 'test_attention_fwd_bwd',
     'test_attention_weight_dropout_uses_the_oracle_mask', 'test_attention_block_diagonal_segments', 'test_tokenizer_modules_match_oracle',
     'test_head_and_cross_entropy', 'test_adam_matches_torch_and_refreshes_planes', 'test_block_fwd_bwd_matches_oracle',

@@ -309,6 +309,48 @@ def test_fused_layernorm_backward_chain_row_statistics(rows, D, Hd):
     assert rel_err(dg, (gdy.cpu() * xh_d).sum(0)) < 2e-5 and rel_err(db, gdy.cpu().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize('rows,K', [(32896, 768), (16416, 576), (1000, 192), (61, 32)])
+def test_dgrad_with_whole_row_layernorm_backward(rows, K):
+    """s3d_gemm_dgrad_lnrows: dx = LayerNorm'(dy = A @ W) + dres for 192-wide layers on 64 x 192 tiles (whole rows per workgroup: the row
+    statistics come from the tile itself) -- the point path's fc1 -> norm2 and qkv -> norm1 backward (models/3DViT/model.py:318-320).  Against
+    fp64: the product of the same bf16 operands -> nn.LayerNorm backward; partial rows and atomics for dgamma / dbeta; ragged row counts."""
+    D = 192
+    g = torch.Generator().manual_seed(40 + rows)
+    lib = L.lib()
+    x = torch.randn(rows, D, generator=g) * 1.5 + 0.3
+    gamma = 1 + 0.2 * torch.randn(D, generator=g)
+    W = torch.randn(K, D, generator=g) * 0.05
+    dz = torch.randn(rows, K, generator=g)
+    dres = torch.randn(rows, D, generator=g)
+    mean = x.mean(1); rstd = (x.var(1, unbiased=False) + 1e-6).rsqrt()
+    keep = []
+    def dev(t):
+        keep.append(t.to(DEV).contiguous())
+        return keep[-1]
+    wh = dev(W).to(torch.bfloat16); dzh = dev(dz).to(torch.bfloat16)
+    dx = torch.full((rows, D), float('nan'), device=DEV); dx_bf = torch.full((rows, D + 8), float('nan'), dtype=torch.bfloat16, device=DEV)
+    nty = (rows + 63) // 64
+    part = torch.full((nty + 1, 2, D), float('nan'), device=DEV)
+    ga = L.fill(L.S3dGemmArgs(), A_hi=dzh, lda=K, B_hi=wh, ldb=D, M=rows, N=D, K=K, alpha=1.0)
+    ln = L.fill(L.S3dLnBwdArgs(), x=dev(x), ldx=D, mean=dev(mean), rstd=dev(rstd), gamma=dev(gamma), dres=dev(dres), lddres=D, dx=dx, lddx=D,
+                dx_bf=dx_bf, lddxbf=D + 8, rows=rows, D=D, partial=part, partial_blocks=nty)
+    L.check(lib.s3d_gemm_dgrad_lnrows(ctypes.byref(ga), ctypes.byref(ln), L.current_stream()), 'dgrad_lnrows')
+    dy = (dzh.double() @ wh.double()).cpu()
+    xh = ((x - mean[:, None]) * rstd[:, None]).double()
+    gg = dy * gamma.double()
+    ref = rstd.double()[:, None] * (gg - gg.mean(1, keepdim=True) - xh * (gg * xh).mean(1, keepdim=True)) + dres.double()
+    assert rel_err(dx, ref) < 2e-5, 'dx'
+    assert rms_err(dx_bf[:, :D].double(), ref) < 3e-3 and bool(torch.isnan(dx_bf[:, D:].float()).all())
+    assert rel_err(part[:nty, 0].double().sum(0), (dy * xh).sum(0)) < 2e-5, 'dgamma partials'
+    assert rel_err(part[:nty, 1].double().sum(0), dy.sum(0)) < 2e-5, 'dbeta partials'
+    assert bool(torch.isnan(part[nty]).all())
+    dg = torch.zeros(D, device=DEV); db = torch.zeros(D, device=DEV)
+    L.fill(ln, partial=None, partial_blocks=0, dgamma=dg, dbeta=db, dres=None)
+    L.check(lib.s3d_gemm_dgrad_lnrows(ctypes.byref(ga), ctypes.byref(ln), L.current_stream()), 'dgrad_lnrows (atomics, no residual)')
+    assert rel_err(dg, (dy * xh).sum(0)) < 2e-5 and rel_err(db, dy.sum(0)) < 2e-5
+    assert rel_err(dx, ref - dres.double()) < 2e-5
+
+
 @pytest.mark.parametrize('rows,shapes,acc', [
     (1664, [(384, 1536), (1536, 384), (384, 384), (1152, 384)] * 3, 1),       # cfg-2: three blocks' fc2 / fc1 / proj / qkv wgrads in one launch
     (1664, [(384, 1536), (1536, 384), (384, 384), (1152, 384)], 0),           # overwrite mode
