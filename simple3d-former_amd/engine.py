@@ -504,7 +504,13 @@ class VoxelEngine:
         ws = type('WS', (), {})()
         ws.B, ws.M, ws.G = B, M, G
         ws.a = torch.zeros(2, M, self.Kpad, dtype=torch.bfloat16, device=dev)     # cls rows / pad columns stay 0
-        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=CLS_ONLY,
+        # Where the backward runs as the dgrad chain (capi.hip: wgrad_chain_ok) a DENSE last block is four launches + its share of a grouped
+        # wgrad; its class-rows-only variant keeps the seven paired launches and costs more than the rows it skips save (cfg-2 same-box:
+        # 1.527 -> 1.508 ms dense).  At cfg-3's 188 k rows the class-rows-only block stays (279 against 290 ms).
+        chain = (WGRAD_GROUP > 0 and M <= 8192 and not self.group and not self.precise and FUSED_BLOCKS and FUSED_BWD
+                 and D in (192, 384) and self.H * 64 == D and self.ntok <= 32)
+        ws.cls_only = CLS_ONLY and not chain
+        ws.blocks = _BlockWorkspace(self.depth, G, self.ntok, D, self.H, self.hidden, dev, self.split, self.ln_fuse, cls_only=ws.cls_only,
                                     precise=self.precise)
         bhn = max(G * self.H * self.ntok, (self.ntok * self.enc_heads * G) if self.group else 0,
                   (B * self.H * self.ntok2) if self.group else 0)
@@ -513,7 +519,7 @@ class VoxelEngine:
             slot = int(self.lib.s3d_block_wgrad_slot_bytes(ctypes.byref(ws.blocks.shape)))
             ring = (min(WGRAD_GROUP, 6, self.depth), max(1, min(DGRAD_SPLITK, 4)), slot)
         ws.scratch = _BlockScratch(M, D, self.H, self.hidden, bhn, dev, depth=self.depth, precise=self.precise, wgrad_ring=ring)
-        ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev, self.precise) if CLS_ONLY else (ws.scratch.c, None)       # scratch table of the (first) pass
+        ws.sc1, ws._cls1 = _cls_scratch(ws.scratch.c, M, D, dev, self.precise) if ws.cls_only else (ws.scratch.c, None)       # scratch table of the (first) pass
         if self.group:
             f32 = dict(dtype=torch.float32, device=dev)
             b16 = dict(dtype=torch.bfloat16, device=dev)
@@ -612,7 +618,7 @@ class VoxelEngine:
         assert target.dtype == torch.int64 and target.is_cuda
         if not hasattr(ws, 'hl_scratch'):
             ws.hl_scratch = torch.empty(B * (2 * D + 1), dtype=torch.float32, device=self.device)
-        if not CLS_ONLY:
+        if not ws.cls_only:
             sc.zero_dx_a()
         hl = L.fill(L.S3dHeadLossArgs(), x=ws.last.x[self.depth], ldx=nt * D, B=B, D=D, C=self.C, eps=LN_EPS,
                     gamma=a.param('norm.weight'), beta=a.param('norm.bias'), W=a.param('voxel_head.weight'),
@@ -666,7 +672,7 @@ class VoxelEngine:
             ws.dlogits.copy_(dlogits)
         L.check(lib.s3d_head_bwd(ctypes.byref(self._head_args(ws)), s), 'head_bwd')
         sc = ws.scratch
-        if not CLS_ONLY:
+        if not ws.cls_only:
             sc.zero_dx_a()                  # with cls_only_block the last block reads the class rows of d(x_out) only
         nt = ws.ntok_last
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dfeat, lddy=D, x=ws.last.x[self.depth], ldx=nt * D,
@@ -701,7 +707,7 @@ class VoxelEngine:
         L.check(lib.s3d_token_grads(ctypes.byref(pg), s), 'pass-2 token grads')
         L.check(lib.s3d_assemble_tokens_bwd(L.ptr(sc.dx_a), L.ptr(ws.dgfeat), ctypes.c_long(ws.B), self.P * self.P, D, s),
                 'assemble bwd')
-        if not CLS_ONLY:
+        if not ws.cls_only:
             sc.zero_dx_a()
         lb = L.fill(L.S3dLnBwdArgs(), dy=ws.dgfeat, lddy=D, x=ws.blocks.x[self.depth], ldx=self.ntok * D,
                     mean=ws.gstats[0], rstd=ws.gstats[1], gamma=a.param('norm.weight'), dx=sc.dx_a, lddx=self.ntok * D,

@@ -98,8 +98,9 @@ def test_optimizer_update_inside_the_backward_launches_equals_the_single_update(
         if fill:
             st = eng.adam_fill_stats
             # 11 of 12 blocks' GEMM parameters on the paired launches; on the dgrad chain (round 5) a block's share rides on the grouped wgrad
-            # launch AFTER the one that computes its gradients, so the last group of blocks is left to the final launch: 9 of 12
-            assert st['filled'] + st['rest'] == eng.arena.numel and st['filled'] > 0.70 * eng.arena.numel, st
+            # launch AFTER the one that computes its gradients, so the last group of four blocks is left to the final launch: 8 of 12
+            # (all twelve blocks are on the chain since the last block runs dense there)
+            assert st['filled'] + st['rest'] == eng.arena.numel and st['filled'] > 0.60 * eng.arena.numel, st
         runs.append((losses, eng.arena.p.clone(), eng.arena.m.clone(), eng.arena.v.clone(), eng.arena.hi.clone(), eng.arena.lo.clone(), eng.arena.g.clone()))
         assert eng.optimizer_state()['step'] == 4
     for r in runs[1:]:
