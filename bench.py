@@ -287,7 +287,8 @@ def collective_diagnostics(trainer, step, step_ms, world, force, reps=10):
             dist.barrier()
         ar_ms.append(round(timed(one, reps), 4))
         buf.copy_(keep)
-    if trainer.graph_collectives:
+    graph_coll = bool(getattr(trainer, 'graph_collectives', False))      # (the point trainer launches its collectives from the host)
+    if graph_coll:
         # the all-reduces are nodes of the step graph: the yardstick is the single-replica step (one graph, no collective at all)
         g1, sx1, sy1, _ = trainer.eng.capture_train_step(trainer._cap['B'])
         sx1.copy_(trainer._cap['x']); sy1.copy_(trainer._cap['y'])
@@ -319,7 +320,7 @@ def collective_diagnostics(trainer, step, step_ms, world, force, reps=10):
                 ms_per_step_without_collectives=round(t_skip, 4), exposed_comm_ms=round(exposed, 4),
                 overlap_frac=round(1.0 - min(1.0, exposed / total), 4) if total > 0 else None,
                 note='allreduce_ms: each bucket alone on an otherwise idle GPU; overlap_frac = 1 - (step - step without collectives) / '
-                     'sum(allreduce_ms); "without collectives" = ' + ('the single-replica one-graph step' if trainer.graph_collectives else
+                     'sum(allreduce_ms); "without collectives" = ' + ('the single-replica one-graph step' if graph_coll else
                                                                       'the same segmented step with the collectives suppressed'))
 
 
