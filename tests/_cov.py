@@ -6,7 +6,7 @@
 ORACLE_COMPARED = {
     # tests/test_gpu_kernels.py -- one operator through the C ABI vs fp64 / fp32 PyTorch of the same operator
     'test_gemm_forward_nt', 'test_gemm_catches_transposes', 'test_gemm_dgrad_nn', 'test_gemm_wgrad_tn_with_bias_grad',
-    'test_gemm_pair_dgrad_and_wgrad_tight', 'test_gemm_pair_with_a_second_wgrad_riding_on_the_launch', 'test_gemm_column_sums_for_the_following_batchnorm', 'test_gemm_rowstream_convolution', 'test_gemm_wgrad_into_a_sub_matrix',
+    'test_gemm_pair_dgrad_and_wgrad_tight', 'test_gemm_pair_with_a_second_wgrad_riding_on_the_launch', 'test_gemm_column_sums_for_the_following_batchnorm', 'test_gemm_rowstream_convolution', 'test_gemm_wgrad_into_a_sub_matrix', 'test_token_gradients_default_and_deterministic',
     'test_gemm_dgrad_splitk_planes_and_their_sum_in_layernorm_bwd', 'test_gemm_wgrad_group_full_k_deterministic',
     'test_fused_layernorm_backward_chain_row_statistics', 'test_dgrad_with_whole_row_layernorm_backward',
     'test_gemm_epilogues_gelu_resid_token_dgelu', 'test_gemm_fat_forward_tile', 'test_gemm_fat_dgrad_tile', 'test_layernorm_fwd_bwd', 'test_attention_fwd_bwd',

@@ -439,6 +439,32 @@ def test_gemm_rowstream_convolution(M, N, K, sums):
         assert rel_err(s[:N], yd.sum(0)) < 1e-6 and rel_err(s[N:], (yd * yd).sum(0)) < 1e-6
 
 
+@pytest.mark.parametrize('groups,ntok,D', [(64, 26, 384), (5, 3, 40), (700, 15, 192)])
+def test_token_gradients_default_and_deterministic(groups, ntok, D):
+    """s3d_token_grads: d(pos_embed)[t] = sum over groups of dx[g, t], d(cls) = the token-0 sum, d(conv bias) = the sum over the other
+    tokens (vit_3d_2d_pretrain.py:455-470 backward) -- the atomic default and the single-writer deterministic kernel against fp64, both
+    accumulating onto existing content; the deterministic one bitwise equal from run to run."""
+    g = torch.Generator().manual_seed(groups + D)
+    dx = torch.randn(groups, ntok, D, generator=g)
+    dxd = dx.to(DEV)
+    ref = dx.double().sum(0)
+    lib = L.lib()
+    outs = []
+    for det in (0, 1, 1):
+        lib.s3d_set_deterministic(det)
+        try:
+            dpos = torch.full((ntok, D), 0.5, device=DEV); dcls = torch.full((D,), 0.25, device=DEV); dbias = torch.full((D,), -1.0, device=DEV)
+            a = L.fill(L.S3dPosGradArgs(), dx=dxd, groups=groups, ntok=ntok, D=D, dpos=dpos, dcls=dcls, dbias=dbias)
+            L.check(lib.s3d_token_grads(ctypes.byref(a), L.current_stream()), 'token grads')
+            torch.cuda.synchronize()
+        finally:
+            lib.s3d_set_deterministic(0)
+        assert rel_err(dpos - 0.5, ref) < 2e-6 and rel_err(dcls - 0.25, ref[0]) < 2e-6
+        assert rel_err(dbias + 1.0, ref[1:].sum(0)) < 2e-6
+        outs.append((dpos.clone(), dcls.clone(), dbias.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[1], outs[2]))
+
+
 def test_gemm_wgrad_into_a_sub_matrix():
     """The factored set-abstraction convolution accumulates d(Wf) INSIDE the conv weight's gradient: C = dW + 3 columns, ldc = 3 + I."""
     g = torch.Generator().manual_seed(13)
