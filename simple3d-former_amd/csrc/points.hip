@@ -643,21 +643,39 @@ __global__ __launch_bounds__(256) void group_proj_fwd_kernel(const S3dGroupProjA
     }
     const f32x4 bb = ld4(p.bias + c);
     const unsigned SK = (unsigned)p.S * (unsigned)p.K;
+    // U rows per trip: the neighbour indices of all U first, then the U gathers they address (a row is idx -> point -> Pf row: two dependent
+    // loads; one row per trip left a wave with one 1 KB gather in flight and the launch at 2.4 TB/s of its output alone)
+    constexpr int U = 4;
+    const unsigned stride = gridDim.x * l.rpb;
     if (l.on)
-        for (unsigned r = blockIdx.x * l.rpb + l.sub; r < rows; r += gridDim.x * l.rpb) {
-            const unsigned b = r / SK, bs = r / (unsigned)p.K;
-            const long pt = (long)b * p.N + p.idx[r];
-            const float* pp = p.xyz + pt * 3;
-            const float* cc = p.new_xyz + (long)bs * 3;
-            const float rx = pp[0] - cc[0], ry = pp[1] - cc[1], rz = pp[2] - cc[2];
-            f32x4 v = ld4(p.Pf + pt * p.ldp + c);
+        for (unsigned r0 = blockIdx.x * l.rpb + l.sub; r0 < rows; r0 += U * stride) {
+            long pt[U];
+            unsigned rr[U];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = v[i] + ((rx * wx[i] + ry * wy[i]) + rz * wz[i]) + bb[i];
-                const double d = v[i];
-                sm[i] += d; sq[i] += d * d;
+            for (int u = 0; u < U; ++u) {
+                rr[u] = min(r0 + u * stride, rows - 1);
+                pt[u] = (long)(rr[u] / SK) * p.N + p.idx[rr[u]];
             }
-            *reinterpret_cast<f32x4*>(p.x + (long)r * p.ldx + c) = v;
+            f32x4 v[U];
+            float rx[U], ry[U], rz[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float* pp = p.xyz + pt[u] * 3;
+                const float* cc = p.new_xyz + (long)(rr[u] / (unsigned)p.K) * 3;
+                rx[u] = pp[0] - cc[0]; ry[u] = pp[1] - cc[1]; rz[u] = pp[2] - cc[2];
+                v[u] = ld4(p.Pf + pt[u] * p.ldp + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (r0 + u * stride >= rows) break;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[u][i] = v[u][i] + ((rx[u] * wx[i] + ry[u] * wy[i]) + rz[u] * wz[i]) + bb[i];
+                    const double d = v[u][i];
+                    sm[i] += d; sq[i] += d * d;
+                }
+                *reinterpret_cast<f32x4*>(p.x + (long)rr[u] * p.ldx + c) = v[u];
+            }
         }
     if (p.sums) bn_fold_sums(l, p.C, sm, sq, p.sums);              // uniform branch; every thread reaches the barrier inside
 }
