@@ -74,7 +74,7 @@ R5_KERNELS = {
     12: ('dgrad_kernel<64x64 NN, gelu\' + LayerNorm row statistics> (bf16)', 'dgrad_kernel<1, 3'),
     13: ('dgrad_kernel<64x64 NN, LayerNorm-backward epilogue, two wave groups> (bf16)', 'dgrad_kernel<2, 3'),
     14: ('dgrad_lnrows_kernel<64x192 NN, whole-row LayerNorm-backward epilogue> (bf16)', 'dgrad_lnrows_kernel<3'),
-    15: ('blk_mlp_full_kernel<norm2 + fc1 + GELU + fc2 + residual, D = 192, one launch> (split bf16)', 'blk_mlp_full_kernel<16, 8'),
+    15: ('blk_mlp_full_kernel<norm2 + fc1 + GELU + fc2 + residual, D = 192, one launch> (split bf16)', 'blk_mlp_full_kernel<16'),
 }
 
 

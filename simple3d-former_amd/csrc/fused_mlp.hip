@@ -50,7 +50,9 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& hi, bf16x8& 
     hi = h.v; lo = l.v;
 }
 
-template <int RPW, int NW>
+// NW waves of RPW rows each; the first NDMA of them deal the weight stream's pieces among themselves (NW = 9, NDMA = 8: a ninth wave that
+// only computes -- bands of 144 rows, so that cfg-4's 32 896 rows are 229 workgroups = ONE round on 256 CUs instead of 257 = two)
+template <int RPW, int NW, int NDMA = NW>
 __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFullArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int RF = RPW / 16;                                        // 16-row fragments per wave
@@ -58,8 +60,9 @@ __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFul
     constexpr int OF = FM_D / 16;                                       // output fragments of fc2: 12
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    constexpr int FM_PPW = FM_PIECES / NW;                              // pieces per wave: 12 (four waves) or 6 (eight)
-    static_assert(NW == 4 || NW == 8, "four or eight waves");
+    constexpr int FM_PPW = FM_PIECES / NDMA;                            // pieces per DMA wave: 12 (four waves) or 6 (eight)
+    static_assert((NDMA == 4 || NDMA == 8) && NW >= NDMA, "four or eight waves carry the weight stream");
+    const bool dma_wave = wave < NDMA;                                  // uniform per wave
     const long row0 = ((long)blockIdx.x * NW + wave) * RPW;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     float* sb1 = reinterpret_cast<float*>(smem + FM_NS * FM_STAGE);     // [768] fc1 bias
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFul
     const bf16_t* gp[FM_PPW];
     long gstep[1];
     {
-        const int plane = (wave * FM_PPW) / 12, p0 = (wave * FM_PPW) % 12;      // (a wave's pieces lie in one plane: 12 % FM_PPW == 0)
+        const int wv = dma_wave ? wave : 0;                             // (a wave without pieces: valid pointers it never uses)
+        const int plane = (wv * FM_PPW) / 12, p0 = (wv * FM_PPW) % 12;          // (a wave's pieces lie in one plane: 12 % FM_PPW == 0)
         if (plane < 2) {
             const bf16_t* base = plane == 0 ? p.w1_hi : p.w1_lo;
 #pragma unroll
@@ -91,6 +95,7 @@ __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFul
         }
     }
     auto issue = [&](int c) {
+        if (!dma_wave) return;
         const unsigned dst = lds0 + (unsigned)((c % FM_NS) * FM_STAGE + wave * FM_PPW * 1024);
 #pragma unroll
         for (int j = 0; j < FM_PPW; ++j) glds16(gp[j] + (long)c * gstep[0], dst + j * 1024);
@@ -241,12 +246,15 @@ void set_lds_once(K kern, int bytes, bool& done) {
 
 }  // namespace
 
-// From ~24 k rows on (cfg-4: 32 896): there the launch beats LayerNorm + fc1 + fc2 as three launches by 1.5 % of the step; at cfg-5's 16 416
-// rows (129 bands on 256 CUs) the two are equal (profiles/r05_fused_mlp_d192.txt), so the three launches stay.
-bool s3d_fused_mlp_full_ok(long M, int D, int hidden) { return D == FM_D && hidden == FM_H && M >= 24576; }
+// From 16 k rows on: cfg-4 (32 896 rows, 229 bands of nine waves) -5.4 % of the step against LayerNorm + fc1 + fc2 as three launches, cfg-5
+// (16 416 rows, 129 bands of eight waves) -1.4 % (profiles/r05_fused_mlp_d192.txt).
+bool s3d_fused_mlp_full_ok(long M, int D, int hidden) {
+    static const int min_rows = s3d_tune_int("S3D_FUSED_MLP_MIN_ROWS");
+    return D == FM_D && hidden == FM_H && M >= (min_rows > 0 ? min_rows : 16384);
+}
 
 int s3d_launch_fused_mlp_full(const FusedMlpArgs& a, const bf16_t* w2_hi, const bf16_t* w2_lo, const float* b2, float* x_out, int D, hipStream_t s) {
-    S3D_REQUIRE(s3d_fused_mlp_full_ok(a.M, D, a.hidden), "fused MLP: D = 192, hidden = 768, >= 24576 rows (got D=%d hidden=%d M=%ld)", D, a.hidden, a.M);
+    S3D_REQUIRE(s3d_fused_mlp_full_ok(a.M, D, a.hidden), "fused MLP: D = 192, hidden = 768, >= 16384 rows (got D=%d hidden=%d M=%ld)", D, a.hidden, a.M);
     S3D_REQUIRE(a.x && a.gamma && a.beta && a.w_hi && a.w_lo && a.bias && w2_hi && w2_lo && b2 && x_out && a.xn_hi && a.mean && a.rstd && a.hpre && a.hact_hi,
                 "fused MLP: null pointer");
     FusedMlpFullArgs f;
@@ -259,11 +267,29 @@ int s3d_launch_fused_mlp_full(const FusedMlpArgs& a, const bf16_t* w2_hi, const 
     // Eight waves of 16 rows (bands of 128 rows, two waves per SIMD).  Measured (profiles/r05_fused_mlp_d192.txt): four waves of 32 rows -- every
     // weight fragment read serving two row fragments, one wave per SIMD -- take 211 us per launch at cfg-4 against 163, four waves of 16 rows 238.
     s3d_prof_begin(KEY, 2.0 * 2.0 * (double)a.M * FM_D * FM_H, s);
-    static bool set = false;
-    set_lds_once(blk_mlp_full_kernel<16, 8>, LDS, set);
-    hipLaunchKernelGGL((blk_mlp_full_kernel<16, 8>), dim3((unsigned)((a.M + 127) / 128)), dim3(512), LDS, s, f);
-    const bool wide = false;
+    // ... and a ninth, compute-only wave (bands of 144 rows) where that saves a round of workgroups: a workgroup is paced by its own weight
+    // stream and fragment reads, so the 257th band of cfg-4 cost as much as the 256 before it (145 us per launch, two rounds)
+    const long wg8 = (a.M + 127) / 128, wg9 = (a.M + 143) / 144;
+    const bool nine = (wg9 + 255) / 256 < (wg8 + 255) / 256;
+    static const int nw_env = s3d_tune_int("S3D_FUSED_MLP_NW");           // tuning builds: 5 / 6 / 7 (four DMA waves), 8, 9
+    const int nw = nw_env > 0 ? nw_env : (nine ? 9 : 8);
+#define S3D_FM_LAUNCH(NW_, ND_)                                                                                                  \
+    do {                                                                                                                         \
+        static bool set = false;                                                                                                 \
+        set_lds_once(blk_mlp_full_kernel<16, NW_, ND_>, LDS, set);                                                               \
+        hipLaunchKernelGGL((blk_mlp_full_kernel<16, NW_, ND_>), dim3((unsigned)((a.M + 16 * NW_ - 1) / (16 * NW_))), dim3(64 * NW_), LDS, s, f); \
+    } while (0)
+    switch (nw) {
+#ifdef S3D_EXPERIMENTAL_TILES
+        case 5: S3D_FM_LAUNCH(5, 4); break;
+        case 6: S3D_FM_LAUNCH(6, 4); break;
+        case 7: S3D_FM_LAUNCH(7, 4); break;
+#endif
+        case 9: S3D_FM_LAUNCH(9, 8); break;
+        default: S3D_FM_LAUNCH(8, 8); break;
+    }
+#undef S3D_FM_LAUNCH
     s3d_prof_end(s);
-    S3D_CHECK_LAUNCH_V("blk_mlp_full", wide ? 32 : 16);
+    S3D_CHECK_LAUNCH_V("blk_mlp_full", nw * 16 + 16);
     return 0;
 }
