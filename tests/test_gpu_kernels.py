@@ -863,7 +863,10 @@ def test_adam_matches_torch_and_refreshes_planes():
 
 
 @pytest.mark.parametrize('D,H,N,Bb', [(384, 6, 26, 8), (192, 3, 10, 3), (768, 3, 15, 5),
-                                      (384, 6, 26, 64), (192, 3, 513, 8)])     # the benched cfg-2 block (1664 rows: gemm_pair_dmat_kernel, fused forward) and a cfg-5 slice (513 tokens)
+                                      (384, 6, 26, 64), (192, 3, 513, 8),      # the benched cfg-2 block (1664 rows: gemm_pair_dmat_kernel, fused forward) and a cfg-5 slice (513 tokens)
+                                      # the point path's block at >= 16 384 rows: norm2 + fc1 + GELU + fc2 + residual as ONE launch (fused_mlp.hip),
+                                      # bands of eight waves (16 448 rows) and of nine (cfg-4's 32 896 rows: 229 workgroups instead of 257)
+                                      (192, 3, 257, 64), (192, 3, 257, 128)])
 def test_block_fwd_bwd_matches_oracle(D, H, N, Bb):
     """One timm Block through s3d_block_fwd / s3d_block_bwd vs autograd on the oracle restatement."""
     from oracle import voxel_oracle as vo
