@@ -1210,6 +1210,20 @@ static int coop_waves() {
 template <int HD>
 static bool mask_ok(const AttnArgs& a) { return HD < 256 && a.drop_thr != 0 && a.drop_mask != nullptr && use_coop(a.N) && a.N > 32; }
 
+// Nine waves per workgroup for the point path's 257-token sequences (nine query tiles of 32): ONE workgroup per (batch, head) streams the keys
+// once instead of three times, and no wave idles through the key loop.  hd = 64 without dropout only.  Measured (tools/r5/attn_ab.sh, cfg-4):
+// forward 59.5 -> 50.7 us per launch (step -0.7 %); dQ 49.0 -> 53.8 and dK/dV 61.2 -> 123 (240 B of scratch per lane) stay on four waves;
+// at 513 tokens (17 tiles: two workgroups of nine waves against five of four) the forward is no faster.
+// S3D_ATTN_NINE (tuning builds): bit 0 forward, bit 1 dQ, bit 2 dK/dV.
+constexpr int coop_nine_default = 1;
+template <int HD>
+static bool coop_nine(const AttnArgs& a, int bit) {
+    static const int env = s3d_tune_int("S3D_ATTN_NINE");
+    const int mask = env >= 0 ? env : coop_nine_default;
+    const int T = (a.N + 31) / 32;
+    return HD == 64 && a.drop_thr == 0 && a.drop_mask == nullptr && ((mask >> bit) & 1) != 0 && (env >= 0 ? (T + 8) / 9 < (T + 3) / 4 : T == 9);
+}
+
 template <int HD>
 int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
     AttnArgs a = a_in;
@@ -1235,6 +1249,20 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
             return 0;
         }
 #endif
+        if constexpr (HD == 64) if (coop_nine<HD>(a, 0)) {
+            dim3 g9((unsigned)((long)a.Bb * a.H * ((QT + 8) / 9)));
+            if (split) {
+                const int lds = 2 * CoopStage<HD, 4, 576>::BUF_BYTES;
+                set_lds((attn_fwd_coop_kernel<HD, true, 9, false>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true, 9, false>), g9, dim3(576), lds, s, a);
+            } else {
+                const int lds = 2 * CoopStage<HD, 2, 576>::BUF_BYTES;
+                set_lds((attn_fwd_coop_kernel<HD, false, 9, false>), lds);
+                hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, false, 9, false>), g9, dim3(576), lds, s, a);
+            }
+            S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + (split ? 10 : 0) + 9);
+            return 0;
+        }
         dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
         if (split) {
             const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
@@ -1322,7 +1350,13 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 8>), g, dim3(512), lds, s, a);
         } else
 #endif
-        {
+        if (coop_nine<HD>(a, 1)) {
+            if constexpr (HD == 64) {
+                set_lds((attn_bwd_dq_coop_kernel<HD, 9>), lds);
+                dim3 g9((unsigned)((long)a.Bb * a.H * ((KT + 8) / 9)));
+                hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 9>), g9, dim3(576), lds, s, a);
+            }
+        } else {
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
             if constexpr (HD < 256) {
                 if (a.drop_mask) {
@@ -1335,7 +1369,7 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
                 hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0));
+        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0) + (coop_nine<HD>(a, 1) ? 9 : 0));
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
@@ -1353,7 +1387,13 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), g2, dim3(512), lds, s, a);
         } else
 #endif
-        {
+        if (coop_nine<HD>(a, 2)) {
+            if constexpr (HD == 64) {
+                set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 9>), lds);
+                dim3 g9((unsigned)((long)a.Bb * a.H * ((KT + 8) / 9)), DSPLIT);
+                hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 9>), g9, dim3(576), lds, s, a);
+            }
+        } else {
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             if constexpr (HD < 256) {
                 if (a.drop_mask) {
@@ -1366,7 +1406,7 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
                 hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0));
+        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0) + (coop_nine<HD>(a, 2) ? 9 : 0));
     } else {
         // the per-wave kernel splits the d range in two from hd = 192 on (one half = 252 registers + 60 B of scratch there)
         constexpr int DS = HD >= 192 ? 2 : DSPLIT;
