@@ -321,6 +321,8 @@ typedef struct S3dHeadLossArgs {
     float* dx; uint16_t* dx_bf; long lddx;    /* out: d(loss)/d(x) at the class rows, fp32 and bf16, row pitch lddx */
     float* dW; float* dbias; float* dgamma; float* dbeta;   /* accumulated (+=) */
     float* scratch;                            /* B * (2*D + 1) floats */
+    int zero_tokens;                           /* > 0: also clear dx / dx_bf of the zero_tokens token rows that FOLLOW each class row (lddx = tokens per
+                                                * sample * D: the last block's d(x_out) is zero except at the class rows, and a dense last block reads all of it) */
 } S3dHeadLossArgs;
 int s3d_head_loss_fused(const S3dHeadLossArgs* args, s3d_stream_t stream);
 

@@ -416,6 +416,15 @@ __global__ __launch_bounds__(256) void head_loss_sample_kernel(const S3dHeadLoss
         }
     }
     const float* Wsrc = w_lds ? Wl : p.W;
+    if (p.zero_tokens > 0) {                            // d(x_out) of the sample's other tokens: zero (instead of a fill launch in front of this one)
+        const long n4 = (long)p.zero_tokens * D / 4;
+        f32x4* z = reinterpret_cast<f32x4*>(p.dx + (long)b * p.lddx + D);
+        if (p.dx) for (long i = tid; i < n4; i += 256) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.dx_bf) {
+            u32x2* zb = reinterpret_cast<u32x2*>(p.dx_bf + (long)b * p.lddx + D);
+            for (long i = tid; i < n4; i += 256) zb[i] = u32x2{0u, 0u};
+        }
+    }
     // ---- final LayerNorm of the class row (two-pass statistics, as ln_row_finish)
     float xv[4], s = 0.f;
 #pragma unroll

@@ -618,9 +618,9 @@ class VoxelEngine:
         assert target.dtype == torch.int64 and target.is_cuda
         if not hasattr(ws, 'hl_scratch'):
             ws.hl_scratch = torch.empty(B * (2 * D + 1), dtype=torch.float32, device=self.device)
-        if not ws.cls_only:
-            sc.zero_dx_a()
-        hl = L.fill(L.S3dHeadLossArgs(), x=ws.last.x[self.depth], ldx=nt * D, B=B, D=D, C=self.C, eps=LN_EPS,
+        # a dense last block reads all of d(x_out): zero except at the class rows -- cleared by the launch itself (zero_tokens), not by a fill
+        hl = L.fill(L.S3dHeadLossArgs(), zero_tokens=0 if ws.cls_only else nt - 1,
+                    x=ws.last.x[self.depth], ldx=nt * D, B=B, D=D, C=self.C, eps=LN_EPS,
                     gamma=a.param('norm.weight'), beta=a.param('norm.bias'), W=a.param('voxel_head.weight'),
                     bias=a.param('voxel_head.bias'), target=target, weight=weight, grad_scale=grad_scale, feat=ws.feat,
                     mean=ws.fstats[0], rstd=ws.fstats[1], logits=ws.logits, dlogits=ws.dlogits, loss=ws.loss, dx=sc.dx_a,
