@@ -422,16 +422,17 @@ def init_state_dict(*, backbone, embed_layer, voxel_size, cell, patch, n_classes
     return sd
 
 
-def synthetic_class_batch(batch, voxel_size, cell, labels, seed=9):
+def synthetic_class_batch(batch, voxel_size, cell, labels, seed=9, base=0.04, step=0.07):
     """A LEARNABLE portable synthetic batch (trained-state fixtures, tests/golden/make_golden_trained.py): the label is encoded in the
-    grid's occupancy -- the i-th entry of `labels` fills the grid at density 0.04 + 0.07 i -- which a freshly initialised model can pick up
-    without positional information (voxel_pos_embed starts at zero, vit_3d_2d_pretrain.py:370-376).  Labels are drawn uniformly by hash."""
+    grid's occupancy -- the i-th entry of `labels` fills the grid at density base + step i (0.04 + 0.07 i by default) -- which a freshly
+    initialised model can pick up without positional information (voxel_pos_embed starts at zero, vit_3d_2d_pretrain.py:370-376).
+    Labels are drawn uniformly by hash."""
     V = voxel_size
     labels = list(labels)
     pick = (portable_uniform((batch,), seed, 2002) * len(labels)).long().clamp_(max=len(labels) - 1)
     y = torch.tensor(labels, dtype=torch.long)[pick]
     u = portable_uniform((batch, 1, V, V, V), seed, 2001)
-    dens = (0.04 + 0.07 * pick.double()).view(batch, 1, 1, 1, 1)
+    dens = (base + step * pick.double()).view(batch, 1, 1, 1, 1)
     return (u < dens).to(torch.int32).float(), y
 
 

@@ -1348,15 +1348,15 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
             set_lds((attn_bwd_dq_coop_kernel<HD, 8>), lds);
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)));
             hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 8>), g, dim3(512), lds, s, a);
-        } else
-#endif
-        if (coop_nine<HD>(a, 1)) {
+        } else if (coop_nine<HD>(a, 1)) {       // (tuning builds only: the product library ships the nine-wave FORWARD alone)
             if constexpr (HD == 64) {
                 set_lds((attn_bwd_dq_coop_kernel<HD, 9>), lds);
                 dim3 g9((unsigned)((long)a.Bb * a.H * ((KT + 8) / 9)));
                 hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD, 9>), g9, dim3(576), lds, s, a);
             }
-        } else {
+        } else
+#endif
+        {
             dim3 g((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)));
             if constexpr (HD < 256) {
                 if (a.drop_mask) {
@@ -1369,7 +1369,7 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
                 hipLaunchKernelGGL((attn_bwd_dq_coop_kernel<HD>), g, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0) + (coop_nine<HD>(a, 1) ? 9 : 0));
+        S3D_CHECK_LAUNCH_V("attention_bwd_dq_coop", HD * 10 + (a.drop_mask ? 1 : 0));
     } else {
         const int lds = wpb * 32 * HD * 2;
         set_lds(attn_bwd_dq_kernel<HD>, 4 * 32 * HD * 2);
@@ -1385,15 +1385,15 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
             set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), lds);
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 7) / 8)), DSPLIT);
             hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 8>), g2, dim3(512), lds, s, a);
-        } else
-#endif
-        if (coop_nine<HD>(a, 2)) {
+        } else if (coop_nine<HD>(a, 2)) {       // (tuning builds only: 240 B of scratch per lane, 61 -> 123 us)
             if constexpr (HD == 64) {
                 set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 9>), lds);
                 dim3 g9((unsigned)((long)a.Bb * a.H * ((KT + 8) / 9)), DSPLIT);
                 hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 9>), g9, dim3(576), lds, s, a);
             }
-        } else {
+        } else
+#endif
+        {
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             if constexpr (HD < 256) {
                 if (a.drop_mask) {
@@ -1406,7 +1406,7 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
                 hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT>), g2, dim3(256), lds, s, a);
             }
         }
-        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0) + (coop_nine<HD>(a, 2) ? 9 : 0));
+        S3D_CHECK_LAUNCH_V("attention_bwd_dkv_coop", HD * 100 + DSPLIT * 10 + (a.drop_mask ? 1 : 0));
     } else {
         // the per-wave kernel splits the d range in two from hd = 192 on (one half = 252 registers + 60 B of scratch there)
         constexpr int DS = HD >= 192 ? 2 : DSPLIT;

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFul
     static_assert((NDMA == 4 || NDMA == 8) && NW >= NDMA, "four or eight waves carry the weight stream");
     const bool dma_wave = wave < NDMA;                                  // uniform per wave
     const long row0 = ((long)blockIdx.x * NW + wave) * RPW;
+    const bool all_rows = row0 + RPW <= p.M;                            // uniform per wave: every row fragment issues its stores
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)smem);
     float* sb1 = reinterpret_cast<float*>(smem + FM_NS * FM_STAGE);     // [768] fc1 bias
 
@@ -159,8 +160,13 @@ __global__ __launch_bounds__(64 * NW) void blk_mlp_full_kernel(const FusedMlpFul
         // stage c must have landed.  Younger than its pieces (vmcnt retires in issue order): the two 16-byte stores per row fragment of each
         // of the last NS - 1 chunks and the pieces of the NS - 2 stages behind it -- they may all stay in flight (waiting for them too
         // exposed a store acknowledgement + most of a DMA latency at every chunk: 182 us per launch at cfg-4)
-        if (c + FM_NS - 1 <= FM_NCH) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FM_NS - 2) * FM_PPW + (FM_NS - 1) * 2 * RF) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // A wave whose rows lie (partly) beyond M skips those stores altogether (execz branch), so for it only the DMA pieces are younger:
+        // counting stores it never issued would let pieces of stage c stay in flight past the barrier (the tail band of cfg-4 /
+        // cfg-5).  A smaller count is always safe.
+        if (c + FM_NS - 1 <= FM_NCH) {
+            if (all_rows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FM_NS - 2) * FM_PPW + (FM_NS - 1) * 2 * RF) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((FM_NS - 2) * FM_PPW) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (c + FM_NS - 1 < FM_NCH) issue(c + FM_NS - 1);
         const unsigned char* s1h = smem + (c % FM_NS) * FM_STAGE;

@@ -624,6 +624,8 @@ int s3d_launch_posgrad(const PosGradArgs& a, hipStream_t s) {
     S3D_REQUIRE(a.ntok <= 65535, "posgrad: ntok=%d too large", a.ntok);
     if (s3d_deterministic()) {
         S3D_REQUIRE((size_t)a.ntok * 64 <= 160 * 1024, "posgrad (deterministic): ntok=%d too large", a.ntok);
+        static bool attr = false;               // above 64 KB of dynamic LDS a launch needs the attribute (ntok > 1024)
+        if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(posgrad_det_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
         hipLaunchKernelGGL(posgrad_det_kernel, dim3((unsigned)((a.D + 15) / 16)), dim3(256), (size_t)a.ntok * 64, s, a);
         S3D_CHECK_LAUNCH("posgrad (deterministic)");
         return 0;

@@ -8,6 +8,7 @@ torch.distributed only -- all arithmetic of the path runs in the hand-written gf
 Reference call sites this replaces: Feature3D_ViT2D_V2.forward_features/forward
 (models/vit_3d_2d_pretrain.py:453-526), F.cross_entropy + loss.backward() + optimizer.step()
 (train_cls_voxel.py:277-288)."""
+import contextlib
 import ctypes
 import os
 import math
@@ -470,15 +471,20 @@ class VoxelEngine:
         want = (self.dropout_p > 0 and ws.G >= 192 and os.environ.get('S3D_NO_ATTN_MASK') != '1'       # (A/B knob)
                 and words * 4 <= ATTN_MASK_BUDGET_BYTES)             # above the budget the kernels evaluate the hash (bit-identical, ~2 % slower)
         if not want:
-            e.acts.attn_mask = None                                  # ... also after set_dropout(0): nothing reads it in eval mode
-            if self.dropout_p == 0:
-                self._attn_mask = None                               # released with the workspaces' references gone
+            # eval mode / short sequences: nothing reads it.  The buffer itself is KEPT (train <-> eval toggles must neither free memory
+            # that a captured training graph has baked into its kernel arguments nor re-zero gigabytes per toggle)
+            e.acts.attn_mask = None
             return
         buf = getattr(self, '_attn_mask', None)                      # ONE buffer for every batch-size workspace, sized for the largest G seen
         if buf is None or buf.numel() < words:
+            if buf is not None and self._graphs:
+                # graphs captured so far hold the OLD pointer: it stays alive for as long as the engine does (a caller may still replay
+                # its handle -- self-consistent on the old buffer), and the cache forgets them so that the next capture sees the new one
+                self._attn_mask_retired = getattr(self, '_attn_mask_retired', []) + [buf]
+                self._graphs.clear()
             buf = torch.zeros(words, dtype=torch.int32, device=self.device)
             self._attn_mask = buf
-            self.capture_epoch += 1                                  # captured graphs hold the old pointer
+            self.capture_epoch += 1                                  # trainers holding their own captures re-capture
             for other in self._ws.values():
                 if getattr(other, 'enc', None) is not None and other.enc.acts.attn_mask:
                     other.enc.acts.attn_mask = buf.data_ptr()
@@ -577,6 +583,7 @@ class VoxelEngine:
         assert Cc == 1 and H == self.V and W == self.V and V == self.V, \
             f"Input voxel size ({H}*{W}*{V}) doesn't match model ({self.V}*{self.V}*{self.V})."   # embed_layer_3d_modality.py:36
         ws = self.workspace(B)
+        ws._ln_aux_cont = None                  # a new forward: its backward starts with fresh row-statistics vectors
         lib, s, a = self.lib, L.current_stream(), self.arena
         fa = L.fill(L.S3dFoldArgs(), x=x, a_hi=ws.a[0], a_lo=ws.a[1], lda=self.Kpad, B=B, V=self.V, c=self.c, P=self.P,
                     mode=self.fold_mode)
@@ -757,6 +764,17 @@ class VoxelEngine:
             end = start
         return segments, slices
 
+    @contextlib.contextmanager
+    def owning_grads(self):
+        """Scope in which the caller owns the gradient arena -- zeroed by its previous optimizer step, exactly one backward, nothing else
+        accumulates into it: the grouped wgrads STORE dW / db instead of read-modify-write (S3dBlockScratch::wg_overwrite).  A backward
+        outside such a scope (gradient accumulation, autograd.Function callers, gradient checks) accumulates as torch does."""
+        prev, self.grads_owned = self.grads_owned, True
+        try:
+            yield
+        finally:
+            self.grads_owned = prev
+
     def blocks_backward_range(self, ws, first, last):
         fill = getattr(self, '_fill', None)
         if fill is not None:
@@ -765,10 +783,15 @@ class VoxelEngine:
         # accumulates into it): the grouped wgrads store instead of read-modify-write
         ws.sc1.wg_overwrite = 1 if (self.grads_owned and WGRAD_OVERWRITE and not self.group and self.images is None) else 0
         if (first, last) != (self.depth - 1, 0) and ws.scratch.ln_aux is not None and not self.group:
-            # a backward issued in segments: the weights-only vectors of the fused LayerNorm backward once, in front of the first segment
-            if first == self.depth - 1:
+            # a backward issued in segments: the weights-only vectors of the fused LayerNorm backward once per backward -- in front of its
+            # first segment, and again whenever this segment does not CONTINUE the previous one of the same forward (a lone
+            # blocks_backward_range(ws, 5, 3), a segment after a new forward ...): stale u / c vectors would give silently wrong LayerNorm
+            # and dx gradients.  An optimizer slice that runs BETWEEN the segments of one backward (sliced Adam) touches only
+            # blocks whose backward is done: the vectors of the blocks still to come stay valid.
+            if first == self.depth - 1 or getattr(ws, '_ln_aux_cont', None) != first:
                 L.check(self.lib.s3d_blocks_ln_aux(ctypes.byref(ws.blocks.shape), self.bparams, ctypes.byref(ws.sc1), self.depth - 1, 0,
                                                    L.current_stream()), 'blocks_ln_aux')
+            ws._ln_aux_cont = last - 1
             ws.sc1.ln_aux_valid = 1
         try:
             L.check(self.lib.s3d_blocks_bwd(ctypes.byref(ws.blocks.shape), self.bparams, self.bgrads, ws.blocks.acts,
@@ -949,7 +972,10 @@ class VoxelEngine:
 
     def capture_train_step(self, B, weight=None):
         """Captures train_step into a HIP graph over static input buffers; returns (graph, static_x, static_y, loss)."""
-        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p, getattr(self, 'update_slices', UPDATE_OVERLAP), getattr(self, 'adam_fill', ADAM_FILL))     # model.train() / .eval() toggles keep both captures
+        ws = self.workspace(B)                      # (may grow the shared attention-mask buffer: that clears the cache, see _ensure_attn_mask)
+        mask = getattr(self, '_attn_mask', None) if self.group else None
+        key = (B, None if weight is None else weight.data_ptr(), self.dropout_p, getattr(self, 'update_slices', UPDATE_OVERLAP), getattr(self, 'adam_fill', ADAM_FILL),
+               None if mask is None else mask.data_ptr(), self.backward_precision)     # model.train() / .eval() toggles keep both captures
         if key in self._graphs:
             return self._graphs[key]
         sx = torch.zeros(B, 1, self.V, self.V, self.V, dtype=torch.float32, device=self.device)

@@ -238,7 +238,6 @@ class DataParallelTrainer:
         # later buckets are still on the wire -- only the last (smallest) bucket's wire time and update stay exposed, instead of every
         # bucket's wait followed by one update over the whole arena.  Same arithmetic (s3d_adam_begin + s3d_adam_apply == s3d_adam_step).
         self.sliced_adam = sliced_adam and hasattr(engine, 'adam_apply') and len(self.slices) > 1
-        engine.grads_owned = True           # this trainer's step owns the gradient arena: zeroed by its Adam, one backward per step
 
     def collectives_mode(self):
         """How this trainer's captured step issues the bucket all-reduces (bench.py prints it)."""
@@ -274,7 +273,8 @@ class DataParallelTrainer:
         eng, B = self.eng, x.shape[0]
         eng.advance_dropout_seed()
         loss = eng.forward_loss(x, y, weight)
-        eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
+        with eng.owning_grads():            # this step owns the gradient arena (zeroed by its Adam, one backward): the grouped wgrads may store
+            eng.backward(B, segments=self.segments, on_segment=self.reducer.launch)
         self._update()
         return loss
 
@@ -288,7 +288,8 @@ class DataParallelTrainer:
         else:
             ws = eng.workspace(B)
         first, last = self.segments[k]
-        eng.backward_segment(ws, first, last, k == len(self.segments) - 1)
+        with eng.owning_grads():            # scoped to the trainer's own backward: a direct engine.backward() elsewhere keeps accumulating
+            eng.backward_segment(ws, first, last, k == len(self.segments) - 1)
 
     def capture(self, B, weight=None):
         eng = self.eng

@@ -69,5 +69,64 @@ def main():
           f'{int((gap > 2e-3).sum())}/{len(gap)} decisions above the 2e-3 gap')
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the same loop in a STABLE regime, several reference seeds -- the fixture carries the reference's own
+# seed-to-seed spread of held-out accuracy and final loss, which is what the benched (plain-bf16-backward) HIP step is asserted against.
+#   * lr 3e-5: the README recipe (Adam, lr 1e-3) runs under pytorch_warmup.UntunedLinearWarmup dampened once per EPOCH
+#     (train_cls_voxel.py:197-198,293-294): epoch e trains at 1e-3 (e + 1) / 1999, i.e. at <= 3e-5 for its first 60 epochs;
+#   * 12 classes encoded as occupancy 0.05 + 0.015 i (five sigma of a 30^3 grid's density apart: learnable, not trivial), 256 training
+#     samples in 16 batches, 400 steps (25 epochs), 256 held-out samples evaluated at six checkpoints (steps 300, 320 .. 400);
+#   * five seeds of the reference's initialisation scheme.
+STABLE = dict(backbone='deit_small_patch16_224', embed_layer='VoxelEmbed', voxel_size=30, cell=6, patch=5, n_classes=40,
+              pos_embedding='default', head='default', batch=16, steps=400, n_batches=16, lr=3e-5,
+              labels=[0, 3, 7, 12, 18, 21, 26, 33, 38, 5, 15, 29], density_base=0.05, density_step=0.015,
+              held_batch=256, checkpoints=[300, 320, 340, 360, 380, 400], seeds=[9, 10, 11, 12, 13], tail=40)
+
+
+def stable_batches(cfg):
+    kw = dict(base=cfg['density_base'], step=cfg['density_step'])
+    train = [vo.synthetic_class_batch(cfg['batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=500 + i, **kw) for i in range(cfg['n_batches'])]
+    held = vo.synthetic_class_batch(cfg['held_batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=999, **kw)
+    return train, held
+
+
+def main_stable():
+    cfg = STABLE
+    kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')}
+    data, (xh, yh) = stable_batches(cfg)
+    out = dict(cfg=np.array(json.dumps(cfg)), held_target=yh.numpy())
+    for seed in cfg['seeds']:
+        sd = vo.init_state_dict(seed=seed, exercise_all=False, portable=True, **kw)
+        model = build_reference_model(cfg)
+        model.load_state_dict(sd, strict=True)
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=cfg['lr'])                      # train_cls_voxel.py:195
+        losses, accs, ams = [], [], []
+        for step in range(cfg['steps']):
+            x, y = data[step % len(data)]
+            opt.zero_grad()                                                           # train_cls_voxel.py:277-288
+            loss = torch.nn.functional.cross_entropy(model(x), y)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+            if step + 1 in cfg['checkpoints']:
+                model.eval()                                                          # train_cls_voxel.py:306-329
+                with torch.no_grad():
+                    am = model(xh).argmax(1)
+                model.train()
+                ams.append(am.numpy())
+                accs.append(float((am == yh).float().mean()))
+        out[f'fingerprint_{seed}'] = fingerprint(sd)
+        out[f'losses_{seed}'] = np.array(losses)
+        out[f'held_acc_{seed}'] = np.array(accs)
+        out[f'held_argmax_{seed}'] = np.stack(ams).astype(np.int16)
+        print(f'seed {seed}: loss {losses[0]:.4f} -> last-{cfg["tail"]} mean {np.mean(losses[-cfg["tail"]:]):.4f}; held-out accuracy at the checkpoints '
+              f'{" ".join(f"{a:.3f}" for a in accs)} (mean {np.mean(accs):.3f})', flush=True)
+    np.savez_compressed(os.path.join(HERE, 'trained_stable_cfg1_small_v30_adam400.npz'), **out)
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'stable':
+        main_stable()
+    else:
+        main()
