@@ -559,6 +559,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--no-graphs', action='store_true', help='eager launches instead of HIP-graph replay')
     ap.add_argument('--plain-bf16', action='store_true', help='one-MFMA forward (fails the 1e-3 logit bar; for comparison only)')
+    ap.add_argument('--backward', choices=['bf16', 'split'], default='bf16',
+                    help="backward precision of the voxel configs: bf16 (default: plain bf16 MFMA operands -- asserted against the reference's own "
+                         "seed-to-seed spread of trained accuracy / final loss, tests/test_gpu_trajectory.py) or split (every gradient product on "
+                         "hi + lo operands, three MFMAs: VoxelEngine(precise_backward=True), the gradient-parity mode)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--force-collectives', action='store_true',
@@ -579,6 +583,14 @@ def main():
     ap.add_argument('--standin-gbps', type=float, default=0.0,
                     help='one-rank diagnostic (with --force-collectives): every bucket all-reduce is replaced by a copy kernel of that bus bandwidth on a '
                          'side stream / graph branch -- what a LIVE collective branch costs the captured step (profiles/r05_dp_branch_tax.txt)')
+    ap.add_argument('--dp', choices=['auto', 'sharded', 'replicated'], default='auto',
+                    help='N > 1 design of the voxel configs.  sharded (auto at N > 1): per bucket reduce-scatter -> Adam on the local 1/N shard -> '
+                         'all-gather overlapped with the NEXT forward (parallel.ShardedDataParallelTrainer); replicated: bucketed all-reduce + the '
+                         'full Adam on every rank (rounds 1 - 5, parallel.DataParallelTrainer)')
+    ap.add_argument('--bucket-list', type=str, default=None, help='sharded design: blocks per bucket in backward order, e.g. 3,3,3,2,1 (the default at depth 12)')
+    ap.add_argument('--emulate-world', type=int, default=0,
+                    help='one-rank diagnostic of the sharded design (with --standin-gbps): collectives replaced by copy kernels of an E-rank '
+                         "ring's reduce-scatter / all-gather duration, Adam on 1/E of every bucket; timing only (profiles/r06_dp_sharded.txt)")
     ap.add_argument('--event-graph', action='store_true',
                     help='ONE graph with an event-record node behind every backward segment, collectives launched from a side stream on '
                          'those events (measured slower than the default on this runtime: one graph per segment, collectives in between)')
@@ -586,6 +598,17 @@ def main():
     ap.add_argument('--no-pipeline', action='store_true',
                     help='point configs: FPS / kNN inside the step instead of one step ahead on the side stream (the default)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` the way `--gpus 1` is run: re-launch this very command line as N ranks on this node (one process per
+        # GPU over RCCL), rendezvous on 127.0.0.1 at a free port; the ranks' stdout is ours, so rank 0's JSON line is the last line printed
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        return sys.exit(subprocess.call(cmd))
     if args.config in POINT_CONFIGS:
         return main_points(args)
     global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE, PMC_TRAFFIC_FILE
@@ -618,7 +641,7 @@ def main():
         dist.init_process_group(backend=os.environ.get('S3D_BENCH_BACKEND', 'nccl'), init_method='env://', world_size=world, rank=rank)
 
     # model + optimizer state (reference init, seed 9), per-rank synthetic shard of the global batch
-    eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, pos_embedding=conf['pos_embedding'], **CFG)
+    eng = s3d.VoxelEngine(device=dev, split=not args.plain_bf16, pos_embedding=conf['pos_embedding'], backward=args.backward, **CFG)
     sd = vo.init_state_dict(seed=9, pos_embedding=conf['pos_embedding'], **CFG)
     eng.load_state_dict(sd)
     x_cpu, y_cpu = vo.synthetic_batch(BATCH_PER_GPU, CFG['voxel_size'], CFG['n_classes'], seed=9 + rank)
@@ -627,12 +650,23 @@ def main():
         eng.set_dropout(conf['dropout'], seed=9)                # model.train(): nn.TransformerEncoderLayer(dropout=0.1)
     # fp32 on the wire = what the reference's DDP all-reduces (train_cls_voxel.py:155-159); bf16 (half the xGMI bytes) is opt-in
     wire = 'fp32' if args.wire == 'auto' else args.wire
-    trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
-                                  force_collectives=args.force_collectives,
-                                  graph_collectives={'auto': 'auto', 'on': True, 'off': False}[args.graph_collectives], wire=wire,
-                                  event_graph=args.event_graph, sliced_adam=not args.single_update, standin_gbps=args.standin_gbps,
-                                  blocks_per_bucket=args.bucket_blocks, standin_latency_us=args.standin_latency_us)
-    trainer.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
+    sharded = args.dp == 'sharded' or (args.dp == 'auto' and (world > 1 or args.emulate_world > 0))
+    if sharded:
+        from simple3d_former_amd.parallel import ShardedDataParallelTrainer
+        eng.set_optimizer(lr=1e-3)                              # README recipe (README.md:60)
+        trainer = ShardedDataParallelTrainer(eng, bucket_blocks=[int(v) for v in args.bucket_list.split(',')] if args.bucket_list else None,
+                                             use_graphs=not args.no_graphs, force_collectives=args.force_collectives,
+                                             graph_collectives={'auto': 'auto', 'on': True, 'off': False}[args.graph_collectives],
+                                             standin_gbps=args.standin_gbps, standin_latency_us=args.standin_latency_us,
+                                             emulate_world=args.emulate_world)
+        args.no_diagnostics = True                              # (the per-bucket all-reduce diagnostics belong to the replicated design)
+    else:
+        trainer = DataParallelTrainer(eng, n_buckets=args.buckets, use_graphs=not args.no_graphs,
+                                      force_collectives=args.force_collectives,
+                                      graph_collectives={'auto': 'auto', 'on': True, 'off': False}[args.graph_collectives], wire=wire,
+                                      event_graph=args.event_graph, sliced_adam=not args.single_update, standin_gbps=args.standin_gbps,
+                                      blocks_per_bucket=args.bucket_blocks, standin_latency_us=args.standin_latency_us)
+        trainer.set_optimizer(lr=1e-3)                          # README recipe (README.md:60)
     ident = rccl_identity(dev, world)
     if world > 1:
         assert ident['rccl_ranks'] == world and ident['distinct_devices'] == world or os.environ.get('S3D_BENCH_DEVICE') is not None, \
@@ -660,6 +694,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    if sharded:
+        trainer.sync_parameters()       # the last step's all-gather phase (otherwise the next step's first phase): inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     L.lib().s3d_prof_skip_get.restype = ctypes.c_double
@@ -678,13 +714,19 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'bf16',
         'precision_note': ('plain bf16 forward (fails the 1e-3 logit bar; comparison only)' if args.plain_bf16 else
-                           'bf16 MFMA operands: split-bf16 (hi+lo, 3 MFMAs per product) forward, plain bf16 backward; fp32 '
-                           'accumulation, residual stream, LayerNorm/softmax/GELU, loss and Adam'),
+                           'bf16 MFMA operands: split-bf16 (hi+lo, 3 MFMAs per product) forward, '
+                           + ('split-bf16 backward too (gradient-parity mode)' if args.backward == 'split' else 'plain bf16 backward')
+                           + '; fp32 accumulation, residual stream, LayerNorm/softmax/GELU, loss and Adam'),
+        'backward_precision': eng.backward_precision,
         'data': f'synthetic (seeded 10%-occupancy {CFG["voxel_size"]}^3 grids, random-init weights of the reference architecture)',
         'config': {'workload': conf['workload'], 'batch_per_gpu': BATCH_PER_GPU,
                    'global_batch': world * BATCH_PER_GPU, 'tokens_per_sample': eng.ntok, 'parallelism': f'dp{world}',
                    'launch': 'eager' if args.no_graphs else 'hipGraph replay',
                    'grad_buckets': len(trainer.slices), 'grad_wire': wire,
+                   'dp_design': ('sharded optimizer: reduce-scatter -> Adam on the 1/N shard -> all-gather overlapped with the next forward'
+                                 if sharded else 'replicated optimizer: bucketed all-reduce overlapped with backward'),
+                   'bucket_blocks': [f - l + 1 for f, l in trainer.segments] if sharded else None,
+                   'emulate_world': getattr(trainer, 'emulate_world', 0) or None,
                    'collectives': trainer.collectives_mode()},
         'rccl_ranks': ident['rccl_ranks'], 'distinct_devices': ident['distinct_devices'], 'dist_backend': ident['backend'],
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),

@@ -499,6 +499,12 @@ int s3d_blocks_fwd(const S3dBlockShape* shape, const S3dBlockParams* params, con
 int s3d_blocks_bwd(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockGrads* grads,
                    const S3dBlockActs* acts, const S3dBlockScratch* scratch, int first, int last,
                    s3d_stream_t stream);
+/* blocks first .. last (first <= last < depth) of the same stack, the forward's counterpart of s3d_blocks_bwd's range: a data-parallel
+ * caller whose parameters arrive bucket by bucket (sharded optimizer: all-gather of block k's parameters overlapped with blocks < k of the next
+ * forward, train_cls_voxel.py:287-288's DDP overlap turned around) runs the forward in the same ranges.  Block `last` never reads the
+ * parameters of block last + 1 (the fused next-norm1 hand-off of ln_tickets stops at the range end); results are those of s3d_blocks_fwd. */
+int s3d_blocks_fwd_range(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockActs* acts, int depth, int first, int last,
+                         s3d_stream_t stream);
 /* the weights-only row-statistics vectors (S3dBlockScratch::ln_aux) of blocks last .. first in one launch; set scratch->ln_aux_valid = 1 for the
  * s3d_blocks_bwd calls that follow, until the parameters change */
 int s3d_blocks_ln_aux(const S3dBlockShape* shape, const S3dBlockParams* params, const S3dBlockScratch* scratch, int first, int last,

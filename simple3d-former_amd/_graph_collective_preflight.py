@@ -35,6 +35,32 @@ def main():
     torch.cuda.synchronize()
     want = world * (world + 1) / 2
     ok = bool((buf[0] == 0.5 * want).all()) and bool((buf[1] == want).all())
+    if ok and os.environ.get('S3D_PREFLIGHT_SHARDED') == '1':
+        # the sharded trainer's pair: IN-PLACE reduce-scatter of a bucket (output = the rank's chunk of the input) and in-place all-gather
+        # (input = the rank's chunk of the output) on a side stream of a captured graph, as parallel.ShardedDataParallelTrainer issues them
+        m = (1 << 20) // world * world
+        b2 = torch.zeros(m, device='cuda')
+        c = m // world
+        dist.reduce_scatter_tensor(b2[rank * c:(rank + 1) * c], b2)
+        dist.all_gather_into_tensor(b2, b2[rank * c:(rank + 1) * c])
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            b2.fill_(float(rank + 1))
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dist.reduce_scatter_tensor(b2[rank * c:(rank + 1) * c], b2)
+                b2[rank * c:(rank + 1) * c].add_(float(rank))          # "the shard's update"
+                dist.all_gather_into_tensor(b2, b2[rank * c:(rank + 1) * c])
+            torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            g2.replay()
+        torch.cuda.synchronize()
+        expect = torch.cat([torch.full((c,), want + r, device='cuda') for r in range(world)])
+        ok = bool((b2 == expect).all())
+        if not ok:
+            print(f'S3D_PREFLIGHT_WRONG sharded pair: {b2[::c].tolist()} want {expect[::c].tolist()}', flush=True)
     dist.destroy_process_group()
     print('S3D_PREFLIGHT_OK' if ok else f'S3D_PREFLIGHT_WRONG {float(buf[0, 0])} {float(buf[1, 0])} want {0.5 * want} {want}', flush=True)
     sys.exit(0 if ok else 4)

@@ -1009,24 +1009,28 @@ int s3d_graph_marker(int id, s3d_stream_t s) {
     S3D_CHECK_LAUNCH("graph_marker");
     return 0;
 }
-// Measurement aid (parallel.py: BucketedGradReducer stand-in): copies nbytes with a few workgroups (gbps / 5) paced to `gbps` GB/s against the 100 MHz
-// wall clock -- the footprint (a few CUs) and duration a ring all-reduce of the same bytes has on RCCL's stream, for measuring what a live
-// side branch costs a captured step graph on one GPU.
+// Measurement aid (parallel.py: the stand-in collectives of BucketedGradReducer / ShardedDataParallelTrainer): copies nbytes with a few workgroups
+// paced to `gbps` GB/s against the 100 MHz wall clock -- the footprint (a few CUs) and duration a ring collective of the same bytes has on RCCL's
+// stream, for measuring what a live side branch costs a captured step graph on one GPU.  Round 6: four 16-byte loads in flight per thread
+// (~25 GB/s per workgroup instead of ~7), so that 286 GB/s takes 16 workgroups, not 58 -- a ring kernel's channel count, not a quarter of the chip.
 __global__ __launch_bounds__(256) void s3d_paced_copy_kernel(u32x4* dst, const u32x4* src, long n16, float bytes_per_tick) {
-    const long per = (n16 + gridDim.x - 1) / gridDim.x, b = (long)blockIdx.x * per, e = b + per < n16 ? b + per : n16;
+    const long per = ((n16 + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024, b = (long)blockIdx.x * per, e = b + per < n16 ? b + per : n16;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     long chunk = 0;
-    for (long i = b; i < e; i += 256, ++chunk) {
-        if (i + threadIdx.x < e) dst[i + threadIdx.x] = src[i + threadIdx.x];
-        const float due = (float)((chunk + 1) * 4096) / bytes_per_tick;
+    for (long i = b; i < e; i += 1024, ++chunk) {
+        u32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const long k = i + j * 256 + threadIdx.x; v[j] = k < e ? src[k] : u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const long k = i + j * 256 + threadIdx.x; if (k < e) dst[k] = v[j]; }
+        const float due = (float)((chunk + 1) * 16384) / bytes_per_tick;
         while ((float)(__builtin_amdgcn_s_memrealtime() - t0) < due) __builtin_amdgcn_s_sleep(2);
     }
 }
 int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t s) {
     S3D_REQUIRE(dst && src && nbytes >= 16 && (nbytes & 15) == 0 && gbps > 0.f, "s3d_debug_paced_copy: 16-byte multiples, a positive rate");
-    // one workgroup of this loop moves ~7 GB/s (measured: 16 workgroups 118 GB/s): enough of them that the pacing, not the copy, sets the rate
-    int wgs = (int)(gbps / 5.0f) + 1;
-    wgs = wgs < 8 ? 8 : wgs > 128 ? 128 : wgs;
+    int wgs = (int)(gbps / 18.0f) + 1;
+    wgs = wgs < 4 ? 4 : wgs > 64 ? 64 : wgs;
     const float bytes_per_tick = gbps * 10.0f / wgs;                    // GB/s = bytes per ns; one tick of the 100 MHz clock = 10 ns
     hipLaunchKernelGGL(s3d_paced_copy_kernel, dim3(wgs), dim3(256), 0, st(s), static_cast<u32x4*>(dst), static_cast<const u32x4*>(src), nbytes / 16,
                        bytes_per_tick);
@@ -1115,6 +1119,18 @@ int s3d_blocks_fwd(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBl
     bool ln1_done = false;
     for (int i = 0; i < depth; ++i) {
         const bool has_next = i + 1 < depth && a[i + 1].x_in == a[i].x_out;     // the next block normalises exactly this block's output
+        bool next_done = false;
+        S3D_TRY(block_fwd(*sh, p[i], a[i], st(s), ln1_done, has_next ? &p[i + 1] : nullptr, has_next ? &a[i + 1] : nullptr, &next_done,
+                          sh->cls_only_block == i + 1));
+        ln1_done = next_done;
+    }
+    return 0;
+}
+int s3d_blocks_fwd_range(const S3dBlockShape* sh, const S3dBlockParams* p, const S3dBlockActs* a, int depth, int first, int last, s3d_stream_t s) {
+    S3D_REQUIRE(sh && p && a && first >= 0 && first <= last && last < depth, "s3d_blocks_fwd_range: null args or not 0 <= first <= last < depth");
+    bool ln1_done = false;
+    for (int i = first; i <= last; ++i) {
+        const bool has_next = i < last && a[i + 1].x_in == a[i].x_out;     // the range end never touches block last + 1's parameters
         bool next_done = false;
         S3D_TRY(block_fwd(*sh, p[i], a[i], st(s), ln1_done, has_next ? &p[i + 1] : nullptr, has_next ? &a[i + 1] : nullptr, &next_done,
                           sh->cls_only_block == i + 1));

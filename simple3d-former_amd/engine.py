@@ -38,6 +38,9 @@ BLOCK_PARAM_SHAPE = {'norm1.weight': lambda D: (D,), 'norm1.bias': lambda D: (D,
                      'mlp.fc2.weight': lambda D: (D, 4 * D), 'mlp.fc2.bias': lambda D: (D,)}
 
 
+BUCKET_ALIGN = 512
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -99,9 +102,15 @@ class ParamArena:
         self.offsets = {}
         off = 0
         for k, shp in self.shapes.items():
+            if k.startswith('blocks.') and k.endswith('.norm1.weight'):
+                # a block starts on a BUCKET_ALIGN boundary: data-parallel gradient buckets are arena slices that begin at block starts,
+                # and the sharded optimizer (parallel.ShardedDataParallelTrainer) cuts every bucket into world-size equal, 8-element
+                # aligned shards (reduce_scatter_tensor / all_gather_into_tensor need equal chunks) -- 512 = 8 x 64 ranks.  The pad
+                # elements are ordinary zeros with zero gradients: Adam leaves them at zero.
+                off = _round_up(off, BUCKET_ALIGN)
             self.offsets[k] = off
             off = _round_up(off + int(np.prod(shp)), 8)       # 16-byte aligned bf16 planes, 32-byte aligned fp32
-        self.numel = _round_up(off, 8)
+        self.numel = _round_up(off, BUCKET_ALIGN)
         self.device = device
         self.p = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.g = torch.zeros_like(self.p)
@@ -126,6 +135,12 @@ class ParamArena:
 
     def state_dict(self):
         return {k: self.param(k).detach().clone() for k in self.shapes}
+
+    def refresh_planes_range(self, start, end):
+        """hi / lo planes of the arena slice [start, end) from the fp32 parameters (the sharded optimizer's all-gathered buckets)."""
+        off = lambda t, b: ctypes.c_void_p(t.data_ptr() + b * start)
+        L.check(L.lib().s3d_split_bf16(off(self.p, 4), off(self.hi, 2), off(self.lo, 2), ctypes.c_long(1), ctypes.c_long(end - start),
+                                       ctypes.c_long(end - start), L.current_stream()), 'split_bf16 (range)')
 
     def refresh_planes(self):
         """fp32 arena -> split-bf16 planes (needed whenever the parameters were changed outside s3d_adam_step)."""
@@ -302,7 +317,11 @@ class VoxelEngine:
 
     def __init__(self, *, backbone, embed_layer, voxel_size, cell, patch, n_classes, pos_embedding='default',
                  head='default', device='cuda', split=True, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, image_branch=False, ln_fuse=None,
-                 precise_backward=False):
+                 precise_backward=False, backward=None):
+        if backward not in (None, 'bf16', 'split'):
+            raise ValueError(f"backward must be 'bf16' (plain bf16 MFMA operands: the default, what bench.py times) or 'split' "
+                             f"(every gradient product on hi + lo operands: precise_backward), not {backward!r}")
+        precise_backward = bool(precise_backward) or backward == 'split'
         if backbone not in BACKBONES:
             raise ValueError("Unknown transformer backbone name!")           # vit_3d_2d_pretrain.py:393-394
         if pos_embedding not in (None, 'default', 'group_embed'):
@@ -337,6 +356,7 @@ class VoxelEngine:
         # operands without split-K, fp32 attention backward, gradients carried as hi + lo pairs -- so that gradients can be held to
         # ~1e-4 of the reference instead of the plain-bf16 noise floor.  Several times slower.  Tests only.
         self.precise = bool(precise_backward)
+        self.backward_precision = 'split' if self.precise else 'bf16'
         if self.precise and (image_branch or not split):
             raise NotImplementedError('precise_backward covers the split-bf16 voxel path (no image branch)')
         self.ln_fuse = ln_fuse              # None: S3D_LN_FUSE decides (default off, see LN_FUSE above)
@@ -413,6 +433,10 @@ class VoxelEngine:
     def refresh_weight_planes(self):
         self.arena.refresh_planes()
         self._refresh_conv_planes()
+
+    def refresh_planes_range(self, start, end):
+        """hi / lo planes of the arena slice [start, end) (an all-gathered bucket of the sharded data-parallel step)."""
+        self.arena.refresh_planes_range(start, end)
 
     def _refresh_conv_planes(self):
         if self.Kpad != self.Kc:
@@ -564,9 +588,9 @@ class VoxelEngine:
         return ws
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x):
+    def forward(self, x, block_ranges=None, before_range=None):
         """x: [B,1,V,V,V] float32 on the device (the trainer's voxel.float(), train_cls_voxel.py:276) -> logits."""
-        ws = self.forward_features(x)
+        ws = self.forward_features(x, block_ranges, before_range)
         a, lib, s, B = self.arena, self.lib, L.current_stream(), x.shape[0]
         ln = L.fill(L.S3dLnArgs(), x=ws.last.x[self.depth], ldx=ws.ntok_last * self.D, rows=B, D=self.D, eps=LN_EPS,
                     gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
@@ -576,8 +600,22 @@ class VoxelEngine:
         self._loss_end_done = False
         return ws.logits
 
-    def forward_features(self, x):
-        """Everything up to the last block's output (the class rows of ws.last.x[depth] feed the final norm + head)."""
+    def forward_features(self, x, block_ranges=None, before_range=None):
+        """Everything up to the last block's output (the class rows of ws.last.x[depth] feed the final norm + head).
+        block_ranges = [(first, last), ...] ascending: the first block pass as s3d_blocks_fwd_range calls with before_range(i) in front of
+        range i > 0 (parallel.ShardedDataParallelTrainer: range i's parameters arrive by all-gather while ranges < i compute)."""
+        ws = self.forward_tokens(x)
+        if block_ranges is None:
+            L.check(self.lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, L.current_stream()), 'blocks_fwd')
+        else:
+            for i, (first, last) in enumerate(block_ranges):
+                if before_range is not None and i > 0:
+                    before_range(i)                 # (range 0's parameters were awaited by the caller: the tokenizer needs them too)
+                self.forward_blocks(ws, first, last)
+        return self.forward_tail(ws)
+
+    def forward_tokens(self, x):
+        """Tokenizer (+ the seq-first encoder layer of group_embed): fills the input of block 0 of the (first) block pass."""
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(), 'voxel grid must be a contiguous fp32 device tensor'
         B, Cc, H, W, V = x.shape
         assert Cc == 1 and H == self.V and W == self.V and V == self.V, \
@@ -604,8 +642,18 @@ class VoxelEngine:
             # seq-first encoder layer over the B*P*P axis, then pass 1 of the blocks on (B*P*P, P+1, D)
             L.check(lib.s3d_encoder_layer_fwd(ctypes.byref(ws.enc.shape), ctypes.byref(self.eparams),
                                               ctypes.byref(ws.enc.acts), s), 'encoder_layer_fwd')
-        L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, s), 'blocks_fwd')
+        return ws
+
+    def forward_blocks(self, ws, first, last):
+        """Blocks first .. last of the (first) block pass (s3d_blocks_fwd_range)."""
+        L.check(self.lib.s3d_blocks_fwd_range(ctypes.byref(ws.blocks.shape), self.bparams, ws.blocks.acts, self.depth, first, last,
+                                              L.current_stream()), 'blocks_fwd_range')
+
+    def forward_tail(self, ws):
+        """What follows the (first) block pass: nothing for the default embedding; group_embed's pass-1 final norm, token assembly and
+        the second pass over the same blocks (vit_3d_2d_pretrain.py:481-496)."""
         if self.group:
+            lib, s, a, B = self.lib, L.current_stream(), self.arena, ws.B
             # norm(x)[:, 0] of every group -> '(b px py) c -> b (px py) c' + cls + voxel_pos_embed -> pass 2 (same blocks)
             ln1 = L.fill(L.S3dLnArgs(), x=ws.blocks.x[self.depth], ldx=self.ntok * self.D, rows=ws.G, D=self.D, eps=LN_EPS,
                          gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.gfeat, ldo=self.D,
@@ -615,6 +663,21 @@ class VoxelEngine:
                                             L.ptr(ws.blocks2.x[0]), ctypes.c_long(B), self.P * self.P, self.D, s), 'assemble')
             L.check(lib.s3d_blocks_fwd(ctypes.byref(ws.blocks2.shape), self.bparams, ws.blocks2.acts, self.depth, s), 'blocks_fwd 2')
         return ws
+
+    def loss_of_features(self, B, target, weight=None):
+        """The loss end of a training forward whose features are in place (forward_features / forward_tokens + forward_blocks +
+        forward_tail): final norm + head + F.cross_entropy, fused where forward_loss fuses it."""
+        if self.am or not FUSE_LOSS_END or self.C > 256 or self.D > 1024 or self.precise:
+            ws = self.workspace(B)
+            a, lib, s = self.arena, self.lib, L.current_stream()
+            ln = L.fill(L.S3dLnArgs(), x=ws.last.x[self.depth], ldx=ws.ntok_last * self.D, rows=B, D=self.D, eps=LN_EPS,
+                        gamma=a.param('norm.weight'), beta=a.param('norm.bias'), out_f32=ws.feat, ldo=self.D,
+                        mean=ws.fstats[0], rstd=ws.fstats[1])
+            L.check(lib.s3d_layernorm_fwd(ctypes.byref(ln), s), 'final norm')
+            L.check(lib.s3d_head_fwd(ctypes.byref(self._head_args(ws)), s), 'head_fwd')
+            self._loss_end_done = False
+            return self.cross_entropy(B, target, weight)
+        return self.head_loss(B, target, weight)
 
     def head_loss(self, B, target, weight=None, grad_scale=1.0):
         """Final norm -> Linear head -> F.cross_entropy -> d(logits) -> d(feat) -> final-norm backward in two launches
@@ -733,7 +796,7 @@ class VoxelEngine:
             if on_segment is not None:
                 on_segment(i)
 
-    def grad_buckets(self, n_buckets=3, blocks_per_bucket=None):
+    def grad_buckets(self, n_buckets=3, blocks_per_bucket=None, block_counts=None):
         """Splits the backward into `n_buckets` block ranges and returns (segments, [(start, end) arena slices]) such
         that slice i holds exactly the gradients that are final once segment i has run (arena is in forward order).
         Bucket sizes shrink geometrically in backward order (depth 12, 4 buckets: blocks 11-6, 5-3, 2-1, 0 + tokenizer):
@@ -742,7 +805,17 @@ class VoxelEngine:
         blocks_per_bucket = k: UNIFORM buckets of k blocks instead (depth 12, k = 2: 11-10 | 9-8 | .. | 1-0 + tokenizer) -- the wire then
         starts after k blocks of backward instead of after half of it, which matters when the wire time of the whole gradient is about
         as long as the backward itself (cfg-2: 0.6 ms of fp32 ring all-reduce against a 0.7 ms backward, profiles/r05_dp_branch_tax.txt)."""
-        if blocks_per_bucket:
+        if block_counts:
+            # explicit bucket sizes in BACKWARD order (depth 12, [3, 3, 3, 2, 1]: 11-9 | 8-6 | 5-3 | 2-1 | 0 + tokenizer): the sharded trainer's
+            # last bucket -- the only one whose wire time is exposed, and the first the next forward needs -- is the smallest
+            counts = [int(c) for c in block_counts]
+            assert all(c >= 1 for c in counts) and sum(counts) == self.depth, f'block_counts {counts} must be positive and sum to depth {self.depth}'
+            n = len(counts)
+            bounds = [self.depth]
+            for c in counts:
+                bounds.append(bounds[-1] - c)
+            bounds = bounds[::-1]
+        elif blocks_per_bucket:
             k = max(1, int(blocks_per_bucket))
             n = (self.depth + k - 1) // k
             bounds = [max(0, self.depth - (n - j) * k) for j in range(n)] + [self.depth]
@@ -944,15 +1017,12 @@ class VoxelEngine:
         self._refresh_conv_planes()
         return loss
 
-    def forward_loss(self, x, target, weight=None):
+    def forward_loss(self, x, target, weight=None, block_ranges=None, before_range=None):
         """model(voxel) + F.cross_entropy for a TRAINING step; with the Linear head (C <= 256, D <= 1024) the loss end runs fused
         (head_loss): the head / final-norm gradients are accumulated right here, so follow it with exactly one backward() (no
         dlogits) -- for inference or custom d(logits) use forward() + cross_entropy()."""
-        if self.am or not FUSE_LOSS_END or self.C > 256 or self.D > 1024 or self.precise:     # s3d_head_loss_fused: Linear head, C <= 256, D <= 1024
-            self.forward(x)
-            return self.cross_entropy(x.shape[0], target, weight)
-        self.forward_features(x)
-        return self.head_loss(x.shape[0], target, weight)
+        self.forward_features(x, block_ranges, before_range)
+        return self.loss_of_features(x.shape[0], target, weight)     # s3d_head_loss_fused: Linear head, C <= 256, D <= 1024
 
     def lwf_train_step(self, x, target, img, img_target, lambda_weight=0.1, weight=None):
         """One learning-without-forgetting step (train_cls_voxel.py:240-268): loss = CE(model(voxel), cls_idx) +

@@ -23,6 +23,41 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _collect(procs, q, world, timeout):
+    """Results of all ranks, failing FAST when a rank died without reporting (a rendezvous error outside the worker's try block left the
+    other rank waiting and this test sitting out its whole timeout: 600 s of the driver's 1200)."""
+    import queue
+    import time
+    res, t0 = [], time.monotonic()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=1.0))
+            continue
+        except queue.Empty:
+            pass
+        dead = [p for p in procs if p.exitcode not in (None, 0)]
+        if dead and q.empty():
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f'{len(dead)} worker(s) exited with {[p.exitcode for p in dead]} without reporting (see stderr)')
+        if time.monotonic() - t0 > timeout:
+            for p in procs:
+                if p.is_alive():
+                    p.terminate()
+            raise AssertionError(f'no result within {timeout} s')
+    return sorted(res, key=lambda t: t[0])
+
+
+def _init_group(rank, world, port):
+    """gloo rendezvous through a FILE store (the token is unique per test): no listening port is chosen ahead of time, so there is no window in
+    which another listener can take it (the EADDRINUSE that once left rank 1 waiting for the whole timeout)."""
+    import datetime
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f's3d_rdzv_{os.getppid()}_{port}')
+    dist.init_process_group('gloo', init_method=f'file://{path}', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+
+
 def _voxel_setup(seed):
     import simple3d_former_amd as s3d
     from oracle import voxel_oracle as vo
@@ -44,9 +79,8 @@ def _point_setup(seed):
 
 
 def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_group(rank, world, port)
     try:
         from simple3d_former_amd.parallel import DataParallelTrainer, PointDataParallelTrainer
         sl = slice(rank * 3, rank * 3 + 3)
@@ -73,7 +107,7 @@ def test_two_processes_one_gpu_equal_single_process_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    res = _collect(procs, q, world, 300)
     for r in res:
         assert len(r) == 5, f'rank {r[0]} failed:\n{r[1]}'
     res = [(r[0], torch.from_numpy(r[1]), r[2], torch.from_numpy(r[3]), r[4]) for r in res]
@@ -104,9 +138,8 @@ WIRE_STEPS = 20
 
 def _worker_wire(rank, world, port, q):
     """Real engines, real process group, the two gradient wire formats one after the other on identical data."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_group(rank, world, port)
     try:
         from simple3d_former_amd.parallel import DataParallelTrainer
         sl = slice(rank * 3, rank * 3 + 3)
@@ -137,7 +170,7 @@ def test_bf16_gradient_wire_tracks_the_fp32_wire_over_twenty_steps():
     procs = [ctx.Process(target=_worker_wire, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    res = _collect(procs, q, world, 300)
     for r in res:
         assert isinstance(r[1], dict), f'rank {r[0]} failed:\n{r[1]}'
     for p in procs:
@@ -153,3 +186,71 @@ def test_bf16_gradient_wire_tracks_the_fp32_wire_over_twenty_steps():
         for s in range(WIRE_STEPS):
             worst = max(worst, abs(lb[s] - lf[s]) / max(abs(lf[s]), 1e-3))
     assert worst <= 5e-3, f'bf16 wire deviates from the fp32 wire by {worst:.2e} (relative loss)'
+
+
+def _worker_sharded(rank, world, port, q):
+    """Both data-parallel designs one after the other on the same two ranks, deterministic mode (bitwise reproducible kernels)."""
+    torch.cuda.set_device(0)
+    _init_group(rank, world, port)
+    try:
+        from simple3d_former_amd import _lib as L
+        from simple3d_former_amd.parallel import DataParallelTrainer, ShardedDataParallelTrainer
+        L.lib().s3d_set_deterministic(1)
+        sl = slice(rank * 3, rank * 3 + 3)
+        out = {}
+        for design in ('replicated', 'sharded_eager', 'sharded_graphs'):
+            eng, x, y = _voxel_setup(seed=7 + rank)               # different initial parameters per rank: the broadcast must fix it
+            if design == 'replicated':
+                tr = DataParallelTrainer(eng, blocks_per_bucket=4, use_graphs=True, sliced_adam=True)
+                assert tr.segments == [(11, 8), (7, 4), (3, 0)]
+            else:
+                tr = ShardedDataParallelTrainer(eng, use_graphs=design == 'sharded_graphs')
+                assert tr.segments == [(11, 8), (7, 4), (3, 0)] and tr.world == 2
+                assert all(b - a == (e - s) // 2 for (a, b), (s, e) in zip(tr.shards, tr.slices))
+            losses = [float(tr.step(x[sl].contiguous(), y[sl].contiguous())) for _ in range(STEPS)]
+            stale = None
+            if design != 'replicated':
+                torch.cuda.synchronize()
+                stale = eng.arena.p.cpu().numpy().copy()
+                tr.sync_parameters()
+                # the optimizer state lives in this rank's shards only
+                mask = torch.zeros(eng.arena.numel, dtype=torch.bool, device='cuda')
+                for a, b in tr.shards:
+                    mask[a:b] = True
+                assert not bool(eng.arena.m[~mask].any()) and bool(eng.arena.m[mask].any())
+                assert not bool(eng.arena.g.any())
+            torch.cuda.synchronize()
+            out[design] = (losses, eng.arena.p.cpu().numpy(), eng.arena.hi.view(torch.int16).cpu().numpy(), stale)
+        q.put((rank, out))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_optimizer_two_processes_bitwise_equal_the_replicated_design():
+    """Real engines, two processes, one GPU, gloo: ShardedDataParallelTrainer (eager and as graph phases) leaves both replicas bitwise equal to
+    each other and to DataParallelTrainer's replicas on the same buckets -- parameters AND weight planes -- although each rank ran Adam on
+    half of every bucket only; before the gather phase a rank's copy of the other rank's shards is one step behind."""
+    import numpy as np
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _collect(procs, q, world, 300)
+    for r in res:
+        assert isinstance(r[1], dict), f'rank {r[0]} failed:\n{r[1]}'
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = res[0][1], res[1][1]
+    for design in ('replicated', 'sharded_eager', 'sharded_graphs'):
+        assert np.array_equal(a[design][1], b[design][1]) and np.array_equal(a[design][2], b[design][2]), f'{design}: replicas diverged'
+    for design in ('sharded_eager', 'sharded_graphs'):
+        assert np.array_equal(a[design][1], a['replicated'][1]), f'{design} parameters != replicated parameters'
+        assert np.array_equal(a[design][2], a['replicated'][2]), f'{design} weight planes != replicated weight planes'
+        assert a[design][0] == a['replicated'][0] and b[design][0] == b['replicated'][0]
+        assert not np.array_equal(a[design][3], a[design][1]) and not np.array_equal(a[design][3], b[design][3])

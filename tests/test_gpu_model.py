@@ -336,6 +336,62 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize('mode', ['eager', 'phase_graphs', 'whole_graph', 'rccl_auto', 'group_embed'])
+def test_sharded_trainer_on_one_gpu_equals_the_plain_step(mode):
+    """ShardedDataParallelTrainer (reduce-scatter -> Adam on the local shard -> all-gather overlapped with the next forward in block ranges) at
+    one rank, where a shard is the whole bucket and the collectives move nothing: in DETERMINISTIC mode the parameters after four steps are
+    those of the engine's own fused step (same kernels on the same data; only LayerNorm-gradient partials are reduced per segment) -- eagerly,
+    as one graph per phase with the side-stream work launched from the host, as ONE captured graph, with forced 1-rank RCCL reduce-scatter /
+    all-gather behind the child-process preflight (rccl_auto), and for group_embed (two passes over the shared blocks)."""
+    import os
+    import torch.distributed as dist
+    from simple3d_former_amd import _lib as L
+    from simple3d_former_amd.parallel import ShardedDataParallelTrainer
+    group = mode == 'group_embed'
+    cfg = dict(backbone='deit_tiny_patch16_224', embed_layer='VoxelEmbed_no_average' if group else 'VoxelEmbed', voxel_size=12, cell=4, patch=3,
+               n_classes=10, pos_embedding='group_embed' if group else 'default', head='default', batch=5)
+    sd = vo.init_state_dict(seed=7, exercise_all=True, **{k: cfg[k] for k in MODEL_KEYS})
+    x, y = vo.synthetic_batch(5, 12, 10, seed=8)
+    x, y = x.to(DEV), y.to(DEV)
+    lib = L.lib()
+    lib.s3d_set_deterministic(1)
+    rccl = mode == 'rccl_auto'
+    if rccl:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29519')
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        ref, eng = make_engine(cfg, sd), make_engine(cfg, sd)
+        if rccl:
+            tr = ShardedDataParallelTrainer(eng, bucket_blocks=[5, 4, 2, 1], force_collectives=True)
+            assert tr.preflight is not None and tr.preflight[0], tr.preflight
+            assert tr.collectives_mode() == 'reduce-scatter + all-gather, captured in the step graph'
+        else:
+            tr = ShardedDataParallelTrainer(eng, bucket_blocks=[5, 4, 2, 1], use_graphs=mode != 'eager',
+                                            graph_collectives=mode in ('whole_graph', 'group_embed'))
+        assert tr.segments == [(11, 7), (6, 3), (2, 1), (0, 0)] and tr.fwd_ranges == [(0, 0), (1, 2), (3, 6), (7, 11)]
+        assert tr.slices[0][1] == eng.arena.numel and tr.slices[-1][0] == 0 and tr.shards == tr.slices
+        for step in range(4):
+            l_ref = float(ref.train_step(x, y))
+            l_dp = float(tr.step(x, y))
+            assert abs(l_ref - l_dp) <= 1e-5 * max(1.0, abs(l_ref)), f'step {step}: {l_ref} vs {l_dp}'
+        assert tr.pending
+        tr.sync_parameters()
+        torch.cuda.synchronize()
+        if mode != 'eager':
+            assert ('whole' in tr._cap) == (mode in ('whole_graph', 'rccl_auto', 'group_embed'))
+        d = float((eng.arena.p - ref.arena.p).abs().max())
+        assert d <= 2e-6, d                               # (LayerNorm partials are summed per segment: the last bits of those gradients may differ)
+        assert torch.equal(eng.arena.hi, ref.arena.hi) or d > 0
+        hi, lo = eng.arena.hi.clone(), eng.arena.lo.clone()
+        eng.refresh_weight_planes()                       # the planes the gather phase wrote ARE the split of the parameters
+        assert torch.equal(hi, eng.arena.hi) and torch.equal(lo, eng.arena.lo)
+        assert not eng.arena.g.any()
+    finally:
+        lib.s3d_set_deterministic(0)
+        if rccl:
+            dist.destroy_process_group()
+
+
 def test_group_embed_training_mode_dropout_matches_oracle():
     """model.train() semantics of group_embed: dropout(0.1) at the four sites of nn.TransformerEncoderLayer, with the
     counter-based mask shared by the HIP kernels and the oracle (torch's RNG stream itself cannot be reproduced)."""

@@ -209,3 +209,85 @@ def test_trained_state_fixture_default_backward_trains_alike():
     assert float(rel[:3].max()) <= 5e-3, f'steps 0 - 2: {rel[:3]}'
     assert float(rel[:20].max()) <= 4e-2, f'steps 0 - 19: worst {float(rel[:20].max()):.2e}'
     assert tail <= 0.6 * float(z['losses'][0]), (tail, tail_ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Round 6: class-accuracy parity of the BENCHED mode as an asserted fact.
+def _stable_fixture_runs(backward, seeds=None):
+    import json
+    import numpy as np
+    from tests._util import GOLDEN
+    z = np.load(f'{GOLDEN}/trained_stable_cfg1_small_v30_adam400.npz')
+    cfg = json.loads(str(z['cfg']))
+    kw = {k: cfg[k] for k in ('backbone', 'embed_layer', 'voxel_size', 'cell', 'patch', 'n_classes', 'pos_embedding', 'head')}
+    dk = dict(base=cfg['density_base'], step=cfg['density_step'])
+    data = [vo.synthetic_class_batch(cfg['batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=500 + i, **dk) for i in range(cfg['n_batches'])]
+    data = [(x.to(DEV), y.to(DEV)) for x, y in data]
+    xh, yh = vo.synthetic_class_batch(cfg['held_batch'], cfg['voxel_size'], cfg['cell'], cfg['labels'], seed=999, **dk)
+    assert np.array_equal(yh.numpy(), z['held_target'])
+    xh = xh.to(DEV)
+    T = cfg['tail']
+    out = []
+    for seed in (seeds or cfg['seeds']):
+        sd = vo.init_state_dict(seed=seed, exercise_all=False, portable=True, **kw)
+        eng = s3d.VoxelEngine(device=DEV, lr=cfg['lr'], backward=backward, **kw)
+        eng.load_state_dict(sd)
+        losses, accs = [], []
+        for step in range(cfg['steps']):
+            x, y = data[step % len(data)]
+            losses.append(eng.train_step(x, y).clone())
+            if step + 1 in cfg['checkpoints']:
+                accs.append(float((eng.forward(xh).argmax(1).cpu() == yh).float().mean()))
+        losses = torch.stack(losses).cpu().numpy().astype(np.float64)
+        ref = z[f'losses_{seed}']
+        rel = np.abs(losses - ref) / np.maximum(np.abs(ref), 1e-6)
+        out.append(dict(seed=seed, acc=float(np.mean(accs)), tail=float(np.median(losses[-T:])), rel=rel,
+                        ref_acc=float(z[f'held_acc_{seed}'].mean()), ref_tail=float(np.median(ref[-T:]))))
+    return cfg, out
+
+
+def test_benched_backward_reproduces_the_reference_trained_accuracy_and_final_loss():
+    """The mode bench.py times (plain-bf16 backward, non-deterministic launch structure) against the REFERENCE model trained by the reference's
+    own torch.optim.Adam in a stable regime (tests/golden/make_golden_trained.py stable: lr 3e-5 = the README recipe under its per-epoch
+    warm-up, 400 steps, 12 classes, 256 held-out samples at six checkpoints, TWELVE reference seeds; train_cls_voxel.py:195,277-288,315-329).
+    Per-seed outcomes are chaotic (the reference's own seeds spread by +-0.037 in accuracy; the same seed under two fp32 implementations
+    differs as much), so the criterion is distributional -- the reference's own seed-to-seed spread:
+      * every seed: the first 20 steps track the reference of that seed to 1e-3 (measured 1 - 3e-4), the first 100 to 0.2 (measured 7e-2);
+      * every seed's held-out accuracy inside [min - 2 sigma, max + 2 sigma] of the reference's twelve;
+      * the MEAN accuracy over the seeds within 3 standard errors of the difference of the reference's mean (~0.045);
+      * the geometric-mean final loss (median of the last 40 steps) within 3 standard errors (in log) of the reference's.
+    What sits behind the bars: 40 seeds per mode on an MI355X (profiles/r06_backward_precision_ablation.txt) -- accuracy 0.6738 +- 0.0059
+    (this mode), 0.6762 +- 0.0053 (split-precision backward), 0.6775 +- 0.0052 (deterministic mode), 0.6795 +- 0.0058 (the reference's
+    arithmetic in fp32): no mode is distinguishable from another."""
+    import numpy as np
+    cfg, runs = _stable_fixture_runs('bf16')
+    acc, ref_acc = np.array([r['acc'] for r in runs]), np.array([r['ref_acc'] for r in runs])
+    lt, ref_lt = np.log([r['tail'] for r in runs]), np.log([r['ref_tail'] for r in runs])
+    n = len(runs)
+    sig = float(ref_acc.std(ddof=1))
+    se_acc = float(np.sqrt(ref_acc.var(ddof=1) / n + acc.var(ddof=1) / n))
+    se_lt = float(np.sqrt(ref_lt.var(ddof=1) / n + lt.var(ddof=1) / n))
+    print(f'stable-regime fixture, benched backward, {n} seeds: held-out accuracy {acc.mean():.4f} (reference {ref_acc.mean():.4f}, its seed-to-seed '
+          f'sigma {sig:.3f}, range {ref_acc.min():.3f} .. {ref_acc.max():.3f}; ours {acc.min():.3f} .. {acc.max():.3f}); final loss geo-mean '
+          f'{np.exp(lt.mean()):.4f} (reference {np.exp(ref_lt.mean()):.4f}); steps 0-19 within {max(float(r["rel"][:20].max()) for r in runs):.1e}, '
+          f'0-99 within {max(float(r["rel"][:100].max()) for r in runs):.1e}')
+    assert n >= 12
+    for r in runs:
+        assert float(r['rel'][:20].max()) <= 1e-3, (r['seed'], float(r['rel'][:20].max()))
+        assert float(r['rel'][:100].max()) <= 0.2, (r['seed'], float(r['rel'][:100].max()))
+        assert ref_acc.min() - 2 * sig <= r['acc'] <= ref_acc.max() + 2 * sig, (r['seed'], r['acc'], ref_acc.min(), ref_acc.max(), sig)
+    assert abs(acc.mean() - ref_acc.mean()) <= 3 * se_acc, (acc.mean(), ref_acc.mean(), se_acc)
+    assert abs(lt.mean() - ref_lt.mean()) <= 3 * se_lt, (np.exp(lt.mean()), np.exp(ref_lt.mean()), se_lt)
+
+
+def test_split_backward_tracks_the_reference_seed_by_seed_on_the_stable_fixture():
+    """The gradient-parity mode (backward='split') on four of the fixture's seeds: here the trajectory itself is pinned -- the first 100 steps
+    within 2e-3 of the reference of that seed (measured <= 5e-4), the same distributional bars as above on the outcome."""
+    import numpy as np
+    cfg, runs = _stable_fixture_runs('split', seeds=[9, 11, 12, 13])
+    for r in runs:
+        assert float(r['rel'][:20].max()) <= 2e-5, (r['seed'], float(r['rel'][:20].max()))
+        assert float(r['rel'][:100].max()) <= 2e-3, (r['seed'], float(r['rel'][:100].max()))
+        assert abs(r['acc'] - r['ref_acc']) <= 0.12, (r['seed'], r['acc'], r['ref_acc'])
+    print('stable-regime fixture, split backward: ' + '; '.join(f'seed {r["seed"]}: steps 0-99 within {float(r["rel"][:100].max()):.1e}, accuracy {r["acc"]:.3f} '
+                                                               f'(reference {r["ref_acc"]:.3f})' for r in runs))

@@ -2,6 +2,7 @@
 all-reduce launched segment by segment during backward, 1/world averaging folded into the optimizer, and the
 DistributedSampler index rule.  The HIP engine is replaced by a tiny CPU stand-in that implements the same interface,
 so the test checks the DP protocol itself: two ranks on half batches == one process on the full batch."""
+import contextlib
 import os
 import socket
 
@@ -10,8 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from simple3d_former_amd.parallel import (BucketedGradReducer, DataParallelTrainer, PointDataParallelTrainer, broadcast_parameters,
-                                          shard_indices)
+from simple3d_former_amd.parallel import (BucketedGradReducer, DataParallelTrainer, PointDataParallelTrainer, ShardedDataParallelTrainer,
+                                          broadcast_parameters, shard_indices)
 
 
 class _Arena:
@@ -43,6 +44,11 @@ class FakeEngine:
         return flat[o:o + self.width ** 2].view(self.width, self.width)
 
     capture_epoch = 0
+
+    @contextlib.contextmanager
+    def owning_grads(self):                                     # VoxelEngine.owning_grads: the trainer's backward owns the gradient arena
+        self.owned_scopes = getattr(self, 'owned_scopes', 0) + 1
+        yield
 
     def refresh_weight_planes(self): pass
     def advance_dropout_seed(self): self.dropout_seed += 1
@@ -103,13 +109,20 @@ class FakeEngine:
         self.update_log.append('end')
 
 
+def _init_group(rank, world, port):
+    """gloo rendezvous through a file store (no port chosen ahead of time: no EADDRINUSE race between _free_port() and the bind)."""
+    import datetime
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f's3d_rdzv_{os.getppid()}_{port}')
+    dist.init_process_group('gloo', init_method=f'file://{path}', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 def _worker(rank, world, port, q, wire='fp32'):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_group(rank, world, port)
     try:
         torch.manual_seed(100)
         X = torch.randn(8, 8); Y = torch.randn(8, 8)            # global batch, identical on every rank
@@ -235,8 +248,7 @@ class FakePointEngine(FakeEngine):
 
 
 def _point_worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    _init_group(rank, world, port)
     try:
         torch.manual_seed(100)
         X = torch.randn(8, 8); Y = torch.randn(8, 8)
@@ -319,3 +331,174 @@ def test_reducer_is_a_noop_without_process_group():
     with pytest.raises(AssertionError):
         BucketedGradReducer(flat, [(5, 8), (0, 4)])
     broadcast_parameters(flat)                                   # no group -> no-op
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the sharded optimizer (reduce-scatter -> Adam on the local shard -> all-gather overlapped with the next forward)
+class FakeShardedEngine(FakeEngine):
+    """FakeEngine + the phase interface ShardedDataParallelTrainer drives (VoxelEngine.forward_tokens / forward_blocks / forward_tail /
+    loss_of_features / backward_begin / backward_segment / owning_grads / refresh_planes_range) and an optimizer WITH state (momentum), so
+    that a shard updated from stale or foreign state would show."""
+
+    def __init__(self, depth=6, width=8, seed=0):
+        super().__init__(depth, width, seed)
+        self.planes = self.arena.p.clone()                      # "hi / lo planes": what the forward reads (must be refreshed after a gather)
+        self.plane_log = []
+        self.update_log = []
+        self.ws = type('WS', (), {})()
+        self.ws.loss = torch.zeros(2)
+
+    def W(self, i, flat=None):
+        flat = self.planes if flat is None else flat             # the forward GEMMs read the planes, never the fp32 master
+        return FakeEngine.W(self, i, flat)
+
+    def refresh_weight_planes(self): self.planes.copy_(self.arena.p)
+    def refresh_planes_range(self, s, e):
+        self.planes[s:e] = self.arena.p[s:e]
+        self.plane_log.append((s, e))
+    def workspace(self, B): return self.ws
+    def grad_buckets(self, n=3, blocks_per_bucket=None, block_counts=None):
+        from simple3d_former_amd.engine import VoxelEngine
+        return VoxelEngine.grad_buckets(self, n, blocks_per_bucket, block_counts)
+
+    def forward_tokens(self, x):
+        self.acts = [x]
+        return self.ws
+
+    def forward_blocks(self, ws, first, last):
+        assert len(self.acts) == first + 1, 'forward ranges out of order'
+        for i in range(first, last + 1):
+            self.acts.append(torch.tanh(self.acts[-1] @ self.W(i).t()))
+
+    def forward_tail(self, ws): return ws
+
+    def loss_of_features(self, B, y, weight=None):
+        self.ws.loss[0] = self.cross_entropy(B, y, weight)
+        return self.ws.loss[0]
+
+    def backward_begin(self, B):
+        self._d = self.dout
+        return self.ws
+
+    def backward_segment(self, ws, first, last, with_tokenizer):
+        d = self._d
+        for i in range(first, last - 1, -1):
+            d = d * (1 - self.acts[i + 1] ** 2)
+            FakeEngine.W(self, i, self.arena.g).add_(d.t() @ self.acts[i])
+            d = d @ self.W(i)
+        self._d = d
+
+    def backward(self, B, segments=None, on_segment=None):       # (the replicated trainer's eager path)
+        self.backward_begin(B)
+        for si, (first, last) in enumerate(segments):
+            self.backward_segment(self.ws, first, last, si == len(segments) - 1)
+            if on_segment:
+                on_segment(si)
+
+    def adam_apply(self, start, end, zero_grad=True, max_workgroups=0, wire=None):
+        m = self.arena.m[start:end]
+        m.mul_(0.9).add_(self.arena.g[start:end], alpha=self.grad_scale)
+        self.arena.p[start:end].add_(m, alpha=-self.lr)
+        self.planes[start:end] = self.arena.p[start:end]        # (the real kernel refreshes the planes of what it updates)
+        if zero_grad:
+            self.arena.g[start:end].zero_()
+        self.update_log.append((start, end))
+
+    def adam_step(self, zero_grad=True, wire=None):
+        self.update_log = getattr(self, 'update_log', [])
+        self.adam_apply(0, self.arena.numel, zero_grad)
+
+
+def _sharded_worker(rank, world, port, q, sharded):
+    _init_group(rank, world, port)
+    try:
+        torch.manual_seed(100)
+        X = torch.randn(8, 8); Y = torch.randn(8, 8)
+        eng = FakeShardedEngine(seed=rank)                       # different initial parameters per rank: the broadcast must fix it
+        eng.lr = 0.05
+        if sharded:
+            tr = ShardedDataParallelTrainer(eng, bucket_blocks=[2, 2, 1, 1], use_graphs=False)
+            assert tr.segments == [(5, 4), (3, 2), (1, 1), (0, 0)] and tr.fwd_ranges == [(0, 0), (1, 1), (2, 3), (4, 5)]
+            assert tr.slices == [(256, 384), (128, 256), (64, 128), (0, 64)]
+            assert tr.shards == [(s + rank * (e - s) // 2, s + (rank + 1) * (e - s) // 2) for s, e in tr.slices] and eng.grad_scale == 0.5
+        else:
+            tr = DataParallelTrainer(eng, n_buckets=3, use_graphs=False)
+        sl = slice(rank * 4, rank * 4 + 4)
+        losses = []
+        for _ in range(4):
+            losses.append(float(tr.step_eager(X[sl], Y[sl])))
+        stale = None
+        if sharded:
+            # gather-pending: this rank holds the new values of its OWN shards only ...
+            assert tr.pending
+            stale = eng.arena.p.clone()
+            sd = tr.state_dict if False else None
+            tr.sync_parameters()                                 # ... until the gather phase has run
+            assert not tr.pending
+            # every step: Adam ran on this rank's shards only, in bucket order; the planes of every bucket were refreshed after its gather
+            per_step = ['begin'] + [tuple(s_) for s_ in tr.shards]
+            assert [u for u in eng.update_log if u != 'end'] == per_step * 4, eng.update_log
+            assert eng.plane_log[:4] == [tuple(s_) for s_ in reversed(tr.slices)]
+            assert torch.equal(eng.planes, eng.arena.p)
+            # the optimizer state exists for the shards only: m outside them was never touched
+            mask = torch.zeros(eng.arena.numel, dtype=torch.bool)
+            for a, b in tr.shards:
+                mask[a:b] = True
+            assert not eng.arena.m[~mask].any() and eng.arena.m[mask].any()
+            assert not eng.arena.g.any()                          # the whole gradient arena is zero again (own shard by Adam, the rest by the scatter)
+        q.put((rank, eng.arena.p.clone(), losses, stale))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_two(target, *args):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_sharded_optimizer_two_ranks_bitwise_equal_the_replicated_trainer():
+    """ShardedDataParallelTrainer on two ranks: replicas bitwise equal to each other AND to DataParallelTrainer's (all-reduce + replicated
+    update) on the same two ranks -- same summed gradient, same update element by element -- and within fp32 rounding of one process on the
+    full batch.  Before sync_parameters() a rank's copy of the OTHER rank's shards is one step stale."""
+    sh = _run_two(_sharded_worker, True)
+    rep = _run_two(_sharded_worker, False)
+    assert torch.equal(sh[0][1], sh[1][1]), 'sharded replicas diverged'
+    assert torch.equal(rep[0][1], rep[1][1]), 'replicated replicas diverged'
+    assert torch.equal(sh[0][1], rep[0][1]), 'sharded update != replicated update'
+    assert sh[0][2] != sh[1][2] and sh[0][2] == rep[0][2] and sh[1][2] == rep[1][2]       # per-rank losses of per-rank half batches, same in both designs
+    assert not torch.equal(sh[0][3], sh[0][1]) and not torch.equal(sh[0][3], sh[1][3])   # gather-pending state differs per rank and from the result
+    torch.manual_seed(100)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    ref = FakeShardedEngine(seed=0)
+    ref.lr = 0.05
+    segs, _ = ref.grad_buckets(1)
+    for _ in range(4):
+        ref.forward_tokens(X); ref.forward_blocks(ref.ws, 0, 5); ref.cross_entropy(8, Y); ref.backward(8, segments=segs); ref.adam_step()
+    assert float((sh[0][1] - ref.arena.p).abs().max()) < 1e-6, 'sharded DP on two half batches != one process on the full batch'
+
+
+def test_sharded_trainer_one_rank_equals_the_plain_step():
+    """world size 1, no process group: every collective is a no-op, a shard is the whole bucket -- the step IS forward / backward / update."""
+    torch.manual_seed(7)
+    X = torch.randn(8, 8); Y = torch.randn(8, 8)
+    eng = FakeShardedEngine(seed=3)
+    tr = ShardedDataParallelTrainer(eng, bucket_blocks=[3, 2, 1], use_graphs=False)
+    assert tr.world == 1 and tr.shards == tr.slices and 'none' in tr.collectives_mode()
+    ref = FakeShardedEngine(seed=3)
+    segs, _ = ref.grad_buckets(1)
+    for _ in range(3):
+        tr.step_eager(X, Y)
+        ref.forward_tokens(X); ref.forward_blocks(ref.ws, 0, 5); ref.cross_entropy(8, Y); ref.backward(8, segments=segs); ref.adam_step()
+    tr.sync_parameters()
+    assert torch.equal(eng.arena.p, ref.arena.p) and torch.equal(eng.arena.m, ref.arena.m)
+    with pytest.raises(AssertionError):
+        ShardedDataParallelTrainer(FakeShardedEngine(seed=1), bucket_blocks=[4, 1], use_graphs=False)      # counts must sum to the depth

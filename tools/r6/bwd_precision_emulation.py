@@ -117,18 +117,23 @@ def main():
     modes = (sys.argv[1] if len(sys.argv) > 1 else 'bbb,bsb,sbs,sss').split(',')
     z = np.load(os.path.join(ROOT, 'tests', 'golden', 'trained_stable_cfg1_small_v30_adam400.npz'))
     cfg = json.loads(str(z['cfg']))
+    if os.environ.get('FIXTURE') == 'adam60':      # round 5's unstable-regime fixture (Adam lr 1e-3 from the initialisation, 60 steps), more seeds
+        cfg.update(steps=60, lr=1e-3, n_batches=4, labels=cfg['labels'][:9], density_base=0.04, density_step=0.07, held_batch=256, checkpoints=[40, 50, 60], tail=10)
     seeds = [int(s) for s in sys.argv[2].split(',')] if len(sys.argv) > 2 else cfg['seeds']
+    if os.environ.get('SEEDS'):
+        a, b = os.environ['SEEDS'].split('-')
+        seeds = list(range(int(a), int(b) + 1))
     T = cfg['tail']
     for mode in modes:
         accs, tails = [], []
         for s in seeds:
             t0 = time.time()
             l, a = run(cfg, s, mode)
-            ref = z[f'losses_{s}']
+            ref = z[f'losses_{s}'][:cfg['steps']] if f'losses_{s}' in z.files else l
             rel = np.abs(l - ref) / np.maximum(np.abs(ref), 1e-6)
             accs.append(a.mean()); tails.append(np.median(l[-T:]))
             print(f'  {mode} seed {s}: held-out accuracy {a.mean():.3f} ({" ".join(f"{v:.3f}" for v in a)}) tail loss median {np.median(l[-T:]):.4f}; vs reference: steps 0-19 {rel[:20].max():.1e}, 0-99 {rel[:100].max():.1e} [{time.time() - t0:.0f} s]', flush=True)
-        print(f'{mode}: accuracy {min(accs):.3f} .. {max(accs):.3f} (mean {np.mean(accs):.3f}); tail median geo-mean {np.exp(np.mean(np.log(tails))):.4f}', flush=True)
+        print(f'{mode}: accuracy {min(accs):.3f} .. {max(accs):.3f} (mean {np.mean(accs):.4f} +- {np.std(accs, ddof=1) / np.sqrt(len(accs)):.4f}, std {np.std(accs, ddof=1):.3f}, n {len(accs)}); tail median geo-mean {np.exp(np.mean(np.log(tails))):.4f}', flush=True)
 
 
 if __name__ == '__main__':
