@@ -393,6 +393,9 @@ int s3d_stream_wait_event(s3d_stream_t waiting_stream, void* event);
 /* NOT part of the operator ABI -- measurement aid: copies nbytes (16-byte multiple) with 16 workgroups paced to gbps GB/s (a stand-in
  * with the duration and footprint of a ring all-reduce on one GPU; simple3d-former_amd/parallel.py, profiles/r05_dp_branch_tax.txt). */
 int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t stream);
+/* NOT part of the operator ABI -- same-process A/B of dispatch alternatives (tools/r6/attn_ab.py): knob ids are private to the library's
+ * launchers (0 .. 15), value -1 restores the shipped rule.  The shipped rules quote the measurements these knobs produced. */
+int s3d_debug_knob(int id, int value);
 
 /* ------------------------------------------------------------------------------------------------ timm Block
  * One pre-norm transformer block: x += attn(norm1(x)); x += mlp(norm2(x))  (timm==0.3.2 Block.forward, invoked by

@@ -14,6 +14,7 @@
 #include "attention.h"
 #include "adam_fill.h"
 #include "attn_frag.h"
+#include "dma_tile.h"
 
 #include <stdint.h>
 #include <stdlib.h>
@@ -540,11 +541,29 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+        if constexpr (HD >= 192) {   // fragments of k-step s + 1 are read before the MFMAs of step s (round 6, see attn_bwd_dq_coop_kernel)
+            bf16x8 qf2[2], of2[2];
+            qf2[0] = *reinterpret_cast<const bf16x8*>(ldsQ + l31 * PITCH + h2 * 8);
+            of2[0] = *reinterpret_cast<const bf16x8*>(ldsDO + l31 * PITCH + h2 * 8);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int off = l31 * PITCH + 16 * s + h2 * 8;
-            sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsQ + off), kf[s], sacc);      // S  = Q . K^T   (col = key)
-            dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsDO + off), vf[s], dpacc);   // dP = dO . V^T
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) {
+                    const int off = l31 * PITCH + 16 * (s + 1) + h2 * 8;
+                    qf2[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsQ + off);
+                    of2[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsDO + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sacc = MFMA32(qf2[s & 1], kf[s], sacc);                                       // S  = Q . K^T   (col = key)
+                dpacc = MFMA32(of2[s & 1], vf[s], dpacc);                                     // dP = dO . V^T
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int off = l31 * PITCH + 16 * s + h2 * 8;
+                sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsQ + off), kf[s], sacc);
+                dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsDO + off), vf[s], dpacc);
+            }
         }
         // lse / delta of the 16 query rows this lane's accumulator registers belong to: rows come in four runs of four consecutive
         // ones (acc_row) -> eight 16-byte LDS reads instead of 32 scalar ones; the two bf16 operands are converted in pairs
@@ -598,15 +617,34 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                     dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
                 }
         }
+        if constexpr (HD % 32 == 0 && NDB >= 2 && HD >= 192) {
+            // the transposed dO / Q fragments of d-block d + 1 are in flight during block d's four MFMAs
+            Frag2x2 fr[2];
+            gather_issue_2x2<HD, PITCH>(ldsDO, dblk0 * 32 + l31, ldsQ, dblk0 * 32 + l31, h2, fr[0]);
 #pragma unroll
-        for (int d = 0; d < NDB; ++d) {
-            const int col = (dblk0 + d) * 32 + l31;
-            bf16x8 fo[2], fq[2];
-            gather_frag_2x2<HD, PITCH>(ldsDO, col, ldsQ, col, h2, fo, fq);
+            for (int d = 0; d < NDB; ++d) {
+                bf16x8 fo[2], fq[2];
+                gather_wait(fr[d & 1], fo, fq);
+                if (d + 1 < NDB) gather_issue_2x2<HD, PITCH>(ldsDO, (dblk0 + d + 1) * 32 + l31, ldsQ, (dblk0 + d + 1) * 32 + l31, h2, fr[(d + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
-                dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
+                    dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < NDB; ++d) {
+                const int col = (dblk0 + d) * 32 + l31;
+                bf16x8 fo[2], fq[2];
+                gather_frag_2x2<HD, PITCH>(ldsDO, col, ldsQ, col, h2, fo, fq);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
+                    dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
+                }
             }
         }
         if (more) lstore((qt + 1) & 1);
@@ -667,7 +705,10 @@ struct CoopStage {                                                     // NT_ ti
 
 // NWV waves per workgroup (4 or 8): with eight, two waves share every SIMD and one's softmax / mask VALU phase runs beside the
 // other's MFMAs (the LDS stream and its footprint stay the same; twice the query rows per workgroup)
-template <int HD, bool SPLIT, int NWV = 4, bool DROP = true>
+// NBUF = 1 (round 6, hd = 192 split): ONE LDS buffer of the key stream (51 KB instead of 102) so that TWO workgroups share a CU -- two waves
+// per SIMD from different workgroups, one's softmax / mask VALU phase beside the other's MFMAs (the tile in flight waits in registers as
+// before; the price is a second barrier per key tile, paid while the other workgroup computes).
+template <int HD, bool SPLIT, int NWV = 4, bool DROP = true, int NBUF = 2>
 __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32, NPL = SPLIT ? 2 : 1;
@@ -724,7 +765,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
         const int k0 = kt * 32;
         const bool more = kt + 1 < KT;
         if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
-        const bf16_t* tb = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
+        const bf16_t* tb = reinterpret_cast<const bf16_t*>(smem + (NBUF == 2 ? (kt & 1) : 0) * ST::BUF_BYTES);
         const bf16_t* ldsKh = tb;
         const bf16_t* ldsKl = tb + TILE;                               // split only
         const bf16_t* ldsVh = tb + NPL * TILE;
@@ -810,7 +851,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
                 o[d] = MFMA32(vh[s2], ph[s2].v, o[d]);
             }
         }
-        if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
+        if constexpr (NBUF == 1) __syncthreads();                     // every wave is done reading the only buffer
+        if (more) st.lstore(smem + (NBUF == 2 ? ((kt + 1) & 1) : 0) * ST::BUF_BYTES, tid);
         __syncthreads();
     }
     if (active && qok) {
@@ -830,6 +872,297 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
                 if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
             }
         if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i * 0.6931471805599453f + logf(l_i);      // m_i is in log2 units
+    }
+}
+
+// Round 6: the split forward of the long sequences, SOFTWARE-PIPELINED.  attn_fwd_coop_kernel's key tile is S MFMAs -> softmax / mask VALU ->
+// P V MFMAs in program order, and at hd = 192 a wave holds 430+ registers (Q hi + lo fragments 96, the output tile 96, staging 48 ...): ONE
+// wave per SIMD, so nothing runs beside anything -- per key tile ~2300 MFMA cycles + ~2500 VALU cycles back to back (ISA count: 72 MFMAs,
+// 590 VALU instructions; 27 ms per launch at cfg-3).  Here the scores of tile t + 1 are issued INSIDE the softmax of tile t: one branch-free
+// region holds 36 independent MFMAs and the ~330 VALU instructions of max / exp2 / sum / dropout hash / mask word / bf16 split, which hipcc's
+// scheduler interleaves (the matrix pipe runs while the wave issues VALU).  What that needs:
+//   * K and V rings decoupled: K(t + 1) is read during tile t's softmax, V(t) after it -- two K buffers and two V buffers (the same 102 KB),
+//     K(t + 2) and V(t + 1) wait in registers, one barrier per tile as before;
+//   * no branch between the first score MFMA and the last probability: the ragged last key tile is a peeled instantiation of the body, the
+//     mask-word store is unconditional (duplicate lanes / clamped waves store identical words), DROP means drop_thr != 0;
+//   * the (rare) rescale of the running output stays a wave-uniform branch, between the region and the P V MFMAs.
+template <int HD, bool DROP, bool MASKOUT, int ABL = 0>      // ABL: timing ablations (s3d_debug_knob 1; results wrong), 0 = the product
+__global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
+    constexpr int PITCH = HD + 8;
+    using ST = CoopStage<HD, 4, 256>;                                  // staging registers: K_hi K_lo (tile t + 2), V_hi V_lo (tile t + 1)
+    constexpr int TILE = ST::TILE, PLANE = TILE * 2;                   // bytes of one [32][PITCH] plane
+    constexpr int KBUF = 2 * PLANE;                                    // bytes of one K buffer (hi + lo) = of one V buffer
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h2 = lane >> 5, l31 = lane & 31;
+    const int QT = (p.N + 31) / 32, QTB = (QT + 3) / 4;
+    const int bh = blockIdx.x / QTB;
+    int qt = (blockIdx.x % QTB) * 4 + wave;
+    const bool active = qt < QT;
+    qt = min(qt, QT - 1);
+    const int h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int q0 = qt * 32, qrow = q0 + l31;
+    const bool qok = qrow < p.N;
+    const int qrow_c = min(qrow, p.N - 1);
+    const unsigned long long dkey = DROP ? drop_key(p.drop_seed, p.drop_site) : 0ull;
+    const DropRow drow = drop_row(dkey, ((unsigned long long)bh * p.N + qrow_c) * p.N);
+    bf16x8 qh[NS], ql[NS];
+    {
+        const long off = base + (long)qrow_c * st_ld + h2 * 8;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { qh[s] = ld_frag(p.qkv_hi + off + 16 * s); ql[s] = ld_frag(p.qkv_lo + off + 16 * s); }
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;
+    const int KT = (p.N + 31) / 32;
+    // LDS: [K ring: 2 x (hi, lo)] [V ring: 2 x (hi, lo)]
+    unsigned char* kring = smem;
+    unsigned char* vring = smem + 2 * KBUF;
+    const long koff = base + (long)p.D, voff = base + 2 * (long)p.D;
+
+    // staging: chunk c of a [32][HD] tile -> (row, 16-byte column); K planes from key tile tk, V planes from key tile tv.  (LDS-DMA instead of
+    // registers was built and measured: 23.3 ms per cfg-3 launch with the thirteen 1 KB pieces per wave issued together, 24.5 ms with one
+    // piece behind the first MFMA of every k-step, against 22.4 ms here -- a wave sits in the issue stage for every piece, MFMA shadow or not.)
+    u32x4 rk[2][ST::NCH], rv[2][ST::NCH];
+    auto gload = [&](int tk, int tv) {
+#pragma unroll
+        for (int i = 0; i < ST::NCH; ++i) {
+            const int c = min(tid + 256 * i, 32 * ST::CPR - 1);
+            const int row = c / ST::CPR, cc = c % ST::CPR;
+            const long rowk = min(tk * 32 + row, p.N - 1), rowv = min(tv * 32 + row, p.N - 1);
+            rk[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + koff + rowk * st_ld + cc * 8);
+            rk[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + koff + rowk * st_ld + cc * 8);
+            rv[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + voff + rowv * st_ld + cc * 8);
+            rv[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + voff + rowv * st_ld + cc * 8);
+        }
+    };
+    auto lstore = [&](const u32x4 (&r)[2][ST::NCH], unsigned char* buf) {
+        bf16_t* bp = reinterpret_cast<bf16_t*>(buf);
+#pragma unroll
+        for (int i = 0; i < ST::NCH; ++i) {
+            const int c = tid + 256 * i;
+            if (32 * ST::CPR % 256 == 0 || c < 32 * ST::CPR) {
+                const int row = c / ST::CPR, cc = c % ST::CPR;
+                *reinterpret_cast<u32x4*>(bp + row * PITCH + cc * 8) = r[0][i];
+                *reinterpret_cast<u32x4*>(bp + TILE + row * PITCH + cc * 8) = r[1][i];
+            }
+        }
+    };
+    auto scores = [&](const unsigned char* kb, f32x16& acc) {           // S^T = K Q^T, three MFMAs per product
+        const bf16_t* ldsKh = reinterpret_cast<const bf16_t*>(kb);
+        const bf16_t* ldsKl = ldsKh + PLANE / 2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int off = l31 * PITCH + 16 * s + h2 * 8;
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(ldsKh + off);
+            const bf16x8 kl = *reinterpret_cast<const bf16x8*>(ldsKl + off);
+            acc = MFMA32(kl, qh[s], acc);
+            acc = MFMA32(kh, ql[s], acc);
+            acc = MFMA32(kh, qh[s], acc);
+        }
+    };
+
+    // prologue: K(0), V(0), K(1) in LDS; S(0) in registers; K(2), V(1) on their way
+    gload(0, 0);
+    lstore(rk, kring); lstore(rv, vring);
+    gload(1, 1);
+    lstore(rk, kring + KBUF);
+    __syncthreads();
+    f32x16 scur, snext;
+    scores(kring, scur);
+    gload(2, 1);
+    uint32_t zz[8], zh[2];                                             // dropout hashes of the CURRENT tile's key pairs (computed one tile ahead)
+    if constexpr (DROP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) zz[j] = drop_hash_at(drow, (uint32_t)acc_row(2 * j, h2));
+    }
+
+    auto body = [&](int kt, auto ragged_tag, auto more_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value, MORE = decltype(more_tag)::value;
+        const int k0 = kt * 32;
+        // ---- region 1 (branch-free): the 36 score MFMAs of tile kt + 1, each followed by ONE slot of tile kt's softmax / mask work.
+        // hipcc's scheduler does not interleave the two by itself (it clusters the MFMAs in front of the VALU, and an in-order wave
+        // sits out every MFMA's 8 passes before the next one issues -- measured, also with sched_group_barrier templates), so the order
+        // is written out and pinned with sched_barrier(0): MFMA, ~8 VALU instructions (= its 32 cycles), MFMA, ...
+        float sv[16], mloc = -INFINITY, mnew = m_i, alpha = 1.f, lsum = 0.f, nmn = 0.f;
+        const float mold = m_i;
+        uint32_t wb = 0u;
+        U128 ph[2], pl[2];
+        if (ABL == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { ph[0].w[q] = ph[1].w[q] = 0x3f803f80u; pl[0].w[q] = pl[1].w[q] = 0u; }
+        }
+        if constexpr (RAGGED) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (k0 + acc_row(r, h2) >= p.N) scur[r] = -INFINITY;
+        }
+        auto slot = [&](auto jt) {
+            constexpr int J = decltype(jt)::value;
+            if constexpr (J < 2) {                                    // row maximum, two halves
+                constexpr int r0 = J * 8;
+#pragma unroll
+                for (int r = r0; r < r0 + 8; ++r) mloc = fmaxf(mloc, scur[r]);
+            } else if constexpr (J == 2) {
+                mloc = half_max(mloc) * sc2;
+                mnew = fmaxf(m_i, mloc);
+                alpha = __builtin_amdgcn_exp2f(m_i - mnew);
+                nmn = -mnew;
+            } else if constexpr (J < 19) {                            // one probability per slot
+                constexpr int r0 = J - 3;
+                sv[r0] = __builtin_amdgcn_exp2f(fmaf(scur[r0], sc2, nmn));
+                lsum += sv[r0];
+            } else if constexpr (J == 19) {
+                lsum = half_sum(lsum);
+                l_i = l_i * alpha + lsum;
+                m_i = mnew;
+            } else if constexpr (J < 28) {                            // keep decisions of pair J - 20 (hash zz[] computed beside the previous
+                if constexpr (DROP) {                                 // tile's P V MFMAs): probabilities, mask bits
+                    constexpr int r = (J - 20) * 2;
+                    const bool keep0 = drop_half(zz[J - 20], 0u, p.drop_thr), keep1 = drop_half(zz[J - 20], 1u, p.drop_thr);
+                    sv[r] = keep0 ? sv[r] : 0.f;
+                    sv[r + 1] = keep1 ? sv[r + 1] : 0.f;
+                    wb |= (keep0 ? (1u << acc_row(r, 0)) : 0u) | (keep1 ? (1u << acc_row(r + 1, 0)) : 0u);
+                }
+            } else {                                                  // J = 28 .. 35: bf16 hi / lo of pair J - 28
+                constexpr int q = J - 28, s2 = q / 4, j = (q % 4) * 2;
+                split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
+            }
+        };
+        if constexpr (MORE) {
+            const bf16_t* ldsKh = reinterpret_cast<const bf16_t*>(kring + ((kt + 1) & 1) * KBUF);
+            const bf16_t* ldsKl = ldsKh + PLANE / 2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) snext[r] = 0.f;
+            bf16x8 kfh[2], kfl[2];                                     // K fragments of k-step S in [S & 1]: read one step ahead
+            kfh[0] = *reinterpret_cast<const bf16x8*>(ldsKh + l31 * PITCH + h2 * 8);
+            kfl[0] = *reinterpret_cast<const bf16x8*>(ldsKl + l31 * PITCH + h2 * 8);
+            auto kstep = [&](auto st) {
+                constexpr int S = decltype(st)::value;
+                if constexpr (S + 1 < NS) {                           // the next step's fragments are in flight while this step's MFMAs run
+                    const int off = l31 * PITCH + 16 * (S + 1) + h2 * 8;
+                    kfh[(S + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsKh + off);
+                    kfl[(S + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsKl + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 kh = kfh[S & 1], kl = kfl[S & 1];
+                if (ABL != 3) snext = MFMA32(kl, qh[S], snext);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 1) slot(std::integral_constant<int, 3 * S>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 3) snext = MFMA32(kh, ql[S], snext);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 1) slot(std::integral_constant<int, 3 * S + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 3) snext = MFMA32(kh, qh[S], snext);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 1) slot(std::integral_constant<int, 3 * S + 2>{});
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            kstep(std::integral_constant<int, 0>{}); kstep(std::integral_constant<int, 1>{}); kstep(std::integral_constant<int, 2>{});
+            kstep(std::integral_constant<int, 3>{}); kstep(std::integral_constant<int, 4>{}); kstep(std::integral_constant<int, 5>{});
+            kstep(std::integral_constant<int, 6>{}); kstep(std::integral_constant<int, 7>{}); kstep(std::integral_constant<int, 8>{});
+            kstep(std::integral_constant<int, 9>{}); kstep(std::integral_constant<int, 10>{}); kstep(std::integral_constant<int, 11>{});
+            static_assert(NS == 12, "the slot table is written for hd = 192 (12 k-steps of three MFMAs)");
+        } else {
+            [&]<int... Js>(std::integer_sequence<int, Js...>) { (slot(std::integral_constant<int, Js>{}), ...); }(std::make_integer_sequence<int, 36>{});
+        }
+        if constexpr (DROP && MASKOUT) {
+            wb <<= 4 * h2;
+            const auto pr = __builtin_amdgcn_permlane32_swap(wb, wb, false, false);
+            // every lane stores: the two half-waves (and a clamped, inactive wave) write the SAME word to the same address
+            p.drop_mask[(((long)bh * QT + qt) * KT + kt) * 32 + l31] = pr[0] | pr[1];
+        }
+        // ---- rescale of the running output (wave-uniform, rare after the first key tiles)
+        if (__builtin_amdgcn_ballot_w64(mnew != mold) != 0ull) {
+            asm volatile("" ::: "memory");                          // (keeps the branch: hipcc otherwise speculates the 96 multiplies -- through
+            //                                                         AGPR reads and writes, 240 instructions -- into every tile)
+#pragma unroll
+            for (int d = 0; d < NDB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
+        // ---- region 2: O^T += V^T P^T
+        const bf16_t* ldsVh = reinterpret_cast<const bf16_t*>(vring + (kt & 1) * KBUF);
+        const bf16_t* ldsVl = ldsVh + PLANE / 2;
+        Frag2x2 vf[2];                                                 // V fragments of d-block d in [d & 1]: read one block ahead
+        gather_issue_2x2<HD, PITCH>(ldsVh, l31, ldsVl, l31, h2, vf[0]);
+#pragma unroll
+        for (int d = 0; d < NDB; ++d) {
+            bf16x8 vh[2], vl[2];
+            gather_wait(vf[d & 1], vh, vl);
+            if (d + 1 < NDB) gather_issue_2x2<HD, PITCH>(ldsVh, (d + 1) * 32 + l31, ldsVl, (d + 1) * 32 + l31, h2, vf[(d + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);                        // (the six MFMAs stay between this block's reads and the next wait)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // the dropout hash of the NEXT tile's key pair 2 d + s2 in the shadow of this block's MFMAs (it depends on nothing here):
+                // drop_hash_at() in two halves, one behind each of the first two MFMAs
+                const int hj = 2 * d + s2;
+                if (ABL != 2) o[d] = MFMA32(vl[s2], ph[s2].v, o[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (DROP && MORE && hj < 8) {
+                    const uint32_t lo = drow.lo + (uint32_t)(k0 + 32 + acc_row(2 * hj, h2));
+                    uint32_t x = (lo ^ drow.kx) + (lo < drow.lo ? drow.mix_b : drow.mix_a);
+                    x ^= x >> 16; x *= 0x21f0aaadu;
+                    zh[s2] = x;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 2) o[d] = MFMA32(vh[s2], pl[s2].v, o[d]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (DROP && MORE && hj < 8) {
+                    uint32_t x = zh[s2];
+                    x ^= x >> 15; x *= 0x735a2d97u; x ^= x >> 15;
+                    zz[hj] = x;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (ABL != 2) o[d] = MFMA32(vh[s2], ph[s2].v, o[d]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (MORE) {
+            // K(kt + 2) -> the K buffer tile kt used (read last in iteration kt - 1); V(kt + 1) -> the V buffer tile kt - 1 used
+            if (ABL != 4) {
+                lstore(rk, kring + (kt & 1) * KBUF);
+                lstore(rv, vring + ((kt + 1) & 1) * KBUF);
+                gload(kt + 3, kt + 2);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scur[r] = snext[r];
+        }
+        __syncthreads();
+    };
+    const bool ragged = (p.N & 31) != 0;
+    for (int kt = 0; kt + 1 < KT; ++kt) body(kt, std::false_type{}, std::true_type{});
+    if (ragged) body(KT - 1, std::true_type{}, std::false_type{});
+    else body(KT - 1, std::false_type{}, std::false_type{});
+
+    if (active && qok) {
+        const float inv = (DROP ? p.drop_scale : 1.0f) / l_i;
+        const long orow = ((long)b * p.sb + (long)qrow * p.st) * p.ldo + h * HD;
+#pragma unroll
+        for (int d = 0; d < NDB; ++d)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                union { uint2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) split_bf16(o[d][4 * c + i] * inv, hi.h[i], lo.h[i]);
+                const int dcol = d * 32 + 8 * c + 4 * h2;
+                if (HD % 32 != 0 && dcol >= HD) continue;
+                const long off = orow + dcol;
+                *reinterpret_cast<uint2*>(p.out_hi + off) = hi.u;
+                if (p.out_lo) *reinterpret_cast<uint2*>(p.out_lo + off) = lo.u;
+            }
+        if (h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i * 0.6931471805599453f + logf(l_i);
     }
 }
 
@@ -910,11 +1243,31 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+        if constexpr (HD >= 192) {   // fragments of k-step s + 1 are read before the MFMAs of step s (round 6: hipcc waits for every pair right in
+            // front of its MFMAs, and one wave per SIMD has nothing else to run during an LDS round trip -- 2 x 12 of them per key tile; the
+            // hd = 64 kernels of the point path run three / two waves per SIMD and keep their register counts)
+            bf16x8 kf[2], vf2[2];
+            kf[0] = *reinterpret_cast<const bf16x8*>(ldsK + l31 * PITCH + h2 * 8);
+            vf2[0] = *reinterpret_cast<const bf16x8*>(ldsV + l31 * PITCH + h2 * 8);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int off = l31 * PITCH + 16 * s + h2 * 8;
-            sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsK + off), qf[s], sacc);      // S^T  = K . Q^T
-            dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsV + off), dof[s], dpacc);   // dP^T = V . dO^T
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) {
+                    const int off = l31 * PITCH + 16 * (s + 1) + h2 * 8;
+                    kf[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsK + off);
+                    vf2[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsV + off);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                sacc = MFMA32(kf[s & 1], qf[s], sacc);                                        // S^T  = K . Q^T
+                dpacc = MFMA32(vf2[s & 1], dof[s], dpacc);                                    // dP^T = V . dO^T
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int off = l31 * PITCH + 16 * s + h2 * 8;
+                sacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsK + off), qf[s], sacc);
+                dpacc = MFMA32(*reinterpret_cast<const bf16x8*>(ldsV + off), dof[s], dpacc);
+            }
         }
         U128 dsf[2];
         auto ds_tile = [&](auto from_mask) {                           // the mask from the stored bits (block-uniform choice) or from the hash
@@ -938,15 +1291,34 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
                 }
         };
         ds_tile(std::integral_constant<bool, MASK>{});
+        if constexpr (NDB % 2 == 0 && HD % 32 == 0 && HD >= 192) {
+            // dQ^T = K^T . dS^T, two d-blocks per step; the transposed K fragments of the NEXT pair are in flight during this pair's MFMAs
+            Frag2x2 kq[2];
+            gather_issue_2x2<HD, PITCH>(ldsK, l31, ldsK, 32 + l31, h2, kq[0]);
 #pragma unroll
-        for (int d = 0; d < NDB; d += 2) {
-            bf16x8 k0[2], k1[2];
-            if (d + 1 < NDB) gather_frag_2x2<HD, PITCH>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0, k1);
-            else gather_frag_s2<HD, PITCH>(ldsK, h2, d * 32 + l31, k0);
+            for (int d = 0; d < NDB; d += 2) {
+                bf16x8 k0[2], k1[2];
+                gather_wait(kq[(d >> 1) & 1], k0, k1);
+                if (d + 2 < NDB) gather_issue_2x2<HD, PITCH>(ldsK, (d + 2) * 32 + l31, ldsK, (d + 3) * 32 + l31, h2, kq[((d >> 1) + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                dq[d] = MFMA32(k0[s2], dsf[s2].v, dq[d]);                                     // dQ^T = K^T . dS^T
-                if (d + 1 < NDB) dq[d + 1] = MFMA32(k1[s2], dsf[s2].v, dq[d + 1]);
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dq[d] = MFMA32(k0[s2], dsf[s2].v, dq[d]);
+                    dq[d + 1] = MFMA32(k1[s2], dsf[s2].v, dq[d + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < NDB; d += 2) {
+                bf16x8 k0[2], k1[2];
+                if (d + 1 < NDB) gather_frag_2x2<HD, PITCH>(ldsK, d * 32 + l31, ldsK, (d + 1) * 32 + l31, h2, k0, k1);
+                else gather_frag_s2<HD, PITCH>(ldsK, h2, d * 32 + l31, k0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dq[d] = MFMA32(k0[s2], dsf[s2].v, dq[d]);                                 // dQ^T = K^T . dS^T
+                    if (d + 1 < NDB) dq[d + 1] = MFMA32(k1[s2], dsf[s2].v, dq[d + 1]);
+                }
             }
         }
         if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
@@ -1266,6 +1638,26 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
         dim3 g((unsigned)((long)a.Bb * a.H * ((QT + 3) / 4)));
         if (split) {
             const int lds = 2 * CoopStage<HD, 4>::BUF_BYTES;
+            if constexpr (HD == 192) if (s3d_knob(0) != 2 && (a.N + 31) / 32 >= 3) {      // software-pipelined (see attn_fwd_coop_pipe_kernel)
+#define S3D_PIPE_LAUNCH(DROP_, MASK_)                                                                              \
+    do {                                                                                                           \
+        set_lds((attn_fwd_coop_pipe_kernel<HD, DROP_, MASK_>), lds);                                               \
+        hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, DROP_, MASK_>), g, dim3(256), lds, s, a);                \
+    } while (0)
+                if (a.drop_thr && a.drop_mask) {
+                    switch (s3d_knob(1)) {
+#define S3D_ABL(N_) case N_: set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), lds); hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), g, dim3(256), lds, s, a); break;
+                        S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4)
+#undef S3D_ABL
+                        default: S3D_PIPE_LAUNCH(true, true);
+                    }
+                }
+                else if (a.drop_thr) S3D_PIPE_LAUNCH(true, false);
+                else S3D_PIPE_LAUNCH(false, false);
+#undef S3D_PIPE_LAUNCH
+                S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + 10 + (a.drop_thr ? 1 : 0) + (a.drop_mask ? 2 : 0) + 4);
+                return 0;
+            }
             if (a.drop_thr) {
                 set_lds((attn_fwd_coop_kernel<HD, true, 4, true>), lds);
                 hipLaunchKernelGGL((attn_fwd_coop_kernel<HD, true, 4, true>), g, dim3(256), lds, s, a);

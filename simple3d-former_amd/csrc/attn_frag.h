@@ -72,5 +72,35 @@ __device__ __forceinline__ void gather_frag_2x2(const bf16_t* ldsA, int colA, co
     u.u = u32x4{q2[0], q2[1], q3[0], q3[1]}; fb[1] = u.v;
 }
 
+// The same eight transpose reads WITHOUT the wait: the caller overlaps them with MFMAs on the previous fragments and calls gather_wait()
+// before the first use (the operands tie the wait to the registers, so hipcc cannot move a use above it).
+struct Frag2x2 { u32x2 r[8]; };
+template <int HD, int PITCH = HD>
+__device__ __forceinline__ void gather_issue_2x2(const bf16_t* ldsA, int colA, const bf16_t* ldsB, int colB, int h2, Frag2x2& f) {
+    const int lane = threadIdx.x & 63, t = lane & 15, g = lane >> 4;
+    int cA = (colA & ~31) + 16 * (g & 1) + 4 * (t & 3), cB = (colB & ~31) + 16 * (g & 1) + 4 * (t & 3);
+    if (HD % 32 != 0) { cA = min(cA, HD - 4); cB = min(cB, HD - 4); }
+    const int e = (4 * h2 + (t >> 2)) * PITCH;
+    const unsigned aA = (unsigned)(uintptr_t)(ldsA + e + cA), aB = (unsigned)(uintptr_t)(ldsB + e + cB);
+    asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:%10\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:%11\n\tds_read_b64_tr_b16 %3, %8 offset:%12\n\t"
+                 "ds_read_b64_tr_b16 %4, %9\n\tds_read_b64_tr_b16 %5, %9 offset:%10\n\t"
+                 "ds_read_b64_tr_b16 %6, %9 offset:%11\n\tds_read_b64_tr_b16 %7, %9 offset:%12"
+                 : "=&v"(f.r[0]), "=&v"(f.r[1]), "=&v"(f.r[2]), "=&v"(f.r[3]), "=&v"(f.r[4]), "=&v"(f.r[5]), "=&v"(f.r[6]), "=&v"(f.r[7])
+                 : "v"(aA), "v"(aB), "n"(8 * PITCH * 2), "n"(16 * PITCH * 2), "n"(24 * PITCH * 2)
+                 : "memory");
+}
+__device__ __forceinline__ void gather_wait(Frag2x2& f, bf16x8 (&fa)[2], bf16x8 (&fb)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.r[4]), "+v"(f.r[5]), "+v"(f.r[6]), "+v"(f.r[7])
+                 :
+                 : "memory");
+    U128 u;
+    u.u = u32x4{f.r[0][0], f.r[0][1], f.r[1][0], f.r[1][1]}; fa[0] = u.v;
+    u.u = u32x4{f.r[2][0], f.r[2][1], f.r[3][0], f.r[3][1]}; fa[1] = u.v;
+    u.u = u32x4{f.r[4][0], f.r[4][1], f.r[5][0], f.r[5][1]}; fb[0] = u.v;
+    u.u = u32x4{f.r[6][0], f.r[6][1], f.r[7][0], f.r[7][1]}; fb[1] = u.v;
+}
+
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 

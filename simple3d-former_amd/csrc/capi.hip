@@ -27,6 +27,9 @@ bool s3d_deterministic() {
     return g_deterministic != 0;
 }
 
+static int g_knobs[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+int s3d_knob(int id) { return (id >= 0 && id < 16) ? g_knobs[id] : -1; }
+
 // ---- launch coverage (common.h: S3D_CHECK_LAUNCH_V)
 bool g_s3d_cov_on = false;
 static std::map<std::pair<std::string, long long>, long> g_cov;
@@ -1026,6 +1029,11 @@ __global__ __launch_bounds__(256) void s3d_paced_copy_kernel(u32x4* dst, const u
         const float due = (float)((chunk + 1) * 16384) / bytes_per_tick;
         while ((float)(__builtin_amdgcn_s_memrealtime() - t0) < due) __builtin_amdgcn_s_sleep(2);
     }
+}
+int s3d_debug_knob(int id, int value) {
+    S3D_REQUIRE(id >= 0 && id < 16, "s3d_debug_knob: id 0 .. 15");
+    g_knobs[id] = value;
+    return 0;
 }
 int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t s) {
     S3D_REQUIRE(dst && src && nbytes >= 16 && (nbytes & 15) == 0 && gbps > 0.f, "s3d_debug_paced_copy: 16-byte multiples, a positive rate");

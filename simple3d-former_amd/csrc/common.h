@@ -189,6 +189,7 @@ void s3d_set_error(const char* fmt, ...);
 // with fp32 atomics from several workgroups (split-K wgrads, token / bias gradients, loss, final-norm gamma/beta) takes a
 // single-writer path instead, so a training step is bitwise reproducible run to run.  Slower; for parity tests.
 bool s3d_deterministic();
+int s3d_knob(int id);                    // s3d_debug_knob (capi.hip): -1 = the shipped rule
 // Launch coverage (s3d_cov_enable / s3d_cov_collect, tests/test_gpu_zz_coverage.py): while enabled, every launcher notes the kernel
 // family it dispatched to and an instantiation key (GEMMs: the profiling key = tiles | transposes | split | epilogue; attention /
 // LayerNorm / BatchNorm: the template choice), so that a test can prove that every kernel variant a benched training step launches
