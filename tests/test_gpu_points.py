@@ -449,9 +449,12 @@ def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
                 assert abs(l_ref - l_dp) <= 2e-3, f'{variant} step {step}: {l_ref} vs {l_dp}'
             upd = float((ref.arena.p - p0).abs().max())
             d = float((eng.arena.p - ref.arena.p).abs().max())
-            assert d <= 0.02 * upd + 1e-6, f'{variant}: replicas differ by {d:.3e} (largest update {upd:.3e})'
+            # two NON-deterministic runs (fp32 atomics in different orders, train-mode BatchNorm on four clouds amplifying them): measured
+            # 0.5 - 2.1 % of the largest update -- round 4's 2 % bar failed once in a full-suite run of round 6, and `pytest -x` in front
+            # of 80 other tests is no place for a coin flip.  A wrong average / a missed bucket shows as ~100 %.
+            assert d <= 0.05 * upd + 1e-6, f'{variant}: replicas differ by {d:.3e} (largest update {upd:.3e})'
             # running statistics follow the parameters, which may differ between two runs by the order of the fp32 atomics in the
-            # wgrad / scatter kernels (bounded above at 2 % of an update): compare with a matching, not an absolute 1e-4, bar
+            # wgrad / scatter kernels (bounded above at 5 % of an update): compare with a matching, not an absolute 1e-4, bar
             for a, b in zip(eng.bn_buffers(), ref.bn_buffers()):
                 assert float((a - b).abs().max()) <= 1e-3 * (1.0 + float(b.abs().max()))
     finally:
