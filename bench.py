@@ -613,11 +613,10 @@ def main():
         return main_points(args)
     global CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE, PMC_TRAFFIC_FILE
     conf = CONFIGS[args.config]
-    if args.config != 'cfg2':
-        for rnd in ('r05', 'r04', 'r03'):                     # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh; the newest passes that exist
-            PMC_TRAFFIC_FILE = f'profiles/{rnd}_pmc_{args.config}_traffic.json'
-            if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)):
-                break
+    for rnd in ('r06', 'r05', 'r04', 'r03'):                  # PMC_BENCH_ARGS="--config cfg3 .." tools/pmc_step.sh; the newest passes that exist
+        PMC_TRAFFIC_FILE = f'profiles/{rnd}_pmc_step_traffic.json' if args.config == 'cfg2' else f'profiles/{rnd}_pmc_{args.config}_traffic.json'
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_TRAFFIC_FILE)):
+            break
     CFG, BATCH_PER_GPU, TRAIN_FLOPS_PER_SAMPLE = conf['cfg'], args.batch or conf['batch'], conf['train_flops']
 
     import torch.distributed as dist

@@ -27,7 +27,7 @@ ORACLE_COMPARED = {
     'test_cfg4_full_size_parity', 'test_cfg5_full_size_parity', 'test_am_softmax_row_head_kernels', 'test_sgd_momentum_matches_torch_and_refreshes_planes',
     'test_drop_in_seg_module_with_am_softmax_head_and_cls_error', 'test_point_trained_state_fixture_from_the_reference_sgd',
     # tests/test_gpu_trajectory.py, tests/test_eval_binvox.py
-    'test_fifty_step_trajectory_tracks_the_oracle', 'test_trained_state_fixture_from_the_reference_optimizer', 'test_trained_state_fixture_default_backward_trains_alike', 'test_gpu_unpack_voxels', 'test_gpu_cls_eval_matches_reference_fixture',
+    'test_trajectory_tracks_the_oracle', 'test_benched_backward_reproduces_the_reference_trained_accuracy_and_final_loss', 'test_split_backward_tracks_the_reference_seed_by_seed_on_the_stable_fixture', 'test_trained_state_fixture_from_the_reference_optimizer', 'test_trained_state_fixture_default_backward_trains_alike', 'test_gpu_unpack_voxels', 'test_gpu_cls_eval_matches_reference_fixture',
     'test_gpu_partseg_eval_matches_reference_fixture', 'test_gpu_partseg_eval_large_random_vs_oracle',
 }
 COVERED = {}          # 'family:key' -> the oracle-compared tests that launched it

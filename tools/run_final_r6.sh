@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-5 final measurements on a gpurun box: smoke, the four bench configurations, rocprofv3 summaries, PMC passes of the headline step
-# (the GPU test suite runs in its own call: gpurun_out/r5_full.log)
+# Round-6 final measurements on a gpurun box: smoke, the four bench configurations, rocprofv3 summaries, PMC passes of the headline step
+# (the GPU test suite runs in its own call: gpurun_out/r6 full_suite.log)
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/final_r5; rm -rf $O; mkdir -p $O
+O=gpurun_out/final_r6; rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
