@@ -24,7 +24,7 @@ ORACLE_COMPARED = {
     'test_point_engine_matches_reference_golden', 'test_point_engine_variants_match_reference_golden',
     'test_drop_in_point_module_matches_reference', 'test_drop_in_variant_module_lwf_step_matches_reference',
     'test_drop_in_variant_modules_points_only', 'test_group_project_fwd_bwd', 'test_mean_points_and_broadcast',
-    'test_cfg4_full_size_parity', 'test_cfg5_full_size_parity', 'test_am_softmax_row_head_kernels', 'test_sgd_momentum_matches_torch_and_refreshes_planes',
+    'test_cfg4_full_size_parity', 'test_cfg5_full_size_parity', 'test_cfg3_forward_at_batch_13_reaches_the_fat_residual_tile_and_matches_oracle', 'test_am_softmax_row_head_kernels', 'test_sgd_momentum_matches_torch_and_refreshes_planes',
     'test_drop_in_seg_module_with_am_softmax_head_and_cls_error', 'test_point_trained_state_fixture_from_the_reference_sgd',
     # tests/test_gpu_trajectory.py, tests/test_eval_binvox.py
     'test_trajectory_tracks_the_oracle', 'test_benched_backward_reproduces_the_reference_trained_accuracy_and_final_loss', 'test_split_backward_tracks_the_reference_seed_by_seed_on_the_stable_fixture', 'test_trained_state_fixture_from_the_reference_optimizer', 'test_trained_state_fixture_default_backward_trains_alike', 'test_gpu_unpack_voxels', 'test_gpu_cls_eval_matches_reference_fixture',
