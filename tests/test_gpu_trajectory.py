@@ -254,7 +254,8 @@ def test_benched_backward_reproduces_the_reference_trained_accuracy_and_final_lo
     warm-up, 400 steps, 12 classes, 256 held-out samples at six checkpoints, TWELVE reference seeds; train_cls_voxel.py:195,277-288,315-329).
     Per-seed outcomes are chaotic (the reference's own seeds spread by +-0.037 in accuracy; the same seed under two fp32 implementations
     differs as much), so the criterion is distributional -- the reference's own seed-to-seed spread:
-      * every seed: the first 20 steps track the reference of that seed to 1e-3 (measured 1 - 3e-4), the first 100 to 0.2 (measured 7e-2);
+      * every seed: the first 20 steps track the reference of that seed to 1e-3 (measured 1.9 - 2.6e-4 over six repetitions of the twelve seeds,
+        tools/r6/stable_margins.py), the first 50 to 5e-3 (measured 1.0 - 1.6e-3), the first 100 to 0.3 (6 - 10e-2: the divergence is under way);
       * every seed's held-out accuracy inside [min - 2 sigma, max + 2 sigma] of the reference's twelve;
       * the MEAN accuracy over the seeds within 3 standard errors of the difference of the reference's mean (~0.045);
       * the geometric-mean final loss (median of the last 40 steps) within 3 standard errors (in log) of the reference's.
@@ -276,7 +277,8 @@ def test_benched_backward_reproduces_the_reference_trained_accuracy_and_final_lo
     assert n >= 12
     for r in runs:
         assert float(r['rel'][:20].max()) <= 1e-3, (r['seed'], float(r['rel'][:20].max()))
-        assert float(r['rel'][:100].max()) <= 0.2, (r['seed'], float(r['rel'][:100].max()))
+        assert float(r['rel'][:50].max()) <= 5e-3, (r['seed'], float(r['rel'][:50].max()))
+        assert float(r['rel'][:100].max()) <= 0.3, (r['seed'], float(r['rel'][:100].max()))
         assert ref_acc.min() - 2 * sig <= r['acc'] <= ref_acc.max() + 2 * sig, (r['seed'], r['acc'], ref_acc.min(), ref_acc.max(), sig)
     assert abs(acc.mean() - ref_acc.mean()) <= 3 * se_acc, (acc.mean(), ref_acc.mean(), se_acc)
     assert abs(lt.mean() - ref_lt.mean()) <= 3 * se_lt, (np.exp(lt.mean()), np.exp(ref_lt.mean()), se_lt)
