@@ -728,6 +728,16 @@ class ShardedDataParallelTrainer:
             with torch.cuda.graph(g):
                 self._step_body(sx, sy, weight, lambda i, fn: fn())
             self._cap = dict(B=B, whole=g, x=sx, y=sy, loss=eng.workspace(B).loss, epoch=eng.capture_epoch)
+            if self.world > 1 or self.force:
+                # first replay of a graph that holds RCCL kernels, under the watchdog of the replicated trainer (a capture problem that only
+                # shows with real peers would hang inside the device queue forever); the state is restored afterwards
+                DataParallelTrainer._guarded_first_replay(self, g, state)
+                self.sync_parameters() if self.pending else None
+                for t, sv in zip(state, snap):
+                    t.copy_(sv)
+                eng.refresh_weight_planes()
+                self.pending = False
+                torch.cuda.synchronize()
             return self._cap
         graphs = {}
 
