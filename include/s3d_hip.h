@@ -233,6 +233,12 @@ typedef struct S3dAttnArgs {
      * keys for query row q.  s3d_attention_fwd writes it while it evaluates the hash, s3d_attention_bwd (given the SAME buffer, seed and
      * shape) reads it instead of evaluating the hash twice more.  NULL: every kernel evaluates the hash. */
     unsigned int* drop_mask;
+    /* split forward of LONG sequences (head dim 192, the cooperative kernel): 1 = the probabilities enter the P V product as ONE bf16 plane
+     * (P_hi (V_hi + V_lo): two MFMAs per product instead of three; the row sum, the log-sum-exp and the Q K^T product stay as they are).  The
+     * rounding of P is 2^-9 relative per weight; through a softmax-weighted average it reaches the layer's output at <= 2^-9 of the spread of V
+     * and the logits of the group_embed model at 1 - 3e-6 (tools/r6/pv_plain_probe.py: diffuse and sharpened attention, bar 1e-3).  The seq-first
+     * encoder layer of group_embed sets it (vit_3d_2d_pretrain.py:381,479); 0 (default) = the full split product. */
+    int p_single_plane;
 } S3dAttnArgs;
 int s3d_attention_fwd(const S3dAttnArgs* args, int split, s3d_stream_t stream);
 int s3d_attention_bwd(const S3dAttnArgs* args, s3d_stream_t stream);

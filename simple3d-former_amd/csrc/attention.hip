@@ -886,7 +886,8 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
 //   * no branch between the first score MFMA and the last probability: the ragged last key tile is a peeled instantiation of the body, the
 //     mask-word store is unconditional (duplicate lanes / clamped waves store identical words), DROP means drop_thr != 0;
 //   * the (rare) rescale of the running output stays a wave-uniform branch, between the region and the P V MFMAs.
-template <int HD, bool DROP, bool MASKOUT, int ABL = 0>      // ABL: timing ablations (s3d_debug_knob 1; results wrong), 0 = the product
+// P1: S3dAttnArgs::p_single_plane -- the probabilities as one bf16 plane in the P V product (two MFMAs per product: 60 instead of 72 per key tile)
+template <int HD, bool DROP, bool MASKOUT, int ABL = 0, bool P1 = false>      // ABL: timing ablations (s3d_debug_knob 1; results wrong), 0 = the product
 __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
@@ -980,6 +981,12 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs 
     __syncthreads();
     f32x16 scur, snext;
     scores(kring, scur);
+    // K(2) goes into the buffer S(0) was just read from, at the END of iteration 0 -- without this barrier a wave that is a whole key tile behind
+    // scores tile 0 against rows of K(2).  It happens: the Q fragments are first used above, and in the first workgroups of a launch (cold TLB; a
+    // wave's 32 query rows are 32 pages of their own) one wave's Q data arrives microseconds after its neighbours'.  Measured at cfg-3 before
+    // the barrier was here: one launch in ~40 with 32 - 96 rows off by 3e-5 - 1e-4 in the log-sum-exp, always key tile 0, always the k-steps at
+    // the end of the tile, in blocks < 400 of 5880 (tools/r6/attn_repro_stress.py, attn_repro_diag.py; profiles/r06_attn_prologue_race.txt).
+    __syncthreads();
     gload(2, 1);
     uint32_t zz[8], zh[2];                                             // dropout hashes of the CURRENT tile's key pairs (computed one tile ahead)
     if constexpr (DROP) {
@@ -1036,7 +1043,8 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs 
                 }
             } else {                                                  // J = 28 .. 35: bf16 hi / lo of pair J - 28
                 constexpr int q = J - 28, s2 = q / 4, j = (q % 4) * 2;
-                split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
+                if constexpr (P1) ph[s2].w[j / 2] = f2bf2(sv[8 * s2 + j], sv[8 * s2 + j + 1]);
+                else split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
             }
         };
         if constexpr (MORE) {
@@ -1117,7 +1125,7 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs 
                     zh[s2] = x;
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (ABL != 2) o[d] = MFMA32(vh[s2], pl[s2].v, o[d]);
+                if constexpr (!P1) { if (ABL != 2) o[d] = MFMA32(vh[s2], pl[s2].v, o[d]); }
                 __builtin_amdgcn_sched_barrier(0);
                 if (DROP && MORE && hj < 8) {
                     uint32_t x = zh[s2];
@@ -1649,13 +1657,20 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
 #define S3D_ABL(N_) case N_: set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), lds); hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), g, dim3(256), lds, s, a); break;
                         S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4)
 #undef S3D_ABL
-                        default: S3D_PIPE_LAUNCH(true, true);
+                        default:
+                            if (a.p_single_plane) {
+                                set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), lds);
+                                hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), g, dim3(256), lds, s, a);
+                            } else S3D_PIPE_LAUNCH(true, true);
                     }
                 }
                 else if (a.drop_thr) S3D_PIPE_LAUNCH(true, false);
-                else S3D_PIPE_LAUNCH(false, false);
+                else if (a.p_single_plane) {
+                    set_lds((attn_fwd_coop_pipe_kernel<HD, false, false, 0, true>), lds);
+                    hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, false, false, 0, true>), g, dim3(256), lds, s, a);
+                } else S3D_PIPE_LAUNCH(false, false);
 #undef S3D_PIPE_LAUNCH
-                S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + 10 + (a.drop_thr ? 1 : 0) + (a.drop_mask ? 2 : 0) + 4);
+                S3D_CHECK_LAUNCH_V("attention_fwd_coop", HD * 100 + 10 + (a.drop_thr ? 1 : 0) + (a.drop_mask ? 2 : 0) + 4 + (a.p_single_plane && (!a.drop_thr || a.drop_mask) ? 1000 : 0));
                 return 0;
             }
             if (a.drop_thr) {

@@ -605,6 +605,7 @@ int enc_fwd(const S3dEncShape& sh, const S3dEncParams& p, const S3dEncActs& a, h
     at.scale = 1.0f / sqrtf((float)(D / sh.H));
     SET_DROP(at, 0);
     at.drop_mask = a.attn_mask;
+    at.p_single_plane = s3d_knob(2) == 0 ? 0 : 1;     // one bf16 plane of P in the P V product (S3dAttnArgs::p_single_plane; knob 2 = 0: A/B against the full split)
     S3D_TRY(s3d_launch_attention_fwd(at, split, s));
     g = gemm_zero();                                // s1 = x + drop(att @ Wo^T + bo)
     g.A_hi = a.att_hi; g.A_lo = a.att_lo; g.lda = D; g.B_hi = p.out_w_hi; g.B_lo = p.out_w_lo; g.ldb = D;

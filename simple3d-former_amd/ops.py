@@ -80,13 +80,14 @@ def _drop_fields(drop):
     return dict(drop_seed=seed, drop_site=int(site), drop_thr=int(p * 4294967296.0), drop_scale=1.0 / (1.0 - p))
 
 
-def attention_fwd(qkv_hi, qkv_lo, Bb, H, N, D, sb, st, split=True, seg=0, drop=None, drop_mask=None):
+def attention_fwd(qkv_hi, qkv_lo, Bb, H, N, D, sb, st, split=True, seg=0, drop=None, drop_mask=None, p_single_plane=0):
     rows = qkv_hi.shape[0]
     out_hi = torch.zeros(rows, D, dtype=torch.bfloat16, device=qkv_hi.device)
     out_lo = torch.zeros_like(out_hi)
     lse = torch.zeros(Bb * H * N, dtype=torch.float32, device=qkv_hi.device)
     a = L.fill(L.S3dAttnArgs(), qkv_hi=_dev(qkv_hi), qkv_lo=_dev(qkv_lo), ld=3 * D, out_hi=out_hi, out_lo=out_lo, ldo=D,
-               lse=lse, Bb=Bb, H=H, N=N, D=D, sb=sb, st=st, scale=float((D // H) ** -0.5), seg=seg, drop_mask=drop_mask, **_drop_fields(drop))
+               lse=lse, Bb=Bb, H=H, N=N, D=D, sb=sb, st=st, scale=float((D // H) ** -0.5), seg=seg, drop_mask=drop_mask, p_single_plane=p_single_plane,
+               **_drop_fields(drop))
     L.check(L.lib().s3d_attention_fwd(ctypes.byref(a), 1 if split else 0, L.current_stream()), 'attention_fwd')
     return out_hi, out_lo, lse
 

@@ -22,6 +22,33 @@ DEV = 'cuda'
 LOGIT_TOL = 1e-3
 
 
+def test_cfg3_encoder_attention_forward_repeats_bit_for_bit_launch_after_launch():
+    """The seq-first encoder attention at the cfg-3 geometry (15 x 4 heads, 12544 keys, hd 192, weight dropout with the stored mask), 48 launches:
+    every output, log-sum-exp and mask word equals the first launch's.  Round 6 shipped a software-pipelined forward whose prologue scored key
+    tile 0 from a buffer that a wave one tile ahead was already refilling with K(2): one launch in ~40 came back with 32 - 96 rows off by 1e-4
+    (first workgroups of a launch only, where one wave's Q rows can arrive microseconds late) -- profiles/r06_attn_prologue_race.txt."""
+    from simple3d_former_amd import ops
+    Bb, H, hd, N = 15, 4, 192, 64 * 196
+    D = H * hd
+    g = torch.Generator(device=DEV).manual_seed(6)
+    hi, lo = ops.split_bf16(torch.randn(Bb * N, 3 * D, generator=g, device=DEV) * 0.5)
+    seed = torch.tensor([4321], dtype=torch.int64, device=DEV)
+    T = (N + 31) // 32
+    mbuf = torch.zeros(Bb * H * T * T * 32, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+    for flag in (1, 0):                                            # what the encoder layer launches (one bf16 plane of P), and the full split
+        first = None
+        for r in range(24):
+            if r % 3 == 1:                                         # unrelated traffic on a second stream: different cache / TLB state at launch
+                with torch.cuda.stream(side): torch.randn(1 << 24, device=DEV).sum()
+            o_hi, o_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, 1, Bb, split=True, drop=(0.1, seed, 0), drop_mask=mbuf, p_single_plane=flag)
+            if first is None: first = (o_hi.clone(), o_lo.clone(), lse.clone(), mbuf.clone())
+            else:
+                for name, a, b in zip(('out_hi', 'out_lo', 'lse', 'mask'), (o_hi, o_lo, lse, mbuf), first):
+                    assert torch.equal(a, b), f'launch {r} (p_single_plane {flag}): {int((a != b).sum())} elements of {name} differ from the first launch'
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('B', [16, 64])
 def test_cfg3_full_geometry_properties(B):
     """BASELINE cfg-3 geometry (deit_base H=3, VoxelEmbed_no_average 128^3, cell 9, patch 14, group_embed, 55 classes).

@@ -737,6 +737,38 @@ def test_attention_weight_dropout_uses_the_oracle_mask(Bb, H, N, hd, seq_first, 
         assert e < 2e-2, f'd{name} rms err {e:.3e}'
 
 
+@pytest.mark.parametrize('stored', [False, True])
+def test_attention_single_plane_probabilities_keep_the_row_statistics_and_stay_within_bf16_of_the_full_split(stored):
+    """S3dAttnArgs::p_single_plane (the seq-first encoder layer's forward sets it): P enters P V as one bf16 plane.  The log-sum-exp (what the
+    backward recomputes P from) and the stored dropout bits are those of the full split bit for bit; the output moves by at most the rounding
+    of the weights (2^-9 relative per weight -> <= 2^-9 max|V| per element, far less in rms) and still matches fp64 at 2e-3 relative."""
+    g = torch.Generator().manual_seed(23)
+    Bb, H, N, hd = 3, 4, 300, 192
+    D, rows = H * hd, Bb * N
+    qkv = torch.randn(rows, 3 * D, generator=g).to(DEV)
+    hi, lo = ops.split_bf16(qkv)
+    T = (N + 31) // 32
+    seed = torch.tensor([99], dtype=torch.int64, device=DEV)
+    kw = dict(drop=(0.1, seed, 0), drop_mask=None) if stored else {}
+    outs = []
+    for flag in (0, 1):
+        if stored: kw['drop_mask'] = torch.zeros((Bb * H, T, T, 32), dtype=torch.int32, device=DEV)
+        o_hi, o_lo, lse = ops.attention_fwd(hi, lo, Bb, H, N, D, 1, Bb, split=True, p_single_plane=flag, **kw)
+        outs.append((o_hi.float() + o_lo.float(), lse.clone(), kw.get('drop_mask')))
+    (full, lse0, m0), (one, lse1, m1) = outs
+    assert torch.equal(lse0, lse1)
+    if stored: assert torch.equal(m0, m1)
+    assert not torch.equal(full, one), 'the flag did not select the single-plane kernel'
+    vmax = float(qkv[:, 2 * D:].abs().max())
+    assert float((full - one).abs().max()) <= 2.0 ** -9 * vmax * (1.0 / 0.9 if stored else 1.0)
+    assert 1e-6 < rel_err(one, full) < 5e-3
+    if not stored:                     # against fp64 of the operator (the full split holds 1e-4 in test_attention_fwd_bwd)
+        x = qkv.double().view(N, Bb, 3, H, hd).permute(2, 1, 3, 0, 4)
+        ref = ((x[0] @ x[1].transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ x[2]
+        got = one.view(N, Bb, H, hd).permute(1, 2, 0, 3)
+        assert rel_err(got, ref) < 5e-3
+
+
 @pytest.mark.parametrize('H,N,hd,seg', [(3, 30, 256, 15), (6, 26, 64, 13), (4, 32, 48, 16), (2, 21, 96, 11)])
 def test_attention_block_diagonal_segments(H, N, hd, seg):
     """S3dAttnArgs::seg: a query attends to the keys of its own segment only (what the launchers use to pack two short

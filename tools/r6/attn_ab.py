@@ -1,6 +1,6 @@
 """Same-process A/B of the seq-first encoder attention (cfg-3: 15 x 4 heads, N = 196 B keys, hd = 192, dropout 0.1 with the stored mask):
 times forward / backward per s3d_debug_knob setting and checks the variants against each other bit for bit (tools only).
-    python tools/r6/attn_ab.py [B=64] [knob_id:value,...;...]"""
+    python tools/r6/attn_ab.py [B=64] [knob_id:value,...;...]     (id 100 = S3dAttnArgs::p_single_plane)"""
 import ctypes, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,10 +35,11 @@ def main():
     base = None
     for st in settings:
         for k in range(16): lib.s3d_debug_knob(k, -1)
-        for k, v in st.items(): lib.s3d_debug_knob(k, v)
+        for k, v in st.items():
+            if k < 16: lib.s3d_debug_knob(k, v)
         res = {}
         def fwd():
-            res['o'] = ops.attention_fwd(hi, lo, Bb, H, N, D, 1, Bb, split=True, drop=drop, drop_mask=mbuf)
+            res['o'] = ops.attention_fwd(hi, lo, Bb, H, N, D, 1, Bb, split=True, drop=drop, drop_mask=mbuf, p_single_plane=st.get(100, 0))
         t_f = timed(fwd)
         out_hi, out_lo, lse = res['o']
         def bwd():
@@ -51,7 +52,8 @@ def main():
         else:
             same = [bool(torch.equal(a, b)) for a, b in zip(cur, base)]
             dmax = float((cur[3].float() - base[3].float()).abs().max())
-            note = f'  vs shipped: out_hi {same[0]} out_lo {same[1]} lse {same[2]} dqkv {same[3]} (max |d dqkv| {dmax:.2e})'
+            dl = (cur[2] - base[2]).abs()
+            note = f'  [lse: {int((dl > 0).sum())} of {dl.numel()} differ, max {float(dl.max()):.2e}]  vs shipped: out_hi {same[0]} out_lo {same[1]} lse {same[2]} dqkv {same[3]} (max |d dqkv| {dmax:.2e})'
         print(f'knobs {st or "shipped"}: forward {t_f:8.3f} ms  backward {t_b:8.3f} ms{note}', flush=True)
 
 if __name__ == '__main__':
