@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs p) {
 // load latency hidden behind the previous tile.
 // MASK: the instantiation that reads S3dAttnArgs::drop_mask (kept apart: its extra state took the hd = 64 kernel of the point path from
 // 128 to 136 registers = three waves per SIMD instead of four, 59.6 -> 91.8 us)
-template <int HD, int DSPLIT, int NWV = 4, bool MASK = false>
+// ABL: timing ablations (s3d_debug_knob 3; results wrong), 0 = the product
+template <int HD, int DSPLIT, int NWV = 4, bool MASK = false, int ABL = 0>
 __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnArgs p) {
     constexpr int NTHR = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -492,27 +493,38 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
     const long st_lddo = p.st * p.lddo;
     const int QT = (p.N + 31) / 32;
 
-    u32x4 rq[NCH], rd[NCH];
-    float rr = 0.f;
-    [[maybe_unused]] uint32_t rm = 0u;
+    // staging registers, TWO sets (DEEP; set t & 1 holds query tile t): the loads of tile t + 2 are issued at the top of iteration t and stored at
+    // the end of iteration t + 1.  One tile ahead was not enough at hd = 192: a q-tile iteration lasts ~2.2 us, the mask words (one 128-byte
+    // line per wave and tile, 50 KB apart) and the first touch of a Q / dO tile miss L2, and a wave's loads return in order -- the staging
+    // mechanism on cache-hot addresses measured 3.5 - 4.3 ms less per cfg-3 launch than on the real ones (profiles/r06_attn_backward_staging.txt)
+    constexpr bool DEEP = MASK && HD >= 192 && NWV == 4;
+    constexpr bool DEEPQ = DEEP && ABL == 8;                           // the Q / dO tiles too (48 staging registers: spills at hd = 192)
+    constexpr int NSET = DEEP ? 2 : 1, NSETQ = DEEPQ ? 2 : 1;
+    u32x4 rq[NSETQ][NCH], rd[NSETQ][NCH];
+    float rr = 0.f;                                                    // lse / delta: one tile ahead (the bh's workgroups share the lines)
+    [[maybe_unused]] uint32_t rm[NSET] = {};
     // S3dAttnArgs::drop_mask: the 32 words (one per query row) of tile (query tile, THIS wave's key tile), staged with the query tile
     [[maybe_unused]] const unsigned int* mwave = MASK ? p.drop_mask + ((long)bh * QT * KT + kt) * 32 + l31 : nullptr;
-    auto gload = [&](int q0) {
-        if constexpr (MASK) { if (h2 == 0) rm = mwave[(long)(q0 >> 5) * KT * 32]; }
+    auto gload_qd = [&](auto set_tag, int q0) {
+        constexpr int S = DEEPQ ? decltype(set_tag)::value : 0;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = min(tid + NTHR * i, 32 * CPR - 1);
             const int r = c / CPR, cc = c % CPR;
-            const long t = min(q0 + r, p.N - 1);
-            rq[i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + base + t * st_ld + cc * 8);
-            rd[i] = *reinterpret_cast<const u32x4*>(p.dout + dobase + t * st_lddo + cc * 8);
-        }
-        if (tid < 64) {
-            rr = (tid < 32 ? p.lse : p.delta)[(long)bh * p.N + min(q0 + (tid & 31), p.N - 1)];
-            if (tid < 32) rr *= 1.4426950408889634f;               // lse is staged in log2 units: P = exp2(S * scale * log2 e - lse2)
+            const long t = ABL == 7 ? r : min(q0 + r, p.N - 1);
+            rq[S][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + base + t * st_ld + cc * 8);
+            rd[S][i] = *reinterpret_cast<const u32x4*>(p.dout + dobase + t * st_lddo + cc * 8);
         }
     };
-    auto lstore = [&](int buf) {
+    auto gload_rr = [&](int q0) {
+        if (tid < 64) rr = (tid < 32 ? p.lse : p.delta)[(long)bh * p.N + min(q0 + (tid & 31), p.N - 1)];
+    };
+    auto gload_aux = [&](auto set_tag, int q0) {                       // the wave's mask words of the tile
+        constexpr int S = decltype(set_tag)::value;
+        if constexpr (MASK) { if (h2 == 0) rm[S] = mwave[ABL == 6 ? 0 : (long)(q0 >> 5) * KT * 32]; }
+    };
+    auto lstore = [&](auto set_tag, int buf) {
+        constexpr int S = decltype(set_tag)::value, SQ = DEEPQ ? S : 0;
         bf16_t* q = reinterpret_cast<bf16_t*>(smem + buf * BUF_BYTES);
         bf16_t* dO = q + 32 * PITCH;
 #pragma unroll
@@ -520,21 +532,33 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
             const int c = tid + NTHR * i;
             if (32 * CPR % NTHR == 0 || c < 32 * CPR) {
                 const int r = c / CPR, cc = c % CPR;
-                *reinterpret_cast<u32x4*>(q + r * PITCH + cc * 8) = rq[i];
-                *reinterpret_cast<u32x4*>(dO + r * PITCH + cc * 8) = rd[i];
+                *reinterpret_cast<u32x4*>(q + r * PITCH + cc * 8) = rq[SQ][i];
+                *reinterpret_cast<u32x4*>(dO + r * PITCH + cc * 8) = rd[SQ][i];
             }
         }
-        if (tid < 64) reinterpret_cast<float*>(dO + 32 * PITCH)[tid] = rr;
-        if constexpr (MASK) { if (h2 == 0) reinterpret_cast<uint32_t*>(dO + 32 * PITCH)[64 + wave * 32 + l31] = rm; }
+        // lse is staged in log2 units: P = exp2(S * scale * log2 e - lse2)
+        if (tid < 64) reinterpret_cast<float*>(dO + 32 * PITCH)[tid] = tid < 32 ? rr * 1.4426950408889634f : rr;
+        if constexpr (MASK) { if (h2 == 0) reinterpret_cast<uint32_t*>(dO + 32 * PITCH)[64 + wave * 32 + l31] = rm[S]; }
     };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, DEEP ? 1 : 0>;
 
-    gload(0);
-    lstore(0);
+    gload_qd(Set0{}, 0); gload_rr(0); gload_aux(Set0{}, 0);
+    lstore(Set0{}, 0);
+    if constexpr (DEEP) { if (QT > 1) { if constexpr (DEEPQ) gload_qd(Set1{}, 32); gload_aux(Set1{}, 32); } }
     __syncthreads();
-    for (int qt = 0; qt < QT; ++qt) {
+    // iteration qt computes on buffer qt & 1; DEEP: loads tile qt + 2 into set qt & 1 (stored by the previous iteration), stores tile qt + 1
+    // from set (qt + 1) & 1 into buffer (qt + 1) & 1 -- last read in iteration qt - 1, behind that iteration's barrier.  No compute happens
+    // between the prologue's barrier and the loop (cf. the forward's prologue race, profiles/r06_attn_prologue_race.txt).
+    auto body = [&](int qt, auto cur_tag, auto nxt_tag) {
         const int q0 = qt * 32;
         const bool more = qt + 1 < QT;                                // block-uniform
-        if (more) gload(q0 + 32);
+        // order: the Q / dO loads whose data the END of this iteration stores first, the deep ones (two iterations to land) behind them
+        if constexpr (!DEEPQ) { if (more && ABL != 4) gload_qd(cur_tag, ABL == 5 ? 0 : q0 + 32); }   // (ABL 5: the staging mechanism on a cache-hot tile)
+        if (more && ABL != 4) gload_rr(ABL == 5 ? 0 : q0 + 32);
+        if constexpr (DEEP) {
+            if (qt + 2 < QT && ABL != 4) { if constexpr (DEEPQ) gload_qd(cur_tag, q0 + 64); gload_aux(cur_tag, ABL == 5 ? 0 : q0 + 64); }
+        } else { if (more && ABL != 4) gload_aux(cur_tag, ABL == 5 ? 0 : q0 + 32); }
         const bf16_t* ldsQ = reinterpret_cast<const bf16_t*>(smem + (qt & 1) * BUF_BYTES);
         const bf16_t* ldsDO = ldsQ + 32 * PITCH;
         const float* ldsR = reinterpret_cast<const float*>(ldsDO + 32 * PITCH);
@@ -553,8 +577,10 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                     of2[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(ldsDO + off);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL != 3) {
                 sacc = MFMA32(qf2[s & 1], kf[s], sacc);                                       // S  = Q . K^T   (col = key)
                 dpacc = MFMA32(of2[s & 1], vf[s], dpacc);                                     // dP = dO . V^T
+                } else { asm volatile("" :: "v"(qf2[s & 1]), "v"(of2[s & 1])); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -595,6 +621,10 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                     pf[s2].w[j / 2] = f2bf2(pv[0], pv[1]);
                     dsf[s2].w[j / 2] = f2bf2(dv2[0], dv2[1]);
                 }
+        } else if constexpr (ABL == 1) {                               // (no softmax / dS arithmetic: the accumulators are only kept alive)
+            asm volatile("" :: "v"(sacc), "v"(dpacc));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pf[0].w[q] = pf[1].w[q] = 0x3c003c00u; dsf[0].w[q] = dsf[1].w[q] = 0x3c003c00u; }
         } else {                                                       // the mask from the bits the forward stored
             u32x4 mw4[4];                                              // the words of this lane's 16 query rows (four runs of four, like lse4)
 #pragma unroll
@@ -627,10 +657,13 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                 gather_wait(fr[d & 1], fo, fq);
                 if (d + 1 < NDB) gather_issue_2x2<HD, PITCH>(ldsDO, (dblk0 + d + 1) * 32 + l31, ldsQ, (dblk0 + d + 1) * 32 + l31, h2, fr[(d + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ABL == 2) { asm volatile("" :: "v"(fo[0]), "v"(fo[1]), "v"(fq[0]), "v"(fq[1]), "v"(pf[0].v), "v"(pf[1].v), "v"(dsf[0].v), "v"(dsf[1].v)); }
+                else {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     dv[d] = MFMA32(fo[s2], pf[s2].v, dv[d]);      // dV^T = dO^T . P
                     dk[d] = MFMA32(fq[s2], dsf[s2].v, dk[d]);     // dK^T = Q^T . dS
+                }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -647,8 +680,16 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
                 }
             }
         }
-        if (more) lstore((qt + 1) & 1);
+        if (more && ABL != 4) lstore(nxt_tag, (qt + 1) & 1);
         __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);                            // (the two copies of the DEEP loop stay apart: merged they spill)
+    };
+    if constexpr (DEEP) {
+        // always an even number of iterations: for an odd QT the last one is a phantom tile (q0 = 32 QT >= N: every probability is selected to
+        // zero by the ragged-tile rule, nothing is loaded or stored for it) -- a third copy of the body for the tail made hipcc spill
+        for (int qt = 0; qt < QT; qt += 2) { body(qt, Set0{}, Set1{}); body(qt + 1, Set1{}, Set0{}); }
+    } else {
+        for (int qt = 0; qt < QT; ++qt) body(qt, Set0{}, Set0{});
     }
     if (active && kok) {
         const long orow = ((long)b * p.sb + (long)krow * p.st) * p.lddq + h * HD;
@@ -1231,19 +1272,28 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
     const bf16_t* src[2] = {p.qkv_hi, p.qkv_hi};
     long rowoff[2] = {base + p.D, base + 2 * (long)p.D}, pitch[2] = {st_ld, st_ld};
     const int KT = (p.N + 31) / 32;
-    // S3dAttnArgs::drop_mask: this query's word of tile (qt, kt), fetched one key tile ahead
+    // S3dAttnArgs::drop_mask: this query's word of tile (qt, kt), fetched MD key tiles ahead into a ring of MR registers.  One tile ahead (rounds
+    // 5 - 6) left the wave waiting: the word is a first touch of its cache line every time, a key-tile iteration lasts ~1.4 us at hd = 192, and the
+    // K / V loads of the next tile queue up behind it (a wave's loads return in order) -- see attn_bwd_dkv_coop_kernel's DEEP.  The ring needs
+    // static indices: the loop is unrolled MR times (tags).
+    constexpr bool DEEP = MASK && HD >= 192 && NWV == 4;
+    constexpr int MR = DEEP ? 4 : 1, MD = DEEP ? 3 : 1;
     const unsigned int* mrow = MASK ? p.drop_mask + ((long)bh * QT + qt) * KT * 32 + l31 : nullptr;
-    uint32_t wnext = 0u;
-    if constexpr (MASK) wnext = mrow[0];
+    uint32_t wring[MR] = {};
+    if constexpr (MASK) {
+#pragma unroll
+        for (int j = 0; j < MD; ++j) if (j < KT) wring[j % MR] = mrow[(long)j * 32];
+    }
     st.gload(src, rowoff, pitch, 0, p.N, tid);
     st.lstore(smem, tid);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
+    auto body = [&](int kt, auto ring_tag) {
+        constexpr int J = decltype(ring_tag)::value;
         const int k0 = kt * 32;
         const bool more = kt + 1 < KT;
         if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
-        const uint32_t wcur = wnext >> (4 * h2);                       // bit acc_row(r, 0) = key acc_row(r, h2)
-        if constexpr (MASK) { if (more) wnext = mrow[(long)(kt + 1) * 32]; }
+        const uint32_t wcur = wring[J] >> (4 * h2);                    // bit acc_row(r, 0) = key acc_row(r, h2)
+        if constexpr (MASK) { if (kt + MD < KT) wring[(J + MD) % MR] = mrow[(long)(kt + MD) * 32]; }   // (behind the tile's loads: they are stored first)
         const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
         const bf16_t* ldsV = ldsK + TILE;
         const bool ragged = k0 + 32 > p.N;
@@ -1331,6 +1381,20 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
         }
         if (more) st.lstore(smem + ((kt + 1) & 1) * ST::BUF_BYTES, tid);
         __syncthreads();
+    };
+    {
+        int kt = 0;
+        if constexpr (MR == 4) {
+            for (; kt + 3 < KT; kt += 4) {
+                body(kt, std::integral_constant<int, 0>{}); body(kt + 1, std::integral_constant<int, 1>{});
+                body(kt + 2, std::integral_constant<int, 2>{}); body(kt + 3, std::integral_constant<int, 3>{});
+            }
+            if (kt < KT) body(kt, std::integral_constant<int, 0>{});
+            if (kt + 1 < KT) body(kt + 1, std::integral_constant<int, 1>{});
+            if (kt + 2 < KT) body(kt + 2, std::integral_constant<int, 2>{});
+        } else {
+            for (; kt < KT; ++kt) body(kt, std::integral_constant<int, 0>{});
+        }
     }
     if (active && qok) {
         const long orow = tokrow * p.lddq + h * HD;
@@ -1804,8 +1868,18 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
             dim3 g2((unsigned)((long)a.Bb * a.H * ((KT + 3) / 4)), DSPLIT);
             if constexpr (HD < 256) {
                 if (a.drop_mask) {
+                    bool done = false;
+#ifdef S3D_EXPERIMENTAL_TILES
+                    if constexpr (HD == 192 && DSPLIT == 1) {
+#define S3D_ABL(N_) case N_: set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true, N_>), lds); hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true, N_>), g2, dim3(256), lds, s, a); done = true; break;
+                        switch (s3d_knob(3)) { S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4) S3D_ABL(5) S3D_ABL(6) S3D_ABL(7) S3D_ABL(8) default: break; }
+#undef S3D_ABL
+                    }
+#endif
+                    if (!done) {
                     set_lds((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true>), lds);
                     hipLaunchKernelGGL((attn_bwd_dkv_coop_kernel<HD, DSPLIT, 4, true>), g2, dim3(256), lds, s, a);
+                    }
                 }
             }
             if (!a.drop_mask) {

@@ -679,6 +679,7 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
 
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first,stored', [(3, 4, 300, 192, True, False),      # cooperative long-sequence kernels (>= 6 query tiles)
                                                        (3, 4, 300, 192, True, True),       # ... with the forward's 1-bit mask handed to the backward
+                                                       (2, 4, 330, 192, True, True),       # ... an odd number of query tiles (the dK / dV loop runs in pairs)
                                                        (2, 3, 333, 64, False, True), (2, 3, 197, 256, False, True),    # (hd = 256: mask ignored)
                                                        (2, 3, 197, 256, False, False), (4, 6, 26, 64, False, False), (3, 4, 100, 192, True, False),
                                                        (3, 3, 27, 256, False, False), (2, 4, 30, 192, True, False)])     # single-launch backward at hd = 192 / 256

@@ -17,7 +17,7 @@ if torch.cuda.is_available():
     from simple3d_former_amd import _lib as L
 
 from oracle import voxel_oracle as vo
-from tests._util import MODEL_KEYS, check_grads_against_golden, check_grads_against_oracle, fwd_kwargs, load_case, rebuild_inputs
+from tests._util import release_graphs, teardown_process_group, MODEL_KEYS, check_grads_against_golden, check_grads_against_oracle, fwd_kwargs, load_case, rebuild_inputs
 
 DEV = 'cuda'
 LOGIT_TOL = 1e-3
@@ -304,6 +304,7 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
     x, y = vo.synthetic_batch(5, 12, 10, seed=8)
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29517')
     dist.init_process_group('nccl', rank=0, world_size=1)
+    tr = None
     try:
         ref = make_engine(cfg, sd)
         eng = make_engine(cfg, sd)
@@ -333,7 +334,9 @@ def test_dp_trainer_segmented_graphs_and_rccl_path(mode):
         assert (len(tr._cap['graphs']) == 3) == (mode in ('segment_graphs', 'auto_fallback'))
         assert float(d) <= 8.5e-3          # bound 2*steps*lr: Adam moves +-lr per step and fp32-atomic ordering may flip near-zero grads
     finally:
-        dist.destroy_process_group()
+        release_graphs(tr)                  # the HIP graphs (with captured collectives in 'auto') go before the communicator
+        del tr
+        teardown_process_group()
 
 
 @pytest.mark.parametrize('mode', ['eager', 'phase_graphs', 'whole_graph', 'rccl_auto', 'group_embed'])
@@ -389,7 +392,8 @@ def test_sharded_trainer_on_one_gpu_equals_the_plain_step(mode):
     finally:
         lib.s3d_set_deterministic(0)
         if rccl:
-            dist.destroy_process_group()
+            release_graphs(locals().get('tr'))
+            teardown_process_group()
 
 
 def test_group_embed_training_mode_dropout_matches_oracle():

@@ -458,7 +458,8 @@ def test_point_dp_trainer_two_halves_graphs_and_rccl_path():
             for a, b in zip(eng.bn_buffers(), ref.bn_buffers()):
                 assert float((a - b).abs().max()) <= 1e-3 * (1.0 + float(b.abs().max()))
     finally:
-        dist.destroy_process_group()
+        from tests._util import teardown_process_group
+        teardown_process_group()
 
 
 @pytest.mark.parametrize('B,N,S,C,ch', [(2, 40, 10, 8, 16), (3, 64, 64, 48, 96), (2, 256, 64, 96, 192), (1, 128, 32, 192, 384),
