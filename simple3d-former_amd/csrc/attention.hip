@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs 
             if (ABL != 4) {
                 lstore(rk, kring + (kt & 1) * KBUF);
                 lstore(rv, vring + ((kt + 1) & 1) * KBUF);
-                gload(kt + 3, kt + 2);
+                gload(ABL == 5 ? 0 : kt + 3, ABL == 5 ? 0 : kt + 2);      // (ABL 5: the staging mechanism on cache-hot tiles)
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) scur[r] = snext[r];
@@ -1719,7 +1719,7 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
                 if (a.drop_thr && a.drop_mask) {
                     switch (s3d_knob(1)) {
 #define S3D_ABL(N_) case N_: set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), lds); hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), g, dim3(256), lds, s, a); break;
-                        S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4)
+                        S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4) S3D_ABL(5)
 #undef S3D_ABL
                         default:
                             if (a.p_single_plane) {
