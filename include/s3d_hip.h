@@ -400,7 +400,10 @@ int s3d_stream_wait_event(s3d_stream_t waiting_stream, void* event);
  * with the duration and footprint of a ring all-reduce on one GPU; simple3d-former_amd/parallel.py, profiles/r05_dp_branch_tax.txt). */
 int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t stream);
 /* NOT part of the operator ABI -- same-process A/B of dispatch alternatives (tools/r6/attn_ab.py): knob ids are private to the library's
- * launchers (0 .. 15), value -1 restores the shipped rule.  The shipped rules quote the measurements these knobs produced. */
+ * launchers (0 .. 15), value -1 restores the shipped rule.  The shipped rules quote the measurements these knobs produced.  In use:
+ * 0 = 2: the round-5 long-sequence attention forward instead of the pipelined one; 1 = 1 .. 5: timing ablations of the pipelined forward
+ * (results wrong); 2 = 0: s3d_encoder_layer_fwd keeps the full split in P V (S3dAttnArgs::p_single_plane off); 3 = 1 .. 8: timing ablations of
+ * the long-sequence dK / dV kernel (tuning builds, make EXP=1). */
 int s3d_debug_knob(int id, int value);
 
 /* ------------------------------------------------------------------------------------------------ timm Block
