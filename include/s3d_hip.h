@@ -155,7 +155,9 @@ long s3d_cov_collect(char* buf, long cap);
 /* Deterministic mode (default: environment S3D_DETERMINISTIC=1, else off).  On: no reduction combines partial sums from several
  * workgroups with fp32 atomics -- wgrads run without split-K, the token / conv-bias gradients, the loss and the final-norm
  * gamma / beta gradients take single-writer kernels -- so a training step (train_cls_voxel.py:277-288) is bitwise reproducible
- * run to run.  Slower; meant for parity and trajectory tests.  Process-wide; set it before capturing graphs. */
+ * run to run.  Slower; meant for parity and trajectory tests.  Process-wide; set it before capturing graphs.  The point path's training
+ * step (train_cls.py / train_partseg.py) is NOT covered: its BatchNorm batch statistics and scatter / interpolation gradients are summed
+ * with atomics in either mode (profiles/r06_repro_audit.txt: forward bit-reproducible, gradients to 2.5e-3 of the largest). */
 int s3d_set_deterministic(int on);
 int s3d_get_deterministic(void);
 int s3d_prof_event_overhead(s3d_stream_t stream, double* microseconds);
