@@ -731,6 +731,8 @@ def main():
         'voxel_cells_per_sec': round(value * CFG['voxel_size'] ** 3, 0),
         'algorithmic_tflops': round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         'loss_first_step': round(first_loss, 5) if first_loss is not None else None, 'loss_last_step': round(final_loss, 5),
+        'loss_note': 'one repeated batch at lr 1e-3: plateau at 3.385 (label-histogram entropy) from step ~20, chaotic escape at step 160 - 260+ '
+                     '(CPU oracle: ~168), then ~1e-3 -- profiles/r06_single_batch_dynamics.txt' if args.config == 'cfg2' else None,
         'kernels_suppressed': bool(suppressed),
     }
 

@@ -117,6 +117,25 @@ def _init_group(rank, world, port):
     dist.init_process_group('gloo', init_method=f'file://{path}', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
 
 
+
+def _to_wire(obj):
+    """Tensors cross the multiprocessing queue as numpy arrays (pickled by VALUE).  A torch tensor travels as a shared-memory handle that the parent
+    has to fetch from the worker: when the worker has already exited, q.get() dies with EOFError -- a once-in-twenty-runs flake of this file."""
+    if isinstance(obj, torch.Tensor):
+        return ('__tensor__', obj.detach().cpu().numpy())
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_to_wire(o) for o in obj)
+    return obj
+
+
+def _from_wire(obj):
+    if isinstance(obj, tuple) and len(obj) == 2 and isinstance(obj[0], str) and obj[0] == '__tensor__':
+        return torch.from_numpy(obj[1].copy())
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_from_wire(o) for o in obj)
+    return obj
+
+
 def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -143,7 +162,7 @@ def _worker(rank, world, port, q, wire='fp32'):
         assert int(eng.dropout_seed) == 1000003 * rank + 3       # advanced once per step
         # optimizer.step() ran bucket by bucket, in the order the buckets' collectives were launched, once per step
         assert tr.sliced_adam and eng.update_log == (['begin'] + [tuple(sl_) for sl_ in tr.slices] + ['end']) * 3, eng.update_log
-        q.put((rank, eng.arena.p.clone(), flat.clone(), tr.segments, tr.slices))
+        q.put(_to_wire((rank, eng.arena.p.clone(), flat.clone(), tr.segments, tr.slices)))
     finally:
         dist.destroy_process_group()
 
@@ -155,7 +174,7 @@ def test_two_rank_data_parallel_equals_single_process_full_batch():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_wire(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -184,7 +203,7 @@ def test_two_rank_bf16_wire_format_stays_within_the_rounding_bound():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, 'bf16')) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_wire(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -257,7 +276,7 @@ def _point_worker(rank, world, port, q):
         stats0 = eng.stats.clone()                               # after the constructor broadcast
         sl = slice(rank * 4, rank * 4 + 4)
         losses = [float(tr.step(X[sl], Y[sl], ())) for _ in range(3)]
-        q.put((rank, eng.arena.p.clone(), stats0, eng.stats.clone(), tr.slices, eng.grad_scale, losses))
+        q.put(_to_wire((rank, eng.arena.p.clone(), stats0, eng.stats.clone(), tr.slices, eng.grad_scale, losses)))
     finally:
         dist.destroy_process_group()
 
@@ -269,7 +288,7 @@ def test_point_trainer_two_ranks_equal_single_process_full_batch():
     procs = [ctx.Process(target=_point_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_wire(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -446,7 +465,7 @@ def _sharded_worker(rank, world, port, q, sharded):
                 mask[a:b] = True
             assert not eng.arena.m[~mask].any() and eng.arena.m[mask].any()
             assert not eng.arena.g.any()                          # the whole gradient arena is zero again (own shard by Adam, the rest by the scatter)
-        q.put((rank, eng.arena.p.clone(), losses, stale))
+        q.put(_to_wire((rank, eng.arena.p.clone(), losses, stale)))
     finally:
         dist.destroy_process_group()
 
@@ -458,7 +477,7 @@ def _run_two(target, *args):
     procs = [ctx.Process(target=target, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([_from_wire(q.get(timeout=120)) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
