@@ -505,8 +505,32 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dkv_coop_kernel(const AttnA
     [[maybe_unused]] uint32_t rm[NSET] = {};
     // S3dAttnArgs::drop_mask: the 32 words (one per query row) of tile (query tile, THIS wave's key tile), staged with the query tile
     [[maybe_unused]] const unsigned int* mwave = MASK ? p.drop_mask + ((long)bh * QT * KT + kt) * 32 + l31 : nullptr;
+    // whole tiles: wave-uniform bases + one 32-bit byte offset per chunk and tensor (see attn_fwd_coop_pipe_kernel's gload); GA: hd >= 192
+    constexpr bool GA = HD >= 192 && ABL != 7;
+    [[maybe_unused]] unsigned qoff[GA ? NCH : 1], dooff[GA ? NCH : 1], qoff_last[GA ? NCH : 1], dooff_last[GA ? NCH : 1];
+    if constexpr (GA) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = min(tid + NTHR * i, 32 * CPR - 1);
+            const int r = c / CPR, cc = c % CPR, rl = min(r, p.N - 1 - (QT - 1) * 32);
+            qoff[i] = (unsigned)(((long)r * st_ld + cc * 8) * 2);       dooff[i] = (unsigned)(((long)r * st_lddo + cc * 8) * 2);
+            qoff_last[i] = (unsigned)(((long)rl * st_ld + cc * 8) * 2); dooff_last[i] = (unsigned)(((long)rl * st_lddo + cc * 8) * 2);
+        }
+    }
+    const char* const gq = reinterpret_cast<const char*>(p.qkv_hi + base), *const gdo = reinterpret_cast<const char*>(p.dout + dobase);
     auto gload_qd = [&](auto set_tag, int q0) {
         constexpr int S = DEEPQ ? decltype(set_tag)::value : 0;
+        if constexpr (GA) {
+            const int qt_ = min(q0 >> 5, QT - 1);
+            const bool last = qt_ >= QT - 1;                           // block-uniform
+            const long qb = (long)qt_ * 64 * st_ld, db = (long)qt_ * 64 * st_lddo;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                rq[S][i] = *reinterpret_cast<const u32x4*>(gq + qb + (last ? qoff_last[i] : qoff[i]));
+                rd[S][i] = *reinterpret_cast<const u32x4*>(gdo + db + (last ? dooff_last[i] : dooff[i]));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int c = min(tid + NTHR * i, 32 * CPR - 1);
@@ -743,6 +767,42 @@ struct CoopStage {                                                     // NT_ ti
         }
     }
 };
+// The same stream with the tile addresses split into a wave-uniform base per tensor (SGPR pair, advanced per tile) and ONE 32-bit byte offset per
+// chunk and tensor that never changes (a second set for the ragged last tile): the loads take the `v_off, s[base]` form and the per-tile
+// address arithmetic of gload() (min, two multiplies, 64-bit mad and adds per chunk) disappears -- see attn_fwd_coop_pipe_kernel's gload.
+template <int HD, int NT_, int NTHR = 256>
+struct CoopStageU : CoopStage<HD, NT_, NTHR> {
+    using B = CoopStage<HD, NT_, NTHR>;
+    unsigned co[NT_][B::NCH], co_last[NT_][B::NCH];
+    const char* gb[NT_];
+    long tile_bytes[NT_];
+    int last_tile;
+    __device__ __forceinline__ void init(const bf16_t* const (&src)[NT_], const long (&rowoff)[NT_], const long (&pitch)[NT_], int N, int tid) {
+        last_tile = (N + 31) / 32 - 1;
+#pragma unroll
+        for (int k = 0; k < NT_; ++k) {
+            gb[k] = reinterpret_cast<const char*>(src[k] + rowoff[k]);
+            tile_bytes[k] = 64 * pitch[k];
+#pragma unroll
+            for (int i = 0; i < B::NCH; ++i) {
+                const int c = min(tid + NTHR * i, 32 * B::CPR - 1);
+                const int row = c / B::CPR, cc = c % B::CPR;
+                co[k][i] = (unsigned)(((long)row * pitch[k] + cc * 8) * 2);
+                co_last[k][i] = (unsigned)(((long)min(row, N - 1 - last_tile * 32) * pitch[k] + cc * 8) * 2);
+            }
+        }
+    }
+    __device__ __forceinline__ void gload_tile(int t) {                // tile index (tiles past the end read the last one)
+        const int tc = min(t, last_tile);
+        const bool last = tc >= last_tile;                             // block-uniform
+#pragma unroll
+        for (int k = 0; k < NT_; ++k) {
+            const char* b = gb[k] + tc * tile_bytes[k];
+#pragma unroll
+            for (int i = 0; i < B::NCH; ++i) this->r[k][i] = *reinterpret_cast<const u32x4*>(b + (last ? co_last[k][i] : co[k][i]));
+        }
+    }
+};
 
 // NWV waves per workgroup (4 or 8): with eight, two waves share every SIMD and one's softmax / mask VALU phase runs beside the
 // other's MFMAs (the LDS stream and its footprint stay the same; twice the query rows per workgroup)
@@ -928,7 +988,7 @@ __global__ __launch_bounds__(64 * NWV) void attn_fwd_coop_kernel(const AttnArgs 
 //     mask-word store is unconditional (duplicate lanes / clamped waves store identical words), DROP means drop_thr != 0;
 //   * the (rare) rescale of the running output stays a wave-uniform branch, between the region and the P V MFMAs.
 // P1: S3dAttnArgs::p_single_plane -- the probabilities as one bf16 plane in the P V product (two MFMAs per product: 60 instead of 72 per key tile)
-template <int HD, bool DROP, bool MASKOUT, int ABL = 0, bool P1 = false>      // ABL: timing ablations (s3d_debug_knob 1; results wrong), 0 = the product
+template <int HD, bool DROP, bool MASKOUT, int ABL = 0, bool P1 = false, bool GA = true>      // ABL: timing ablations (s3d_debug_knob 1; results wrong), 0 = the product; GA = false: round-6a staging addresses (A/B, knob 4)
 __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
@@ -974,16 +1034,44 @@ __global__ __launch_bounds__(256) void attn_fwd_coop_pipe_kernel(const AttnArgs 
     // registers was built and measured: 23.3 ms per cfg-3 launch with the thirteen 1 KB pieces per wave issued together, 24.5 ms with one
     // piece behind the first MFMA of every k-step, against 22.4 ms here -- a wave sits in the issue stage for every piece, MFMA shadow or not.)
     u32x4 rk[2][ST::NCH], rv[2][ST::NCH];
-    auto gload = [&](int tk, int tv) {
+    // a whole tile inside the sequence: wave-uniform plane bases (SGPR pairs) + one 32-bit byte offset per chunk (row in the tile, 16-byte
+    // column) that never changes -- the twelve 64-bit row addresses per tile (min, two multiplies, a 64-bit mad and two 64-bit adds each:
+    // ~70 VALU instructions of an in-order wave's key-tile iteration, and 24 registers of address pairs) are only built for a ragged tile
+    unsigned coff[ST::NCH], coff_last[ST::NCH];                        // (coff_last: rows of the ragged last tile clamped to the last key)
+    const int KT_ = (p.N + 31) / 32;
+#pragma unroll
+    for (int i = 0; i < ST::NCH; ++i) {
+        const int c = min(tid + 256 * i, 32 * ST::CPR - 1);
+        const int row = c / ST::CPR, cc = c % ST::CPR;
+        coff[i] = (unsigned)(((long)row * st_ld + cc * 8) * 2);
+        coff_last[i] = (unsigned)(((long)min(row, p.N - 1 - (KT_ - 1) * 32) * st_ld + cc * 8) * 2);
+    }
+    const char* const gkh = reinterpret_cast<const char*>(p.qkv_hi + koff), *const gkl = reinterpret_cast<const char*>(p.qkv_lo + koff);
+    const char* const gvh = reinterpret_cast<const char*>(p.qkv_hi + voff), *const gvl = reinterpret_cast<const char*>(p.qkv_lo + voff);
+    const long tile_bytes = 64 * st_ld;                                // 32 rows x st_ld elements x 2 bytes
+    auto gload = [&](int tk, int tv) {                                 // (tiles past the end -- the prefetch overshoots by up to three -- read the last one)
+        if constexpr (!GA) {
+#pragma unroll
+            for (int i = 0; i < ST::NCH; ++i) {
+                const int c = min(tid + 256 * i, 32 * ST::CPR - 1);
+                const int row = c / ST::CPR, cc = c % ST::CPR;
+                const long rowk = min(tk * 32 + row, p.N - 1), rowv = min(tv * 32 + row, p.N - 1);
+                rk[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + koff + rowk * st_ld + cc * 8);
+                rk[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + koff + rowk * st_ld + cc * 8);
+                rv[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + voff + rowv * st_ld + cc * 8);
+                rv[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + voff + rowv * st_ld + cc * 8);
+            }
+            return;
+        }
+        const long kb = min(tk, KT_ - 1) * tile_bytes, vb = min(tv, KT_ - 1) * tile_bytes;
+        const bool klast = tk >= KT_ - 1, vlast = tv >= KT_ - 1;       // block-uniform
 #pragma unroll
         for (int i = 0; i < ST::NCH; ++i) {
-            const int c = min(tid + 256 * i, 32 * ST::CPR - 1);
-            const int row = c / ST::CPR, cc = c % ST::CPR;
-            const long rowk = min(tk * 32 + row, p.N - 1), rowv = min(tv * 32 + row, p.N - 1);
-            rk[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + koff + rowk * st_ld + cc * 8);
-            rk[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + koff + rowk * st_ld + cc * 8);
-            rv[0][i] = *reinterpret_cast<const u32x4*>(p.qkv_hi + voff + rowv * st_ld + cc * 8);
-            rv[1][i] = *reinterpret_cast<const u32x4*>(p.qkv_lo + voff + rowv * st_ld + cc * 8);
+            const unsigned ko = klast ? coff_last[i] : coff[i], vo = vlast ? coff_last[i] : coff[i];
+            rk[0][i] = *reinterpret_cast<const u32x4*>(gkh + kb + ko);
+            rk[1][i] = *reinterpret_cast<const u32x4*>(gkl + kb + ko);
+            rv[0][i] = *reinterpret_cast<const u32x4*>(gvh + vb + vo);
+            rv[1][i] = *reinterpret_cast<const u32x4*>(gvl + vb + vo);
         }
     };
     auto lstore = [&](const u32x4 (&r)[2][ST::NCH], unsigned char* buf) {
@@ -1219,7 +1307,8 @@ template <int HD, int NWV = 4, bool MASK = false>                   // MASK: see
 __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int NS = HD / 16, NDB = (HD + 31) / 32;
-    using ST = CoopStage<HD, 2, 64 * NWV>;                             // K, V
+    constexpr bool GA = HD >= 192;                                     // uniform-base staging addresses (CoopStageU)
+    using ST = std::conditional_t<GA, CoopStageU<HD, 2, 64 * NWV>, CoopStage<HD, 2, 64 * NWV>>;        // K, V
     constexpr int PITCH = ST::PITCH, TILE = ST::TILE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h2 = lane >> 5, l31 = lane & 31;
@@ -1284,14 +1373,15 @@ __global__ __launch_bounds__(64 * NWV) void attn_bwd_dq_coop_kernel(const AttnAr
 #pragma unroll
         for (int j = 0; j < MD; ++j) if (j < KT) wring[j % MR] = mrow[(long)j * 32];
     }
-    st.gload(src, rowoff, pitch, 0, p.N, tid);
+    if constexpr (GA) { st.init(src, rowoff, pitch, p.N, tid); st.gload_tile(0); }
+    else st.gload(src, rowoff, pitch, 0, p.N, tid);
     st.lstore(smem, tid);
     __syncthreads();
     auto body = [&](int kt, auto ring_tag) {
         constexpr int J = decltype(ring_tag)::value;
         const int k0 = kt * 32;
         const bool more = kt + 1 < KT;
-        if (more) st.gload(src, rowoff, pitch, k0 + 32, p.N, tid);
+        if (more) { if constexpr (GA) st.gload_tile(kt + 1); else st.gload(src, rowoff, pitch, k0 + 32, p.N, tid); }
         const uint32_t wcur = wring[J] >> (4 * h2);                    // bit acc_row(r, 0) = key acc_row(r, h2)
         if constexpr (MASK) { if (kt + MD < KT) wring[(J + MD) % MR] = mrow[(long)(kt + MD) * 32]; }   // (behind the tile's loads: they are stored first)
         const bf16_t* ldsK = reinterpret_cast<const bf16_t*>(smem + (kt & 1) * ST::BUF_BYTES);
@@ -1722,7 +1812,10 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
                         S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4) S3D_ABL(5)
 #undef S3D_ABL
                         default:
-                            if (a.p_single_plane) {
+                            if (a.p_single_plane && s3d_knob(4) == 0) {
+                                set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), lds);
+                                hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), g, dim3(256), lds, s, a);
+                            } else if (a.p_single_plane) {
                                 set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), lds);
                                 hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), g, dim3(256), lds, s, a);
                             } else S3D_PIPE_LAUNCH(true, true);
