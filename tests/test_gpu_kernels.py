@@ -639,7 +639,10 @@ def _attn_ref(q, k, v):
                                                 # even batch, N <= 16, contiguous: two sequences share one 32-row tile (pack_pairs)
                                                 (392, 3, 15, 256, False), (6, 6, 10, 64, False), (4, 4, 16, 48, False), (8, 3, 15, 192, False),
                                                 # N <= 32 at hd = 192 / 256: the one-launch backward, gradients two d-blocks at a time
-                                                (3, 4, 20, 192, True), (5, 3, 32, 256, False), (7, 3, 29, 256, False)])
+                                                (3, 4, 20, 192, True), (5, 3, 32, 256, False), (7, 3, 29, 256, False),
+                                                # hd = 192 long sequences, batch-first and seq-first, ragged last tile, odd tile count: the pipelined forward and
+                                                # the cooperative backward with uniform-base staging addresses
+                                                (2, 4, 300, 192, False), (2, 4, 330, 192, True), (1, 4, 97, 192, False)])
 def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     g = torch.Generator().manual_seed(6)
     D = H * hd
@@ -680,6 +683,7 @@ def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
 @pytest.mark.parametrize('Bb,H,N,hd,seq_first,stored', [(3, 4, 300, 192, True, False),      # cooperative long-sequence kernels (>= 6 query tiles)
                                                        (3, 4, 300, 192, True, True),       # ... with the forward's 1-bit mask handed to the backward
                                                        (2, 4, 330, 192, True, True),       # ... an odd number of query tiles (the dK / dV loop runs in pairs)
+                                                       (2, 4, 300, 192, False, True),      # ... batch-first rows (row pitch = one token)
                                                        (2, 3, 333, 64, False, True), (2, 3, 197, 256, False, True),    # (hd = 256: mask ignored)
                                                        (2, 3, 197, 256, False, False), (4, 6, 26, 64, False, False), (3, 4, 100, 192, True, False),
                                                        (3, 3, 27, 256, False, False), (2, 4, 30, 192, True, False)])     # single-launch backward at hd = 192 / 256
