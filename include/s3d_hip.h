@@ -403,10 +403,10 @@ int s3d_stream_wait_event(s3d_stream_t waiting_stream, void* event);
 int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3d_stream_t stream);
 /* NOT part of the operator ABI -- same-process A/B of dispatch alternatives (tools/r6/attn_ab.py): knob ids are private to the library's
  * launchers (0 .. 15), value -1 restores the shipped rule.  The shipped rules quote the measurements these knobs produced.  In use:
- * 0 = 2: the round-5 long-sequence attention forward instead of the pipelined one; 1 = 1 .. 5: timing ablations of the pipelined forward
- * (results wrong); 2 = 0: s3d_encoder_layer_fwd keeps the full split in P V (S3dAttnArgs::p_single_plane off); 3 = 1 .. 8: timing ablations of
- * the long-sequence dK / dV kernel (tuning builds, make EXP=1); 4 = 0: the pipelined forward with per-tile staging addresses (A/B of the
- * uniform-base form). */
+ * 0 = 2: the round-5 long-sequence attention forward instead of the pipelined one; 2 = 0: s3d_encoder_layer_fwd keeps the full split in P V
+ * (S3dAttnArgs::p_single_plane off).  Tuning builds only (make EXP=1; the product library has no kernel that computes wrong results):
+ * 1 = 1 .. 5: timing ablations of the pipelined forward; 3 = 1 .. 8: timing ablations of the long-sequence dK / dV kernel; 4 = 0: the
+ * pipelined forward with per-tile staging addresses (A/B of the uniform-base form). */
 int s3d_debug_knob(int id, int value);
 
 /* ------------------------------------------------------------------------------------------------ timm Block

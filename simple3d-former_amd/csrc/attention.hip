@@ -1807,19 +1807,25 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
         hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, DROP_, MASK_>), g, dim3(256), lds, s, a);                \
     } while (0)
                 if (a.drop_thr && a.drop_mask) {
+                    bool done = false;
+#ifdef S3D_EXPERIMENTAL_TILES      // tuning builds (make EXP=1): timing ablations (wrong results) and the per-tile staging addresses, by knob
                     switch (s3d_knob(1)) {
-#define S3D_ABL(N_) case N_: set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), lds); hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), g, dim3(256), lds, s, a); break;
+#define S3D_ABL(N_) case N_: set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), lds); hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, N_>), g, dim3(256), lds, s, a); done = true; break;
                         S3D_ABL(1) S3D_ABL(2) S3D_ABL(3) S3D_ABL(4) S3D_ABL(5)
 #undef S3D_ABL
-                        default:
-                            if (a.p_single_plane && s3d_knob(4) == 0) {
-                                set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), lds);
-                                hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), g, dim3(256), lds, s, a);
-                            } else if (a.p_single_plane) {
-                                set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), lds);
-                                hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), g, dim3(256), lds, s, a);
-                            } else S3D_PIPE_LAUNCH(true, true);
+                        default: break;
                     }
+                    if (!done && a.p_single_plane && s3d_knob(4) == 0) {
+                        set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), lds);
+                        hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true, false>), g, dim3(256), lds, s, a);
+                        done = true;
+                    }
+#endif
+                    if (done) {
+                    } else if (a.p_single_plane) {
+                        set_lds((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), lds);
+                        hipLaunchKernelGGL((attn_fwd_coop_pipe_kernel<HD, true, true, 0, true>), g, dim3(256), lds, s, a);
+                    } else S3D_PIPE_LAUNCH(true, true);
                 }
                 else if (a.drop_thr) S3D_PIPE_LAUNCH(true, false);
                 else if (a.p_single_plane) {
