@@ -209,6 +209,146 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------- forward, ONE tile (N <= 32) at hd = 256, split
+// The first pass of group_embed (cfg-3): 15-token sequences packed two to a 32-row tile (SEG), 18 816 (pair, head) items per launch, 92 KB of
+// Q / K / V planes each -- a pure stream.  attn_fwd_kernel stages Q, K and V one after the other through the wave's only tile space and sits out
+// three memory round trips per item (0.55 ms per launch = 4.2 TB/s).  Here a wave requests Q AND K (four planes, 64 x 16 bytes per lane) before
+// it waits for anything -- the 256 staging registers are free at that point: no fragments, no output tile yet -- and V as soon as the Q fragments
+// have been read back out of LDS, so that V's round trip runs under the score MFMAs and the softmax.  One exposed round trip per item.
+template <bool SEG>
+__global__ __launch_bounds__(256) void attn_fwd_tile256_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int HD = 256, NS = HD / 16, NDB = HD / 32, PITCH = fwd_pitch(HD), NCH = 16;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int h2 = lane >> 5, l31 = lane & 31;
+    bf16_t* ldsT = reinterpret_cast<bf16_t*>(smem) + wave * (2 * 32 * PITCH);       // [hi plane][lo plane] of the tile in hand
+    const long W = (long)p.Bb * p.H;
+    long item = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    const bool active = item < W;
+    if (!active) item = W - 1;
+    const int bh = (int)item, h = bh % p.H, b = bh / p.H;
+    const long st_ld = p.st * p.ld;
+    const long base = (long)b * p.sb * p.ld + h * HD;
+    const int qrow = l31;
+    const bool qok = qrow < p.N;
+    const int qrow_c = min(qrow, p.N - 1);
+    // chunk i of a plane: tile row 2 i + lane / 32 (clamped to the last token), 16-byte column lane % 32.  Row pairs inside the sequence: a
+    // wave-uniform base advanced by two rows per i + ONE lane offset; the clamped pairs at the end (rows >= N) build theirs per lane
+    const unsigned loff = (unsigned)(((long)h2 * st_ld + l31 * 8) * 2);
+    const int npair = p.N >> 1;                                        // pairs (2 i, 2 i + 1) with both rows < N
+    const long pair_bytes = 4 * st_ld;
+    const char* const gh = reinterpret_cast<const char*>(p.qkv_hi + base), *const gl = reinterpret_cast<const char*>(p.qkv_lo + base);
+    const long kofs = (long)p.D * 2, vofs = (long)p.D * 4;            // bytes from a row's Q to its K / V
+    auto ld = [&](const char* g, int i) -> u32x4 {
+        if (i < npair) return *reinterpret_cast<const u32x4*>(g + i * pair_bytes + loff);      // wave-uniform choice
+        return *reinterpret_cast<const u32x4*>(g + (unsigned)(((long)min(2 * i + h2, p.N - 1) * st_ld + l31 * 8) * 2));
+    };
+    bf16_t* const sdst = ldsT + h2 * PITCH + l31 * 8;
+    auto put = [&](const u32x4 (&rh)[NCH], const u32x4 (&rl)[NCH]) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            *reinterpret_cast<u32x4*>(sdst + 2 * i * PITCH) = rh[i];
+            *reinterpret_cast<u32x4*>(sdst + 32 * PITCH + 2 * i * PITCH) = rl[i];
+        }
+    };
+    u32x4 ah[NCH], al[NCH], bh_[NCH], bl[NCH];                         // a: Q, later V; b: K
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { ah[i] = ld(gh, i); al[i] = ld(gl, i); }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { bh_[i] = ld(gh + kofs, i); bl[i] = ld(gl + kofs, i); }
+    put(ah, al);
+    __builtin_amdgcn_wave_barrier();
+    bf16x8 qh[NS], ql[NS];
+    const int fo = l31 * PITCH + h2 * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        U128 t;
+        t.u = *reinterpret_cast<const u32x4*>(ldsT + fo + 16 * s); qh[s] = t.v;
+        t.u = *reinterpret_cast<const u32x4*>(ldsT + 32 * PITCH + fo + 16 * s); ql[s] = t.v;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { ah[i] = ld(gh + vofs, i); al[i] = ld(gl + vofs, i); }   // V on its way
+    put(bh_, bl);                                                      // K
+    __builtin_amdgcn_wave_barrier();
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        U128 kh, kl;
+        kh.u = *reinterpret_cast<const u32x4*>(ldsT + fo + 16 * s);
+        kl.u = *reinterpret_cast<const u32x4*>(ldsT + 32 * PITCH + fo + 16 * s);
+        sacc = MFMA32(kl.v, qh[s], sacc);
+        sacc = MFMA32(kh.v, ql[s], sacc);
+        sacc = MFMA32(kh.v, qh[s], sacc);
+    }
+    float sv[16], mloc = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool ok = acc_row(r, h2) < p.N && seg_ok<SEG>(p, qrow_c, acc_row(r, h2));
+        sv[r] = ok ? sacc[r] * p.scale : -INFINITY;
+        mloc = fmaxf(mloc, sv[r]);
+    }
+    const float m_i = half_max(mloc);                                  // finite: a row always sees its own segment
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = fast_exp(sv[r] - m_i); lsum += sv[r]; }
+    const float l_i = half_sum(lsum);
+    U128 ph[2], pl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) split_bf16x2(sv[8 * s2 + j], sv[8 * s2 + j + 1], ph[s2].w[j / 2], pl[s2].w[j / 2]);
+    __builtin_amdgcn_wave_barrier();                                   // the K fragments have been read
+    put(ah, al);                                                       // V
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / l_i;
+    f32x16 o[NDB];
+#pragma unroll
+    for (int d = 0; d < NDB; ++d) {
+        bf16x8 vh[2], vl[2];
+        gather_frag_2x2<HD, PITCH>(ldsT, d * 32 + l31, ldsT + 32 * PITCH, d * 32 + l31, h2, vh, vl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            o[d] = MFMA32(vl[s2], ph[s2].v, o[d]);
+            o[d] = MFMA32(vh[s2], pl[s2].v, o[d]);
+            o[d] = MFMA32(vh[s2], ph[s2].v, o[d]);
+        }
+    }
+    // The output leaves through the tile space: a lane owns ONE query row and four consecutive d per register group -- stored from there, an
+    // instruction writes 32 rows x 16 bytes (64 partial lines; measured: 140 of 552 us per launch at the cfg-3 geometry).  Transposed through LDS
+    // it writes two whole 512-byte row segments.
+    __builtin_amdgcn_wave_barrier();                                   // the V fragments have been read
+#pragma unroll
+    for (int d = 0; d < NDB; ++d)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            union { uint2 u; bf16_t h[4]; } hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split_bf16(o[d][4 * c + k] * inv, hi.h[k], lo.h[k]);
+            const int at = l31 * PITCH + d * 32 + 8 * c + 4 * h2;
+            *reinterpret_cast<uint2*>(ldsT + at) = hi.u;
+            *reinterpret_cast<uint2*>(ldsT + 32 * PITCH + at) = lo.u;
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (active) {
+        const long orow0 = (long)b * p.sb * p.ldo + h * HD + l31 * 8;
+#pragma unroll
+        for (int i2 = 0; i2 < NCH; ++i2) {
+            const int r = 2 * i2 + h2;
+            if (r < p.N) {
+                const long off = orow0 + (long)r * p.st * p.ldo;
+                *reinterpret_cast<u32x4*>(p.out_hi + off) = *reinterpret_cast<const u32x4*>(sdst + 2 * i2 * PITCH);
+                if (p.out_lo) *reinterpret_cast<u32x4*>(p.out_lo + off) = *reinterpret_cast<const u32x4*>(sdst + 32 * PITCH + 2 * i2 * PITCH);
+            }
+        }
+    }
+    if (active && qok && h2 == 0 && p.lse) p.lse[(long)bh * p.N + qrow] = m_i + logf(l_i);
+}
+
 // ------------------------------------------------------------------------------------------- backward: dQ (+ delta)
 template <int HD, bool SEG = false>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs p) {
@@ -1867,6 +2007,14 @@ int fwd_hd(const AttnArgs& a_in, bool split, hipStream_t s) {
             set_lds((attn_fwd_kernel<HD, false, false, true>), 4 * 32 * fwd_pitch(HD) * 2);
             hipLaunchKernelGGL((attn_fwd_kernel<HD, false, false, true>), grid, dim3(64 * wpb), wpb * 32 * fwd_pitch(HD) * 2, s, a);
         }
+    } else if (split && HD == 256 && a.N <= 32 && (a.D & 7) == 0 && s3d_knob(8) != 0) {     // one tile: Q and K requested together, V under the scores
+        const int lds = wpb * 2 * 32 * fwd_pitch(256) * 2;
+        set_lds(attn_fwd_tile256_kernel<false>, 4 * 2 * 32 * fwd_pitch(256) * 2);
+        set_lds(attn_fwd_tile256_kernel<true>, 4 * 2 * 32 * fwd_pitch(256) * 2);
+        if (a.seg) hipLaunchKernelGGL((attn_fwd_tile256_kernel<true>), grid, dim3(64 * wpb), lds, s, a);
+        else hipLaunchKernelGGL((attn_fwd_tile256_kernel<false>), grid, dim3(64 * wpb), lds, s, a);
+        S3D_CHECK_LAUNCH_V("attention_fwd_tile256", a.seg ? 1 : 0);
+        return 0;
     } else if (split) {
         const int lds = wpb * 2 * 32 * fwd_pitch(HD) * 2;
         set_lds(attn_fwd_kernel<HD, true>, 4 * 2 * 32 * fwd_pitch(HD) * 2);

@@ -642,7 +642,10 @@ def _attn_ref(q, k, v):
                                                 (3, 4, 20, 192, True), (5, 3, 32, 256, False), (7, 3, 29, 256, False),
                                                 # hd = 192 long sequences, batch-first and seq-first, ragged last tile, odd tile count: the pipelined forward and
                                                 # the cooperative backward with uniform-base staging addresses
-                                                (2, 4, 300, 192, False), (2, 4, 330, 192, True), (1, 4, 97, 192, False)])
+                                                (2, 4, 300, 192, False), (2, 4, 330, 192, True), (1, 4, 97, 192, False),
+                                                # hd = 256, one tile: the forward that requests Q and K together (attn_fwd_tile256_kernel) -- two tokens,
+                                                # odd lengths, a full tile, packed pairs of 16 (N = 32 with two segments), a workgroup with idle waves
+                                                (2, 3, 2, 256, False), (3, 3, 7, 256, False), (5, 3, 16, 256, False), (4, 3, 16, 256, False), (1, 1, 31, 256, False)])
 def test_attention_fwd_bwd(Bb, H, N, hd, seq_first):
     g = torch.Generator().manual_seed(6)
     D = H * hd
