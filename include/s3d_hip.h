@@ -404,7 +404,7 @@ int s3d_debug_paced_copy(void* dst, const void* src, long nbytes, float gbps, s3
 /* NOT part of the operator ABI -- same-process A/B of dispatch alternatives (tools/r6/attn_ab.py): knob ids are private to the library's
  * launchers (0 .. 15), value -1 restores the shipped rule.  The shipped rules quote the measurements these knobs produced.  In use:
  * 0 = 2: the round-5 long-sequence attention forward instead of the pipelined one; 2 = 0: s3d_encoder_layer_fwd keeps the full split in P V
- * (S3dAttnArgs::p_single_plane off).  Tuning builds only (make EXP=1; the product library has no kernel that computes wrong results):
+ * (S3dAttnArgs::p_single_plane off); 8 = 0: the per-wave forward instead of the one-tile kernel at head dim 256, N <= 32.  Tuning builds only (make EXP=1; the product library has no kernel that computes wrong results):
  * 1 = 1 .. 5: timing ablations of the pipelined forward; 3 = 1 .. 8: timing ablations of the long-sequence dK / dV kernel; 4 = 0: the
  * pipelined forward with per-tile staging addresses (A/B of the uniform-base form). */
 int s3d_debug_knob(int id, int value);
