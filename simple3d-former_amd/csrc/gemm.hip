@@ -1332,6 +1332,7 @@ __global__ __launch_bounds__(512) void gemm_nn_fat_kernel(const GemmArgs p, cons
     }
 
     // epilogue: 32 tile rows at a time (the rows of wave row wm = c / 4, blocks 2 (c % 4) and + 1) through a [32][BN + 4] staging tile
+    // (the first prefetch inside the last k-tile, as in gemm_nt_fat_kernel, was measured here too: cfg-3 264.4 against 257.0 ms -- no)
     using SE = StagedEpilogue<EPI, 32, BN, NTHR>;
     constexpr int LDC = BN + 4;
     float* ct = reinterpret_cast<float*>(smem);
@@ -1497,7 +1498,11 @@ __device__ __forceinline__ void glds16_s(unsigned long long sbase, unsigned voff
 }
 
 // DBG (tuning build only, wrong results): the k-loop with one ingredient removed -- 1 no MFMAs, 2 no fragment reads, 3 no DMA
-template <int EPI, int DBG = 0>
+// EARLY: the epilogue operands (residual rows / bias) of the FIRST 32-row chunk are requested inside the last k-step, behind its second (RESID: sixth)
+// MFMA group -- the registers of the A fragments already consumed are free there -- instead of after the loop where their round trip is exposed
+// once per tile.  Same-process A/B on the cfg-3 step (tools/r6/cfg3_knob_ab.py 10): 260.17 against 261.01 ms (four rounds each; 257.07 / 257.83 on
+// another box).  The same move in gemm_nn_fat_kernel cost 7 ms and is not there.
+template <int EPI, int DBG = 0, bool EARLY = true>
 __global__ __launch_bounds__(512) void gemm_nt_fat_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BM = 256, BN = 256, BK = 32, NW = 8, NTHR = 512, WN = 4;
@@ -1567,6 +1572,8 @@ __global__ __launch_bounds__(512) void gemm_nt_fat_kernel(const GemmArgs p) {
     // (a wave sits in the issue stage until the memory pipeline has taken its piece -- ~300 cycles with eight waves issuing; issued as
     // one burst that is 2.4 k cycles per k-step in which the wave feeds no MFMA: in-kernel timeline, 4.7 k cycles per step against
     // 2.3 k for the last step, which has nothing to issue).
+    using SE = StagedEpilogue<EPI, 32, BN, NTHR>;
+    SE se[2];
     TL_REAL(0); TL_HWID(1); TL_STAMP(2);
     issue(0);
     if (ntiles > 1) issue(1);
@@ -1610,17 +1617,16 @@ __global__ __launch_bounds__(512) void gemm_nt_fat_kernel(const GemmArgs p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_hi[j], a_hi[i], c, 0, 0, 0);
             }
             if (pre && DBG != 3) glds16_s(sb, goff[i], dst + i * 1024);
+            if constexpr (EARLY) { if (i == (EPI == EPI_RESID ? 5 : 1) && t == ntiles - 1) se[0].prefetch(p, m0, n0, tid); }   // (RESID holds 32 rows of the residual too: later, when more A fragments are dead)
             __builtin_amdgcn_sched_barrier(0);                         // keep the piece where it was placed
         }
     }
     TL_STAMP(4);
 
     // epilogue: 32 tile rows at a time through a [32][BN + 4] fp32 staging tile (rows 32 c + 16 wm + (lane & 15) of every wave)
-    using SE = StagedEpilogue<EPI, 32, BN, NTHR>;
     constexpr int LDC = BN + 4;
     float* ct = reinterpret_cast<float*>(smem);
-    SE se[2];
-    se[0].prefetch(p, m0, n0, tid);
+    if constexpr (!EARLY) se[0].prefetch(p, m0, n0, tid);
 #pragma unroll
     for (int c = 0; c < FM; ++c) {
         __syncthreads();                                               // k-loop / previous chunk done with the staging tile
@@ -1650,9 +1656,14 @@ int launch_nt_fat(const GemmArgs& a_in, hipStream_t stream) {
     if (dbg == 2) kern = gemm_nt_fat_kernel<EPI, 2>;
     if (dbg == 3) kern = gemm_nt_fat_kernel<EPI, 3>;
 #endif
+#ifdef S3D_EXPERIMENTAL_TILES
+    if (s3d_knob(10) == 0) kern = gemm_nt_fat_kernel<EPI, 0, false>;           // A/B (tools/r6/cfg3_knob_ab.py): the epilogue's first prefetch after the loop
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fat_kernel<EPI, 0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+#endif
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_fat_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (kern != gemm_nt_fat_kernel<EPI>) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
     dim3 grid(a.N / 256, (a.M + 255) / 256, 1);
