@@ -2045,7 +2045,10 @@ int bwd_hd(const AttnArgs& a_in, hipStream_t s, AdamFillQueue* fillq) {
         if (a.N <= 32 && !no_small && (HD <= 96 || !no_small_big)) {
             constexpr int WAVE_LDS = small_bwd_wave_lds(HD);
             constexpr int MAXW = (160 * 1024) / WAVE_LDS >= 4 ? 4 : (160 * 1024) / WAVE_LDS;      // 3 waves per workgroup at hd = 256
-            const int w = wpb < MAXW ? wpb : MAXW;
+            // hd = 256 (cfg-3's first pass): ONE wave per workgroup.  The kernel's only workgroup barrier puts the three waves a CU holds into
+            // lockstep -- all loading, then all computing -- while three single-wave workgroups drift apart and overlap one's arithmetic with the
+            // others' loads: 677 -> 634 us per launch (two waves per workgroup: 740; tools/r6/attn_pass1_ab.py, profiles/r06_attn_pass1.txt)
+            const int w = HD >= 256 ? 1 : (wpb < MAXW ? wpb : MAXW);
             dim3 gs((unsigned)((W + w - 1) / w));
             set_lds(attn_bwd_small_kernel<HD>, MAXW * WAVE_LDS);
             set_lds(attn_bwd_small_kernel<HD, true>, MAXW * WAVE_LDS);
